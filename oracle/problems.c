@@ -1,0 +1,284 @@
+/* problems.c -- NLP instances for the oracle.  TEST INFRASTRUCTURE ONLY.
+ * toy:     /root/reference/test/ext_solver.jl:14-28 laid out as MOI_wrapper.jl:1081-1199 would
+ * readme1: /root/reference/README.md:18-21,37-39
+ * hs071:   Hock-Schittkowski 71 as in MathOptInterface's nonlinear tests (not vendored)
+ * acopf:   PowerModels ACP build_opf shape (test/opf.jl:5-9), SURVEY.md Appendix B, over the
+ *          arrays produced by sqpsolver.jl_amd/acopf_synth.py */
+#include "sqp_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+struct ora_problem {
+    ora_nlp nlp;
+    double *x0;
+    int64_t *jrow, *jcol, *hrow, *hcol;
+    double *xL, *xU, *gL, *gU;
+    /* acopf */
+    int nb, ng, nl, ref_bus;
+    int32_t *f_bus, *t_bus, *gen_bus, *bal_ptr, *bal_colP, *bal_colQ;
+    double *g, *b, *bsh, *c2, *c1, *bal_coef;
+};
+
+static int64_t *i64dup(const int64_t *s, int64_t k)
+{ int64_t *d = (int64_t *)malloc(sizeof(int64_t) * (size_t)(k + 1)); if (k) memcpy(d, s, sizeof(int64_t) * (size_t)k); return d; }
+static int32_t *i32dup(const int32_t *s, int64_t k)
+{ int32_t *d = (int32_t *)malloc(sizeof(int32_t) * (size_t)(k + 1)); if (k) memcpy(d, s, sizeof(int32_t) * (size_t)k); return d; }
+static double *ddup(const double *s, int64_t k)
+{ double *d = (double *)malloc(sizeof(double) * (size_t)(k + 1)); if (k) memcpy(d, s, sizeof(double) * (size_t)k); return d; }
+
+static ora_problem *mk(int64_t n, int64_t m, int64_t nlin, int64_t nnzj, const int64_t *jr,
+                       const int64_t *jc, int64_t nnzh, const int64_t *hr, const int64_t *hc,
+                       const double *xL, const double *xU, const double *gL, const double *gU,
+                       const double *x0)
+{
+    ora_problem *P = (ora_problem *)calloc(1, sizeof(ora_problem));
+    P->jrow = i64dup(jr, nnzj); P->jcol = i64dup(jc, nnzj);
+    P->hrow = i64dup(hr, nnzh); P->hcol = i64dup(hc, nnzh);
+    P->xL = ddup(xL, n); P->xU = ddup(xU, n); P->gL = ddup(gL, m); P->gU = ddup(gU, m);
+    P->x0 = ddup(x0, n);
+    P->nlp.n = n; P->nlp.m = m; P->nlp.num_linear = nlin; P->nlp.nnzj = nnzj; P->nlp.nnzh = nnzh;
+    P->nlp.jrow = P->jrow; P->nlp.jcol = P->jcol; P->nlp.hrow = P->hrow; P->nlp.hcol = P->hcol;
+    P->nlp.xL = P->xL; P->nlp.xU = P->xU; P->nlp.gL = P->gL; P->nlp.gU = P->gU;
+    P->nlp.ud = P;
+    return P;
+}
+const ora_nlp *ora_problem_nlp(const ora_problem *p) { return &p->nlp; }
+const double *ora_problem_x0(const ora_problem *p) { return p->x0; }
+void ora_problem_destroy(ora_problem *P)
+{
+    if (!P) return;
+    void *ptrs[] = { P->x0, P->jrow, P->jcol, P->hrow, P->hcol, P->xL, P->xU, P->gL, P->gU,
+        P->f_bus, P->t_bus, P->gen_bus, P->bal_ptr, P->bal_colP, P->bal_colQ, P->g, P->b, P->bsh,
+        P->c2, P->c1, P->bal_coef };
+    for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) free(ptrs[i]);
+    free(P);
+}
+
+/* ------------------------------------------------------------------ toy (ext_solver.jl) */
+static double toy_f(void *u, const double *x) { (void)u; return x[0] * x[0] + x[0]; }
+static void toy_df(void *u, const double *x, double *g) { (void)u; g[0] = 2 * x[0] + 1; g[1] = 0; }
+static void toy_g(void *u, const double *x, double *g)
+{ (void)u; g[0] = x[0]; g[1] = x[0] * x[0] - x[0] - 2; g[2] = x[0] * x[1] - 1; g[3] = x[0] * x[1]; }
+static void toy_jac(void *u, const double *x, double *v)
+{ (void)u; v[0] = 1; v[1] = 2 * x[0] - 1; v[2] = x[1]; v[3] = x[0]; v[4] = x[1]; v[5] = x[0]; }
+static void toy_h(void *u, const double *x, double s, const double *l, double *v)
+{ (void)u; (void)x; v[0] = 2 * s; v[1] = 2 * l[1]; v[2] = l[2]; v[3] = l[3]; }
+
+ora_problem *ora_problem_toy(void)
+{
+    int64_t jr[] = {1, 2, 3, 3, 4, 4}, jc[] = {1, 1, 1, 2, 1, 2};
+    int64_t hr[] = {1, 1, 2, 2}, hc[] = {1, 1, 1, 1};
+    double xL[] = {-INFINITY, -INFINITY}, xU[] = {INFINITY, INFINITY};
+    double gL[] = {-2, 0, 0, 0}, gU[] = {INFINITY, 0, 0, INFINITY};
+    double x0[] = {0, 0};
+    ora_problem *P = mk(2, 4, 1, 6, jr, jc, 4, hr, hc, xL, xU, gL, gU, x0);
+    P->nlp.eval_f = toy_f; P->nlp.eval_grad_f = toy_df; P->nlp.eval_g = toy_g;
+    P->nlp.eval_jac_g = toy_jac; P->nlp.eval_h = toy_h;
+    return P;
+}
+
+/* ------------------------------------------------------------------ README one-variable */
+static double r1_f(void *u, const double *x) { (void)u; return x[0] * x[0] + x[0]; }
+static void r1_df(void *u, const double *x, double *g) { (void)u; g[0] = 2 * x[0] + 1; }
+static void r1_g(void *u, const double *x, double *g) { (void)u; g[0] = x[0] * x[0] - x[0] - 2; }
+static void r1_jac(void *u, const double *x, double *v) { (void)u; v[0] = 2 * x[0] - 1; }
+static void r1_h(void *u, const double *x, double s, const double *l, double *v)
+{ (void)u; (void)x; v[0] = 2 * s; v[1] = 2 * l[0]; }
+
+ora_problem *ora_problem_readme1(void)
+{
+    int64_t jr[] = {1}, jc[] = {1}, hr[] = {1, 1}, hc[] = {1, 1};
+    double xL[] = {-INFINITY}, xU[] = {INFINITY}, gL[] = {0}, gU[] = {0}, x0[] = {0};
+    ora_problem *P = mk(1, 1, 0, 1, jr, jc, 2, hr, hc, xL, xU, gL, gU, x0);
+    P->nlp.eval_f = r1_f; P->nlp.eval_grad_f = r1_df; P->nlp.eval_g = r1_g;
+    P->nlp.eval_jac_g = r1_jac; P->nlp.eval_h = r1_h;
+    return P;
+}
+
+/* ------------------------------------------------------------------ HS071 */
+static double hs_f(void *u, const double *x) { (void)u; return x[0] * x[3] * (x[0] + x[1] + x[2]) + x[2]; }
+static void hs_df(void *u, const double *x, double *g)
+{
+    (void)u;
+    g[0] = x[3] * (2 * x[0] + x[1] + x[2]); g[1] = x[0] * x[3];
+    g[2] = x[0] * x[3] + 1; g[3] = x[0] * (x[0] + x[1] + x[2]);
+}
+static void hs_g(void *u, const double *x, double *g)
+{ (void)u; g[0] = x[0] * x[1] * x[2] * x[3]; g[1] = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]; }
+static void hs_jac(void *u, const double *x, double *v)
+{
+    (void)u;
+    v[0] = x[1] * x[2] * x[3]; v[1] = x[0] * x[2] * x[3]; v[2] = x[0] * x[1] * x[3]; v[3] = x[0] * x[1] * x[2];
+    for (int i = 0; i < 4; ++i) v[4 + i] = 2 * x[i];
+}
+static void hs_h(void *u, const double *x, double s, const double *l, double *v)
+{
+    (void)u;
+    /* lower triangle row-major: (1,1),(2,1),(2,2),(3,1),(3,2),(3,3),(4,1),(4,2),(4,3),(4,4) */
+    v[0] = s * 2 * x[3] + l[1] * 2;
+    v[1] = s * x[3] + l[0] * x[2] * x[3];
+    v[2] = l[1] * 2;
+    v[3] = s * x[3] + l[0] * x[1] * x[3];
+    v[4] = l[0] * x[0] * x[3];
+    v[5] = l[1] * 2;
+    v[6] = s * (2 * x[0] + x[1] + x[2]) + l[0] * x[1] * x[2];
+    v[7] = s * x[0] + l[0] * x[0] * x[2];
+    v[8] = s * x[0] + l[0] * x[0] * x[1];
+    v[9] = l[1] * 2;
+}
+ora_problem *ora_problem_hs071(void)
+{
+    int64_t jr[] = {1, 1, 1, 1, 2, 2, 2, 2}, jc[] = {1, 2, 3, 4, 1, 2, 3, 4};
+    int64_t hr[] = {1, 2, 2, 3, 3, 3, 4, 4, 4, 4}, hc[] = {1, 1, 2, 1, 2, 3, 1, 2, 3, 4};
+    double xL[] = {1, 1, 1, 1}, xU[] = {5, 5, 5, 5};
+    double gL[] = {25, 40}, gU[] = {INFINITY, 40}, x0[] = {1, 5, 5, 1};
+    ora_problem *P = mk(4, 2, 0, 8, jr, jc, 10, hr, hc, xL, xU, gL, gU, x0);
+    P->nlp.eval_f = hs_f; P->nlp.eval_grad_f = hs_df; P->nlp.eval_g = hs_g;
+    P->nlp.eval_jac_g = hs_jac; P->nlp.eval_h = hs_h;
+    return P;
+}
+
+/* ------------------------------------------------------------------ ACOPF (polar, ACP shape) */
+/* Row k of branch l:  flow_k - F_k,  F_k = A_k v_self^2 + vf vt (Bc_k cos th + Bs_k sin th) */
+static void ohm_coef(const ora_problem *P, int l, int k, double *A, double *Bc, double *Bs, int *self_t)
+{
+    double g = P->g[l], b = P->b[l], bs = P->bsh[l];
+    switch (k) {
+    case 0: *A = g; *Bc = -g; *Bs = -b; *self_t = 0; break;
+    case 1: *A = -(b + bs); *Bc = b; *Bs = -g; *self_t = 0; break;
+    case 2: *A = g; *Bc = -g; *Bs = b; *self_t = 1; break;
+    default: *A = -(b + bs); *Bc = b; *Bs = g; *self_t = 1; break;
+    }
+}
+#define IDX(P) \
+    const int nb = (P)->nb, ng = (P)->ng, nl = (P)->nl; \
+    const int VA = 0, VM = nb, PG = 2 * nb, QG = 2 * nb + ng, PF = 2 * nb + 2 * ng; \
+    const int PT = PF + nl, QF = PF + 2 * nl, QT = PF + 3 * nl; \
+    const int T0 = 2 * nl + 1 + 2 * nb, O0 = T0 + 2 * nl; \
+    (void)VA; (void)VM; (void)PG; (void)QG; (void)PT; (void)QF; (void)QT; (void)T0; (void)O0;
+
+static double ac_f(void *u, const double *x)
+{
+    const ora_problem *P = (const ora_problem *)u; IDX(P)
+    double f = 0.0;
+    for (int g = 0; g < ng; ++g) f += P->c2[g] * x[PG + g] * x[PG + g] + P->c1[g] * x[PG + g];
+    return f;
+}
+static void ac_df(void *u, const double *x, double *gr)
+{
+    const ora_problem *P = (const ora_problem *)u; IDX(P)
+    memset(gr, 0, sizeof(double) * (size_t)P->nlp.n);
+    for (int g = 0; g < ng; ++g) gr[PG + g] = 2 * P->c2[g] * x[PG + g] + P->c1[g];
+}
+static void ac_g(void *u, const double *x, double *gv)
+{
+    const ora_problem *P = (const ora_problem *)u; IDX(P)
+    const int own[4] = { PF, QF, PT, QT };
+    for (int l = 0; l < nl; ++l) {
+        double th = x[VA + P->f_bus[l]] - x[VA + P->t_bus[l]];
+        gv[l] = th; gv[nl + l] = th;
+    }
+    gv[2 * nl] = x[VA + P->ref_bus];
+    for (int i = 0; i < nb; ++i) {
+        double sp = 0.0, sq = 0.0;
+        for (int k = P->bal_ptr[i]; k < P->bal_ptr[i + 1]; ++k) {
+            sp += P->bal_coef[k] * x[P->bal_colP[k]];
+            sq += P->bal_coef[k] * x[P->bal_colQ[k]];
+        }
+        gv[2 * nl + 1 + 2 * i] = sp; gv[2 * nl + 2 + 2 * i] = sq;
+    }
+    for (int l = 0; l < nl; ++l) {
+        gv[T0 + 2 * l] = x[PF + l] * x[PF + l] + x[QF + l] * x[QF + l];
+        gv[T0 + 2 * l + 1] = x[PT + l] * x[PT + l] + x[QT + l] * x[QT + l];
+        double vf = x[VM + P->f_bus[l]], vt = x[VM + P->t_bus[l]];
+        double th = x[VA + P->f_bus[l]] - x[VA + P->t_bus[l]], C = cos(th), S = sin(th);
+        for (int k = 0; k < 4; ++k) {
+            double A, Bc, Bs; int st; ohm_coef(P, l, k, &A, &Bc, &Bs, &st);
+            double vs = st ? vt : vf;
+            gv[O0 + 4 * l + k] = x[own[k] + l] - (A * vs * vs + vf * vt * (Bc * C + Bs * S));
+        }
+    }
+}
+static void ac_jac(void *u, const double *x, double *v)
+{
+    const ora_problem *P = (const ora_problem *)u; IDX(P)
+    int64_t o = 0;
+    for (int rep = 0; rep < 2; ++rep) for (int l = 0; l < nl; ++l) { v[o++] = 1.0; v[o++] = -1.0; }
+    v[o++] = 1.0;
+    for (int i = 0; i < nb; ++i) {
+        int s = P->bal_ptr[i], e = P->bal_ptr[i + 1];
+        for (int k = s; k < e; ++k) v[o++] = P->bal_coef[k];
+        for (int k = s; k < e; ++k) v[o++] = P->bal_coef[k];
+    }
+    for (int l = 0; l < nl; ++l) { v[o++] = 2 * x[PF + l]; v[o++] = 2 * x[QF + l]; }
+    for (int l = 0; l < nl; ++l) { v[o++] = 2 * x[PT + l]; v[o++] = 2 * x[QT + l]; }
+    for (int k = 0; k < 4; ++k)
+        for (int l = 0; l < nl; ++l) {
+            double vf = x[VM + P->f_bus[l]], vt = x[VM + P->t_bus[l]];
+            double th = x[VA + P->f_bus[l]] - x[VA + P->t_bus[l]], C = cos(th), S = sin(th);
+            double A, Bc, Bs; int st; ohm_coef(P, l, k, &A, &Bc, &Bs, &st);
+            double T0v = Bc * C + Bs * S, T1 = -Bc * S + Bs * C, uu = vf * vt;
+            v[o++] = 1.0;
+            v[o++] = -(uu * T1);
+            v[o++] = uu * T1;
+            v[o++] = -((st ? 0.0 : 2 * A * vf) + vt * T0v);
+            v[o++] = -((st ? 2 * A * vt : 0.0) + vf * T0v);
+        }
+}
+static void ac_h(void *u, const double *x, double sig, const double *lam, double *v)
+{
+    const ora_problem *P = (const ora_problem *)u; IDX(P)
+    int64_t o = 0;
+    for (int g = 0; g < ng; ++g) v[o++] = sig * 2 * P->c2[g];
+    for (int l = 0; l < nl; ++l) { double w = 2 * lam[T0 + 2 * l]; v[o++] = w; v[o++] = w; }
+    for (int l = 0; l < nl; ++l) { double w = 2 * lam[T0 + 2 * l + 1]; v[o++] = w; v[o++] = w; }
+    for (int k = 0; k < 4; ++k) {
+        double *blk = v + o + (int64_t)k * 10 * nl;
+        for (int l = 0; l < nl; ++l) {
+            double vf = x[VM + P->f_bus[l]], vt = x[VM + P->t_bus[l]];
+            double th = x[VA + P->f_bus[l]] - x[VA + P->t_bus[l]], C = cos(th), S = sin(th);
+            double A, Bc, Bs; int st; ohm_coef(P, l, k, &A, &Bc, &Bs, &st);
+            double T0v = Bc * C + Bs * S, T1 = -Bc * S + Bs * C, uu = vf * vt;
+            double w = -lam[O0 + 4 * l + k];       /* row = flow - F  =>  Hess(row) = -Hess(F) */
+            blk[0 * nl + l] = w * (-uu * T0v);     /* va_f va_f */
+            blk[1 * nl + l] = w * (uu * T0v);      /* va_t va_f */
+            blk[2 * nl + l] = w * (-uu * T0v);     /* va_t va_t */
+            blk[3 * nl + l] = w * (vt * T1);       /* vm_f va_f */
+            blk[4 * nl + l] = w * (-vt * T1);      /* vm_f va_t */
+            blk[5 * nl + l] = w * (st ? 0.0 : 2 * A); /* vm_f vm_f */
+            blk[6 * nl + l] = w * (vf * T1);       /* vm_t va_f */
+            blk[7 * nl + l] = w * (-vf * T1);      /* vm_t va_t */
+            blk[8 * nl + l] = w * T0v;             /* vm_t vm_f */
+            blk[9 * nl + l] = w * (st ? 2 * A : 0.0); /* vm_t vm_t */
+        }
+    }
+}
+
+ora_problem *ora_problem_acopf(int nb, int ng, int nl, const int32_t *f_bus,
+                               const int32_t *t_bus, const double *g, const double *b,
+                               const double *bsh, const int32_t *gen_bus, const double *c2,
+                               const double *c1, const int32_t *bal_ptr, const int32_t *bal_colP,
+                               const int32_t *bal_colQ, const double *bal_coef,
+                               int64_t nnzj, const int64_t *jrow, const int64_t *jcol,
+                               int64_t nnzh, const int64_t *hrow, const int64_t *hcol,
+                               const double *xL, const double *xU, const double *gL,
+                               const double *gU)
+{
+    int64_t n = 2 * nb + 2 * ng + 4 * nl, m = 1 + 2 * nb + 8 * nl;
+    double *x0 = (double *)calloc((size_t)n, sizeof(double));
+    ora_problem *P = mk(n, m, 2 * nl + 1 + 2 * nb, nnzj, jrow, jcol, nnzh, hrow, hcol, xL, xU, gL, gU, x0);
+    free(x0);
+    P->nb = nb; P->ng = ng; P->nl = nl;
+    P->ref_bus = (int)(jcol[4 * nl] - 1);
+    P->f_bus = i32dup(f_bus, nl); P->t_bus = i32dup(t_bus, nl); P->gen_bus = i32dup(gen_bus, ng);
+    P->bal_ptr = i32dup(bal_ptr, nb + 1);
+    int64_t nbal = bal_ptr[nb];
+    P->bal_colP = i32dup(bal_colP, nbal); P->bal_colQ = i32dup(bal_colQ, nbal);
+    P->bal_coef = ddup(bal_coef, nbal);
+    P->g = ddup(g, nl); P->b = ddup(b, nl); P->bsh = ddup(bsh, nl);
+    P->c2 = ddup(c2, ng); P->c1 = ddup(c1, ng);
+    P->nlp.eval_f = ac_f; P->nlp.eval_grad_f = ac_df; P->nlp.eval_g = ac_g;
+    P->nlp.eval_jac_g = ac_jac; P->nlp.eval_h = ac_h;
+    return P;
+}

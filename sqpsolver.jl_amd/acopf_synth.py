@@ -1,0 +1,321 @@
+"""Synthetic ACOPF-shaped NLP instances (input data for the hot path).
+
+The reference never ships ACOPF data besides a 3-bus file
+(/root/reference/examples/acopf/case3.m) and builds its ACOPF models through the
+un-vendored PowerModels.jl (`ACPPowerModel` + `build_opf`,
+/root/reference/test/opf.jl:5-9, /root/reference/examples/acopf/opf.jl:12-46).
+This module generates networks of the IEEE-14/118/1354/9241 *shape* and lays the
+NLP out the way `SqpSolver.Optimizer` would see it
+(/root/reference/src/MOI_wrapper.jl:759-766 row ordering, :1083-1086 linear-row
+count, :930-945 Jacobian COO, :1010-1025 Hessian COO with duplicates).
+
+Pure numpy, deterministic per seed (PCG64).  This is *data synthesis*: both the
+CPU oracle and the HIP evaluator consume the same arrays.
+
+Variable order (PowerModels creation order):
+    va[nb], vm[nb], pg[ng], qg[ng], p_f[nl], p_t[nl], q_f[nl], q_t[nl]
+Row order (0-based blocks):
+    [0, nl)            angle difference  va_f - va_t <= angmax      (linear <=)
+    [nl, 2nl)          angle difference  va_f - va_t >= angmin      (linear >=)
+    2nl                reference angle   va_ref == 0                (linear ==)
+    2nl+1+2i, +1       bus i active / reactive balance              (linear ==)
+    T0 + 2l, +1        thermal limit from / to end  p^2+q^2 <= s^2  (quadratic <=)
+    O0 + 4l + {0..3}   Ohm's law p_f, q_f, p_t, q_t                 (NLP block, ==0)
+with T0 = 2nl+1+2nb, O0 = T0+2nl;  n = 2nb+2ng+4nl,  m = 1+2nb+8nl.
+"""
+from __future__ import annotations
+
+import dataclasses
+import numpy as np
+
+__all__ = ["Network", "acopf_synth", "contingency", "NlpLayout", "acopf_layout",
+           "CASES"]
+
+# nb, ng, nl per SURVEY.md section 8 table
+CASES = {
+    "case14": (14, 5, 20, 14),
+    "case118": (118, 54, 186, 118),
+    "case1354": (1354, 260, 1991, 1354),
+    "case9241": (9241, 1445, 16049, 9241),
+}
+
+
+@dataclasses.dataclass
+class Network:
+    nb: int
+    ng: int
+    nl: int
+    # buses
+    pd: np.ndarray
+    qd: np.ndarray
+    vmin: np.ndarray
+    vmax: np.ndarray
+    ref_bus: int
+    # generators
+    gen_bus: np.ndarray      # int32 [ng]
+    pmin: np.ndarray
+    pmax: np.ndarray
+    qmin: np.ndarray
+    qmax: np.ndarray
+    c2: np.ndarray           # cost in per-unit variables: c2*pg^2 + c1*pg
+    c1: np.ndarray
+    # branches
+    f_bus: np.ndarray        # int32 [nl]
+    t_bus: np.ndarray
+    r: np.ndarray
+    x: np.ndarray
+    bc: np.ndarray           # total line charging susceptance
+    rate_a: np.ndarray
+    angmin: np.ndarray
+    angmax: np.ndarray
+    status: np.ndarray       # 1.0 in service, 0.0 outaged (admittance zeroed, pattern kept)
+
+    def branch_coeffs(self):
+        """Per-branch Ohm's-law coefficients (tap=1, shift=0), SURVEY.md App. B.
+
+        p_f = gff*vm_f^2 + (-g)*vm_f*vm_t*cos(th) + (-b)*vm_f*vm_t*sin(th)
+        q_f = -bff*vm_f^2 - (-b)*vm_f*vm_t*cos(th) + (-g)*vm_f*vm_t*sin(th)
+        (to-end: same with th -> -th and f<->t)
+        Returned array [nl, 4] = (g, b, gff=g, bff=b+bc/2) scaled by status.
+        """
+        z2 = self.r ** 2 + self.x ** 2
+        g = self.r / z2 * self.status
+        b = -self.x / z2 * self.status
+        bsh = 0.5 * self.bc * self.status
+        return np.stack([g, b, bsh], axis=1)
+
+
+def _bridges(nb, f, t):
+    """Indices of branches whose removal disconnects the graph (iterative DFS)."""
+    adj = [[] for _ in range(nb)]
+    for k, (a, b) in enumerate(zip(f, t)):
+        adj[a].append((b, k))
+        adj[b].append((a, k))
+    disc = [-1] * nb
+    low = [0] * nb
+    out = set()
+    timer = 0
+    for root in range(nb):
+        if disc[root] != -1:
+            continue
+        stack = [(root, -1, 0)]
+        disc[root] = low[root] = timer
+        timer += 1
+        while stack:
+            u, pe, i = stack.pop()
+            if i < len(adj[u]):
+                stack.append((u, pe, i + 1))
+                v, k = adj[u][i]
+                if k == pe:
+                    continue
+                if disc[v] == -1:
+                    disc[v] = low[v] = timer
+                    timer += 1
+                    stack.append((v, k, 0))
+                else:
+                    low[u] = min(low[u], disc[v])
+            else:
+                if stack:
+                    par = stack[-1][0]
+                    low[par] = min(low[par], low[u])
+                    if low[u] > disc[par]:
+                        out.add(pe)
+    return out
+
+
+def acopf_synth(nb: int, ng: int, nl: int, seed: int, load_scale: float = 1.0) -> Network:
+    """Connected synthetic transmission network."""
+    assert nl >= nb - 1 and ng <= nb
+    rng = np.random.default_rng(seed)
+    edges = set()
+    f_bus, t_bus = [], []
+    # random spanning tree with locally biased parents
+    for i in range(1, nb):
+        back = int(min(i - 1, np.floor(rng.exponential(2.0))))
+        j = i - 1 - back
+        edges.add((j, i))
+        f_bus.append(j)
+        t_bus.append(i)
+    # locally biased chords
+    while len(f_bus) < nl:
+        a = int(rng.integers(0, nb - 1))
+        b = a + 1 + int(np.floor(rng.exponential(4.0)))
+        if b >= nb or (a, b) in edges:
+            continue
+        edges.add((a, b))
+        f_bus.append(a)
+        t_bus.append(b)
+    f_bus = np.asarray(f_bus, dtype=np.int32)
+    t_bus = np.asarray(t_bus, dtype=np.int32)
+    r = rng.uniform(0.005, 0.05, nl)
+    x = np.maximum(rng.uniform(0.05, 0.3, nl), 3.0 * r)
+    bc = rng.uniform(0.0, 0.1, nl)
+    pd = rng.uniform(0.1, 1.0, nb) * load_scale
+    qd = 0.3 * pd
+    gen_bus = np.sort(rng.choice(nb, size=ng, replace=False)).astype(np.int32)
+    w = rng.uniform(0.5, 1.5, ng)
+    pmax = 1.6 * pd.sum() * w / w.sum()
+    pmin = np.zeros(ng)
+    qmax = 0.6 * pmax
+    qmin = -0.6 * pmax
+    base = 100.0
+    c2 = rng.uniform(0.01, 0.1, ng) * base * base
+    c1 = rng.uniform(10.0, 40.0, ng) * base
+    # thermal ratings from a DC power flow with proportional dispatch
+    pg0 = pmax * (pd.sum() / pmax.sum())
+    inj = -pd.copy()
+    np.add.at(inj, gen_bus, pg0)
+    B = np.zeros((nb, nb))
+    for a, b, xx in zip(f_bus, t_bus, x):
+        B[a, a] += 1 / xx
+        B[b, b] += 1 / xx
+        B[a, b] -= 1 / xx
+        B[b, a] -= 1 / xx
+    theta = np.zeros(nb)
+    theta[1:] = np.linalg.solve(B[1:, 1:], inj[1:])
+    flow = (theta[f_bus] - theta[t_bus]) / x
+    rate_a = 1.5 * np.abs(flow) + 0.3 * max(1.0, float(np.median(np.abs(flow))))
+    ang = np.full(nl, np.pi / 6)
+    return Network(
+        nb=nb, ng=ng, nl=nl, pd=pd, qd=qd,
+        vmin=np.full(nb, 0.94), vmax=np.full(nb, 1.06), ref_bus=0,
+        gen_bus=gen_bus, pmin=pmin, pmax=pmax, qmin=qmin, qmax=qmax, c2=c2, c1=c1,
+        f_bus=f_bus, t_bus=t_bus, r=r, x=x, bc=bc, rate_a=rate_a,
+        angmin=-ang, angmax=ang.copy(), status=np.ones(nl),
+    )
+
+
+def contingency(net: Network, s: int, base_seed: int) -> Network:
+    """Scenario `s` of a base network: outage of non-bridge branch ~ s mod nl with the
+    admittance zeroed (sparsity pattern shared) and loads scaled by U(0.9,1.1)
+    drawn from seed base_seed*1000+s."""
+    br = _bridges(net.nb, net.f_bus, net.t_bus)
+    k = s % net.nl
+    while k in br:
+        k = (k + 1) % net.nl
+    rng = np.random.default_rng(base_seed * 1000 + s)
+    scale = rng.uniform(0.9, 1.1)
+    out = dataclasses.replace(
+        net, pd=net.pd * scale, qd=net.qd * scale, status=net.status.copy())
+    out.status[k] = 0.0
+    return out
+
+
+@dataclasses.dataclass
+class NlpLayout:
+    """What `SqpSolver.Model` holds (/root/reference/src/model.jl:3-35) for an ACOPF."""
+    n: int
+    m: int
+    num_linear: int
+    jrow: np.ndarray   # int64, 1-based COO (Julia-native)
+    jcol: np.ndarray
+    hrow: np.ndarray   # int64, 1-based lower-triangular COO with duplicates
+    hcol: np.ndarray
+    xL: np.ndarray
+    xU: np.ndarray
+    gL: np.ndarray
+    gU: np.ndarray
+    x0: np.ndarray
+    # balance-row incidence in CSR form (bus -> list of (col, coef)) for the evaluators
+    bal_ptr: np.ndarray   # int32 [nb+1]
+    bal_colP: np.ndarray  # int32 column of the P-row entry
+    bal_colQ: np.ndarray  # int32 column of the Q-row entry
+    bal_coef: np.ndarray  # +1 arc, -1 generator
+
+
+def acopf_layout(net: Network) -> NlpLayout:
+    nb, ng, nl = net.nb, net.ng, net.nl
+    n = 2 * nb + 2 * ng + 4 * nl
+    m = 1 + 2 * nb + 8 * nl
+    VA, VM, PG, QG = 0, nb, 2 * nb, 2 * nb + ng
+    PF = 2 * nb + 2 * ng
+    PT, QF, QT = PF + nl, PF + 2 * nl, PF + 3 * nl
+    T0 = 2 * nl + 1 + 2 * nb
+    O0 = T0 + 2 * nl
+    f, t = net.f_bus.astype(np.int64), net.t_bus.astype(np.int64)
+    L = np.arange(nl, dtype=np.int64)
+
+    jr, jc = [], []
+    # angle <= and >= rows: (va_f, +1), (va_t, -1)
+    for off in (0, nl):
+        jr.append(np.repeat(off + L, 2))
+        jc.append(np.stack([VA + f, VA + t], axis=1).ravel())
+    # reference angle
+    jr.append(np.array([2 * nl]))
+    jc.append(np.array([VA + net.ref_bus]))
+    # balance rows: arcs at the bus (branch order: from-end then to-end per branch), then gens
+    inc = [[] for _ in range(nb)]
+    for l in range(nl):
+        inc[int(f[l])].append((PF + l, QF + l, 1.0))
+        inc[int(t[l])].append((PT + l, QT + l, 1.0))
+    for g in range(ng):
+        inc[int(net.gen_bus[g])].append((PG + g, QG + g, -1.0))
+    bal_ptr = np.zeros(nb + 1, dtype=np.int32)
+    colP, colQ, coef = [], [], []
+    for i in range(nb):
+        bal_ptr[i + 1] = bal_ptr[i] + len(inc[i])
+        for cp, cq, cf in inc[i]:
+            colP.append(cp)
+            colQ.append(cq)
+            coef.append(cf)
+    colP = np.asarray(colP, dtype=np.int64)
+    colQ = np.asarray(colQ, dtype=np.int64)
+    for i in range(nb):
+        s, e = bal_ptr[i], bal_ptr[i + 1]
+        jr.append(np.full(e - s, 2 * nl + 1 + 2 * i))
+        jc.append(colP[s:e])
+        jr.append(np.full(e - s, 2 * nl + 2 + 2 * i))
+        jc.append(colQ[s:e])
+    # thermal rows: from (p_f, q_f), to (p_t, q_t)
+    jr.append(np.repeat(T0 + 2 * L, 2)); jc.append(np.stack([PF + L, QF + L], 1).ravel())
+    jr.append(np.repeat(T0 + 2 * L + 1, 2)); jc.append(np.stack([PT + L, QT + L], 1).ravel())
+    # interleave thermal from/to per branch to keep creation order
+    # (rows are T0+2l and T0+2l+1; COO order need not be sorted)
+    # Ohm rows: own flow var, va_f, va_t, vm_f, vm_t
+    own = [PF, QF, PT, QT]
+    for k in range(4):
+        jr.append(np.repeat(O0 + 4 * L + k, 5))
+        jc.append(np.stack([own[k] + L, VA + f, VA + t, VM + f, VM + t], 1).ravel())
+    jrow = np.concatenate(jr).astype(np.int64) + 1
+    jcol = np.concatenate(jc).astype(np.int64) + 1
+
+    # Hessian COO (lower triangle, duplicates kept): objective, thermal, Ohm
+    hr, hc = [], []
+    G = np.arange(ng, dtype=np.int64)
+    hr.append(PG + G); hc.append(PG + G)
+    for base_p, base_q in ((PF, QF), (PT, QT)):
+        hr.append(np.stack([base_p + L, base_q + L], 1).ravel())
+        hc.append(np.stack([base_p + L, base_q + L], 1).ravel())
+    # per Ohm row the 10 lower-triangular entries of the 4x4 block on (va_f, va_t, vm_f, vm_t)
+    v4 = np.stack([VA + f, VA + t, VM + f, VM + t], 1)  # [nl,4]
+    pairs = [(a, b) for a in range(4) for b in range(a + 1)]
+    for k in range(4):
+        for a, b in pairs:
+            ia, ib = v4[:, a], v4[:, b]
+            hr.append(np.maximum(ia, ib))
+            hc.append(np.minimum(ia, ib))
+    hrow = np.concatenate(hr).astype(np.int64) + 1
+    hcol = np.concatenate(hc).astype(np.int64) + 1
+
+    inf = np.inf
+    xL = np.concatenate([np.full(nb, -inf), net.vmin, net.pmin, net.qmin,
+                         -net.rate_a, -net.rate_a, -net.rate_a, -net.rate_a])
+    xU = np.concatenate([np.full(nb, inf), net.vmax, net.pmax, net.qmax,
+                         net.rate_a, net.rate_a, net.rate_a, net.rate_a])
+    gL = np.empty(m); gU = np.empty(m)
+    gL[0:nl] = -inf; gU[0:nl] = net.angmax
+    gL[nl:2 * nl] = net.angmin; gU[nl:2 * nl] = inf
+    gL[2 * nl] = gU[2 * nl] = 0.0
+    gL[2 * nl + 1:T0:2] = -net.pd; gU[2 * nl + 1:T0:2] = -net.pd
+    gL[2 * nl + 2:T0:2] = -net.qd; gU[2 * nl + 2:T0:2] = -net.qd
+    gL[T0:O0] = -inf
+    gU[T0:O0:2] = net.rate_a ** 2; gU[T0 + 1:O0:2] = net.rate_a ** 2
+    gL[O0:] = 0.0; gU[O0:] = 0.0
+    # start: midpoint of finite boxes, 0 otherwise
+    # (/root/reference/examples/acopf/init_opf.jl:25-47)
+    x0 = np.where(np.isfinite(xL) & np.isfinite(xU), 0.5 * (xL + xU), 0.0)
+    x0[VM:VM + nb] = 1.0
+    return NlpLayout(n=n, m=m, num_linear=T0, jrow=jrow, jcol=jcol, hrow=hrow, hcol=hcol,
+                     xL=xL, xU=xU, gL=gL, gU=gU, x0=x0,
+                     bal_ptr=bal_ptr, bal_colP=colP.astype(np.int32),
+                     bal_colQ=colQ.astype(np.int32), bal_coef=np.asarray(coef))
