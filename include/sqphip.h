@@ -1,0 +1,179 @@
+/*
+ * sqphip.h -- C ABI of libsqphip.so, the MI355X (gfx950) hot path behind SqpSolver.Optimizer.
+ *
+ * What it replaces in /root/reference (exanauts/SqpSolver.jl):
+ *   - the per-iteration QP sub-problem that `SqpTR` delegates to `external_optimizer` through
+ *     `QpJuMP` (src/algorithms/subproblem_JuMP.jl:127-183 QP, :185-244 LP phase, :283-347 L1QP,
+ *     :352-393 feasibility restoration, :398-429 INFEAS, :432-463 trust-region bounds,
+ *     :514-563 collect_solution!), i.e. the `AbstractSubOptimizer` seat of
+ *     src/algorithms/subproblem.jl:1-28 as dispatched by src/algorithms/sqp_trust_region.jl:314-331;
+ *   - the merit / step-acceptance path of src/algorithms: common.jl:14-77, merit.jl:13-17,
+ *     sqp.jl:170-213, sqp_trust_region.jl:370-380 and :487-579.
+ * The Julia host (MOI_wrapper.jl, model.jl) stays; it reaches this library through `ccall`
+ * (binding shown in INTEGRATION.md).  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative SQPHIP_E* code on misuse / HIP failure;
+ *     nothing throws across the ABI; sqphip_last_error() gives the message.
+ *   - solver outcomes are MOI.TerminationStatusCode integers (sub-problem) and the Ipopt-style
+ *     codes of src/status.jl:2-23 (whole solve).
+ *   - all arrays are caller-owned HOST memory unless the name ends in _dev; indices are 1-based
+ *     (Julia-native) at the boundary.
+ *   - multipliers use the JuMP sign convention exactly as collect_solution! returns them
+ *     (mult_x_U <= 0 <= mult_x_L; stationarity H p + c = J'lambda + mult_x_L + mult_x_U).
+ *   - one HIP stream per context; a context is not thread-safe, distinct contexts are.
+ */
+#ifndef SQPHIP_H
+#define SQPHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sqphip_ctx sqphip_ctx;
+
+enum { SQPHIP_OK = 0, SQPHIP_EINVAL = -1, SQPHIP_EHIP = -2, SQPHIP_ENOMEM = -3, SQPHIP_ESTATE = -4 };
+
+/* sub-problem modes (subproblem_JuMP.jl line ranges above) */
+enum { SQPHIP_MODE_QP = 0, SQPHIP_MODE_FR = 1, SQPHIP_MODE_SOC = 2, SQPHIP_MODE_LP = 3,
+       SQPHIP_MODE_L1QP = 4, SQPHIP_MODE_INFEAS = 5 };
+
+/* MOI.TerminationStatusCode values this library can return (MathOptInterface v1 enum order) */
+enum { SQPHIP_MOI_LOCALLY_SOLVED = 4, SQPHIP_MOI_LOCALLY_INFEASIBLE = 5,
+       SQPHIP_MOI_ITERATION_LIMIT = 11, SQPHIP_MOI_NUMERICAL_ERROR = 20 };
+
+/* Mirror of src/parameters.jl:1-30 (fields the hot path reads) plus the sub-solver's own knobs */
+typedef struct {
+    double tol_direction, tol_residual, tol_infeas;   /* parameters.jl:17-19 */
+    double init_mu, max_mu, tr_size;                   /* :22,:23,:28 */
+    double rho, eta, tau, min_alpha;                   /* :24-27 (Armijo variant) */
+    int32_t max_iter;                                  /* :20 */
+    int32_t use_soc;                                   /* :29 */
+    int32_t literal_quirks;  /* 1: reproduce SURVEY.md App. C #2/#3 (JuMP-sign Hessian/KT residual) */
+    double ipm_tol;          /* interior-point optimality tolerance (scaled), default 1e-9 */
+    int32_t ipm_max_iter;    /* default 200 */
+    int32_t device;          /* HIP device ordinal */
+} sqphip_options;
+
+void sqphip_default_options(sqphip_options *o);
+
+/* Create a context for `batch` NLP instances sharing dimensions and sparsity
+ * (one instance = one SqpSolver.Model, src/model.jl:37-67).  COO structures as produced by
+ * MOI_wrapper.jl:930-945 (Jacobian) and :1010-1025 (Hessian, triangular, duplicates allowed);
+ * nnzH = 0 means no Hessian (LP / SLP).  Bounds may be +-Inf; they apply to every instance
+ * until overridden with sqphip_set_bounds. */
+int sqphip_create(sqphip_ctx **ctx, int64_t n, int64_t m, int64_t num_linear,
+                  int64_t nnzJ, const int64_t *jrow, const int64_t *jcol,
+                  int64_t nnzH, const int64_t *hrow, const int64_t *hcol,
+                  const double *xL, const double *xU, const double *gL, const double *gU,
+                  const sqphip_options *opt, int32_t batch);
+void sqphip_destroy(sqphip_ctx *ctx);
+const char *sqphip_last_error(const sqphip_ctx *ctx);
+int sqphip_set_bounds(sqphip_ctx *ctx, int32_t inst, const double *xL, const double *xU,
+                      const double *gL, const double *gU);
+
+/* ---- the AbstractSubOptimizer seat ------------------------------------------------------------
+ * Replaces sub_optimize! / sub_optimize_FR! / sub_optimize_lp / sub_optimize_L1QP! /
+ * sub_optimize_infeas and sub_optimize_soc! (pass mode SOC with E = E_soc,
+ * sqp_trust_region.jl:341-360).  Jval/Hval are in the COO order given to sqphip_create
+ * (what eval_jac_g / eval_h fill, sqp.jl:93,112); Hval may be NULL.
+ * Outputs: p[n], lambda[m], mult_x_U[n], mult_x_L[n] caller-allocated; slack may be NULL else [2m]
+ * (t+ then t-).  For mode LP `p` receives the absolute point x (subproblem_JuMP.jl:212-218).
+ * Infeasible-family statuses zero the outputs (subproblem_JuMP.jl:551-555). */
+int sqphip_qp_solve(sqphip_ctx *ctx, int32_t mode, const double *x_k, double delta, double mu,
+                    const double *df, const double *E, const double *Jval, const double *Hval,
+                    double *p, double *lambda, double *mult_x_U, double *mult_x_L,
+                    double *slack, int32_t *moi_status);
+/* statistics of the last sqphip_qp_solve: interior-point iterations, KKT factorisations */
+int sqphip_qp_stats(const sqphip_ctx *ctx, int32_t *ipm_iters, int32_t *n_factor);
+
+/* ---- merit / acceptance path (device reductions over host-supplied vectors) -------------------- */
+/* common.jl:54-77; pnorm 1, 2 or 0 (=Inf) */
+int sqphip_norm_violations(sqphip_ctx *ctx, const double *E, const double *x, int32_t pnorm,
+                           double *out);
+/* common.jl:14-23 */
+int sqphip_kt_residuals(sqphip_ctx *ctx, const double *df, const double *lambda,
+                        const double *mult_x_U, const double *mult_x_L, const double *Jval,
+                        double *out);
+/* common.jl:30-47 */
+int sqphip_norm_complementarity(sqphip_ctx *ctx, const double *E, const double *lambda,
+                                int32_t pnorm, double *out);
+/* sqp.jl:170-183 given f(x+ap), g(x+ap) from the host callbacks */
+int sqphip_compute_phi(sqphip_ctx *ctx, double f_trial, const double *E_trial,
+                       const double *x_trial, double mu, int32_t feasibility_restoration,
+                       double *phi);
+/* sqp_trust_region.jl:487-508: q(p) if with_step else q(0) */
+int sqphip_compute_qmodel(sqphip_ctx *ctx, const double *x, const double *p, const double *df,
+                          const double *E, const double *Jval, const double *Hval, double mu,
+                          int32_t with_step, double *q);
+/* merit.jl:13-17 + sqp.jl:190-213 (scalar-mu form): D = df'p - mu * sum(viol(E)) */
+int sqphip_compute_derivative(sqphip_ctx *ctx, const double *df, const double *p,
+                              const double *E, double mu, double *D);
+/* sqp_trust_region.jl:529-538,:574-577: ratio test and radius update.
+ * accept_out = 1 if ared > 0 and ared/pred > 0; delta_out the updated radius. */
+int sqphip_tr_update(double ared, double pred, double delta, double pnorm_inf,
+                     double delta_max, double tol_direction, int32_t *accept_out,
+                     double *delta_out);
+
+/* ---- device-resident batched SQP-TR over the built-in ACOPF evaluator --------------------------
+ * (sqp_trust_region.jl:98-223 for every instance of the batch; callbacks of
+ * MOI_wrapper.jl:1115-1146 replaced by HIP kernels over PowerModels-ACP-shaped data,
+ * test/opf.jl:5-9).  Topology is shared; electrical data, loads and bounds are per instance. */
+int sqphip_acopf_attach(sqphip_ctx *ctx, int32_t nb, int32_t ng, int32_t nl,
+                        const int32_t *f_bus, const int32_t *t_bus, const int32_t *gen_bus,
+                        const int32_t *bal_ptr, const int32_t *bal_colP, const int32_t *bal_colQ,
+                        const double *bal_coef, int32_t ref_bus);
+int sqphip_acopf_set_instance(sqphip_ctx *ctx, int32_t inst, const double *g, const double *b,
+                              const double *bsh, const double *c2, const double *c1,
+                              const double *x0);
+/* Evaluate the five callbacks on the device for instance `inst` at host point x (parity tests).
+ * Any output may be NULL. lambda/sigma only matter for hval. */
+int sqphip_acopf_eval(sqphip_ctx *ctx, int32_t inst, const double *x, double sigma,
+                      const double *lambda, double *f, double *grad, double *g, double *jval,
+                      double *hval);
+/* Run SQP-TR for every instance until each has terminated or done `max_outer` more outer
+ * iterations (0 = no cap beyond options.max_iter).  Restartable: state stays on the device. */
+int sqphip_sqp_reset(sqphip_ctx *ctx);
+int sqphip_sqp_run(sqphip_ctx *ctx, int32_t max_outer);
+/* results per instance (src/model.jl result slots as written by sqp_trust_region.jl:215-222);
+ * any pointer may be NULL */
+int sqphip_sqp_get(sqphip_ctx *ctx, int32_t inst, double *x, double *g, double *mult_g,
+                   double *mult_x_L, double *mult_x_U, double *obj_val, int32_t *status,
+                   int32_t *iter);
+/* ret codes and iteration counts of the whole batch, device -> host (the arrays a host layer
+ * all-gathers across ranks); done[i] = 1 once instance i has terminated */
+int sqphip_sqp_status(sqphip_ctx *ctx, int32_t *ret_codes, int32_t *iters, int32_t *done);
+/* per-instance trace rows (columns of the reference's log line, sqp_trust_region.jl:605-634):
+ * rows[k*12 + {iter, accepted, fr, sub_status, ipm_iters, f, phi, mu, delta, |p|, inf_pr, inf_du}] */
+int sqphip_sqp_trace(sqphip_ctx *ctx, int32_t inst, double *rows, int32_t cap, int32_t *len);
+
+/* counters since create/reset: sub-problem solves, interior-point iterations, factorisations,
+ * flops spent in LDL^T (N^3/3 each), seconds inside the factor kernels (HIP events) */
+typedef struct {
+    int64_t n_qp, n_ipm_iter, n_factor;
+    double ldlt_flops, ldlt_seconds, trailing_seconds, solve_seconds, total_seconds;
+    int64_t trailing_launches;
+} sqphip_counters;
+int sqphip_get_counters(sqphip_ctx *ctx, sqphip_counters *c);
+int sqphip_reset_counters(sqphip_ctx *ctx);
+
+/* ---- kernel-level entry points (parity tests, micro-benchmarks) -------------------------------
+ * Batched dense LDL^T without pivoting of `batch` symmetric N x N matrices given as full
+ * column-major host arrays A[batch][N*N] (lower triangle read).  On return L (unit lower) is in the
+ * strict lower triangle, dinv[batch][N] = 1/D.  npos[batch] = number of positive pivots. */
+int sqphip_ldlt_factor_host(int32_t device, int32_t batch, int64_t N, double *A, double *dinv,
+                            int32_t *npos);
+/* Factor + solve K x = rhs for each batch member; x overwrites rhs[batch][N]. */
+int sqphip_ldlt_solve_host(int32_t device, int32_t batch, int64_t N, const double *A,
+                           double *rhs);
+/* time `reps` factorisations of resident random quasi-definite matrices; returns seconds per
+ * factorisation of the whole batch and seconds spent in the trailing-update kernel */
+int sqphip_ldlt_bench(int32_t device, int32_t batch, int64_t N, int32_t reps,
+                      double *sec_per_factor, double *sec_trailing, int64_t *trailing_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,109 @@
+"""ctypes loader of libsqphip.so (the HIP extension).  Fails loudly when the library is absent:
+there is no CPU fallback anywhere in this package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+SO_PATH = os.path.join(_CSRC, "libsqphip.so")
+SOURCES = ["ldlt.hip", "kernel_api.hip", "ipm.hip", "acopf.hip", "sqp.hip", "api.hip"]
+HEADERS = ["sqphip_internal.hpp", "ctx.hpp", os.path.join("..", "..", "include", "sqphip.h")]
+
+_lib = None
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 every translation unit into csrc/libsqphip.so (in-tree)."""
+    srcs = [os.path.join(_CSRC, s) for s in SOURCES if os.path.exists(os.path.join(_CSRC, s))]
+    deps = srcs + [os.path.join(_CSRC, h) for h in HEADERS if os.path.exists(os.path.join(_CSRC, h))]
+    stale = force or not os.path.exists(SO_PATH)
+    if not stale:
+        t = os.path.getmtime(SO_PATH)
+        stale = any(os.path.getmtime(d) > t for d in deps)
+    if stale:
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-Wno-unused-value", "-o", SO_PATH] + srcs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return SO_PATH
+
+
+class Options(C.Structure):
+    _fields_ = [(k, C.c_double) for k in
+                ("tol_direction", "tol_residual", "tol_infeas", "init_mu", "max_mu", "tr_size",
+                 "rho", "eta", "tau", "min_alpha")] + \
+               [("max_iter", C.c_int32), ("use_soc", C.c_int32), ("literal_quirks", C.c_int32),
+                ("ipm_tol", C.c_double), ("ipm_max_iter", C.c_int32), ("device", C.c_int32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("n_qp", C.c_int64), ("n_ipm_iter", C.c_int64), ("n_factor", C.c_int64),
+                ("ldlt_flops", C.c_double), ("ldlt_seconds", C.c_double),
+                ("trailing_seconds", C.c_double), ("solve_seconds", C.c_double),
+                ("total_seconds", C.c_double), ("trailing_launches", C.c_int64)]
+
+
+def lib():
+    """Load libsqphip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                f"{SO_PATH} is missing: build it with __graft_entry__.build() "
+                "(hipcc --offload-arch=gfx950); this package has no CPU fallback")
+        L = C.CDLL(SO_PATH)
+        dp, ip, lp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+        vp = C.c_void_p
+        if hasattr(L, "sqphip_default_options"):
+            L.sqphip_default_options.argtypes = [C.POINTER(Options)]
+        L.sqphip_ldlt_factor_host.argtypes = [C.c_int32, C.c_int32, C.c_int64, dp, dp, ip]
+        L.sqphip_ldlt_solve_host.argtypes = [C.c_int32, C.c_int32, C.c_int64, dp, dp]
+        L.sqphip_ldlt_bench.argtypes = [C.c_int32, C.c_int32, C.c_int64, C.c_int32, dp, dp, lp]
+        if hasattr(L, "sqphip_create"):
+            L.sqphip_create.argtypes = [C.POINTER(vp), C.c_int64, C.c_int64, C.c_int64,
+                                        C.c_int64, lp, lp, C.c_int64, lp, lp, dp, dp, dp, dp,
+                                        C.POINTER(Options), C.c_int32]
+            L.sqphip_destroy.argtypes = [vp]
+            L.sqphip_last_error.restype = C.c_char_p
+            L.sqphip_last_error.argtypes = [vp]
+            L.sqphip_set_bounds.argtypes = [vp, C.c_int32, dp, dp, dp, dp]
+            L.sqphip_qp_solve.argtypes = [vp, C.c_int32, dp, C.c_double, C.c_double, dp, dp, dp, dp,
+                                          dp, dp, dp, dp, dp, ip]
+            L.sqphip_qp_stats.argtypes = [vp, ip, ip]
+            L.sqphip_norm_violations.argtypes = [vp, dp, dp, C.c_int32, dp]
+            L.sqphip_kt_residuals.argtypes = [vp, dp, dp, dp, dp, dp, dp]
+            L.sqphip_norm_complementarity.argtypes = [vp, dp, dp, C.c_int32, dp]
+            L.sqphip_compute_phi.argtypes = [vp, C.c_double, dp, dp, C.c_double, C.c_int32, dp]
+            L.sqphip_compute_qmodel.argtypes = [vp, dp, dp, dp, dp, dp, dp, C.c_double, C.c_int32, dp]
+            L.sqphip_compute_derivative.argtypes = [vp, dp, dp, dp, C.c_double, dp]
+            L.sqphip_tr_update.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double,
+                                           C.c_double, C.c_double, ip, dp]
+            L.sqphip_acopf_attach.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, ip, ip, ip, ip, ip,
+                                              ip, dp, C.c_int32]
+            L.sqphip_acopf_set_instance.argtypes = [vp, C.c_int32, dp, dp, dp, dp, dp, dp]
+            L.sqphip_acopf_eval.argtypes = [vp, C.c_int32, dp, C.c_double, dp, dp, dp, dp, dp, dp]
+            L.sqphip_sqp_reset.argtypes = [vp]
+            L.sqphip_sqp_run.argtypes = [vp, C.c_int32]
+            L.sqphip_sqp_get.argtypes = [vp, C.c_int32, dp, dp, dp, dp, dp, dp, ip, ip]
+            L.sqphip_sqp_status.argtypes = [vp, ip, ip, ip]
+            L.sqphip_sqp_trace.argtypes = [vp, C.c_int32, dp, C.c_int32, ip]
+            L.sqphip_get_counters.argtypes = [vp, C.POINTER(Counters)]
+            L.sqphip_reset_counters.argtypes = [vp]
+        _lib = L
+    return _lib
+
+
+EXPORTS = [
+    "sqphip_default_options", "sqphip_create", "sqphip_destroy", "sqphip_last_error",
+    "sqphip_set_bounds", "sqphip_qp_solve", "sqphip_qp_stats", "sqphip_norm_violations",
+    "sqphip_kt_residuals", "sqphip_norm_complementarity", "sqphip_compute_phi",
+    "sqphip_compute_qmodel", "sqphip_compute_derivative", "sqphip_tr_update",
+    "sqphip_acopf_attach", "sqphip_acopf_set_instance", "sqphip_acopf_eval", "sqphip_sqp_reset",
+    "sqphip_sqp_run", "sqphip_sqp_get", "sqphip_sqp_status", "sqphip_sqp_trace",
+    "sqphip_get_counters", "sqphip_reset_counters", "sqphip_ldlt_factor_host",
+    "sqphip_ldlt_solve_host", "sqphip_ldlt_bench",
+]

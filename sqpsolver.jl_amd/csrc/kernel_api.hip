@@ -1,0 +1,177 @@
+// kernel_api.hip -- kernel-level C entry points (parity tests and micro-benchmarks of the LDL^T).
+#include "../../include/sqphip.h"
+#include "sqphip_internal.hpp"
+#include <cmath>
+#include <cstring>
+#include <random>
+
+using namespace sqphip;
+
+namespace {
+
+__global__ void k_pad_identity(double *K, long strideK, int ld, int N, int Npad)
+{
+    const int inst = blockIdx.x;
+    for (int i = N + threadIdx.x; i < Npad; i += blockDim.x) K[(long)inst * strideK + (long)i * ld + i] = 1.0;
+}
+
+__global__ void k_count_pos(const double *dinv, int Npad, int N, int *npos)
+{
+    const int inst = blockIdx.x;
+    int c = 0;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        const double d = dinv[(long)inst * Npad + i];
+        if (d > 0.0 && isfinite(d)) ++c;
+    }
+    __shared__ int sh[256];
+    sh[threadIdx.x] = c;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) npos[inst] = sh[0];
+}
+
+struct Scratch {
+    LdltPlan P;
+    double *K = nullptr, *dinv = nullptr, *x = nullptr, *v = nullptr;
+    int *npos = nullptr;
+    void alloc(int B, long N)
+    {
+        P.N = (int)N; P.Npad = (int)((N + 63) / 64 * 64); P.T = P.Npad / 64; P.ld = P.Npad; P.B = B;
+        SQPHIP_HIP_OK(hipStreamCreate(&P.stream));
+        SQPHIP_HIP_OK(hipMalloc(&K, sizeof(double) * (size_t)B * P.ld * P.Npad));
+        SQPHIP_HIP_OK(hipMalloc(&P.Wbuf, sizeof(double) * (size_t)B * P.Npad * 64));
+        SQPHIP_HIP_OK(hipMalloc(&dinv, sizeof(double) * (size_t)B * P.Npad));
+        SQPHIP_HIP_OK(hipMalloc(&x, sizeof(double) * (size_t)B * P.Npad));
+        SQPHIP_HIP_OK(hipMalloc(&v, sizeof(double) * (size_t)B * P.Npad));
+        SQPHIP_HIP_OK(hipMalloc(&npos, sizeof(int) * (size_t)B));
+    }
+    void upload(const double *A)
+    {
+        const long strideK = (long)P.ld * P.Npad;
+        SQPHIP_HIP_OK(hipMemsetAsync(K, 0, sizeof(double) * (size_t)P.B * strideK, P.stream));
+        for (int b = 0; b < P.B; ++b)
+            SQPHIP_HIP_OK(hipMemcpy2DAsync(K + b * strideK, sizeof(double) * P.ld, A + (long)b * P.N * P.N,
+                                           sizeof(double) * P.N, sizeof(double) * P.N, P.N,
+                                           hipMemcpyHostToDevice, P.stream));
+        hipLaunchKernelGGL(k_pad_identity, dim3(P.B), dim3(64), 0, P.stream, K, strideK, P.ld, P.N, P.Npad);
+    }
+    ~Scratch()
+    {
+        hipFree(K); hipFree(P.Wbuf); hipFree(dinv); hipFree(x); hipFree(v); hipFree(npos);
+        if (P.stream) hipStreamDestroy(P.stream);
+    }
+};
+
+}  // namespace
+
+extern "C" int sqphip_ldlt_factor_host(int32_t device, int32_t batch, int64_t N, double *A, double *dinv,
+                                       int32_t *npos)
+{
+    try {
+        SQPHIP_HIP_OK(hipSetDevice(device));
+        Scratch S;
+        S.alloc(batch, N);
+        S.upload(A);
+        ldlt_factor(S.P, S.K, S.dinv, nullptr, 0, nullptr);
+        hipLaunchKernelGGL(k_count_pos, dim3(batch), dim3(256), 0, S.P.stream, S.dinv, S.P.Npad, S.P.N, S.npos);
+        const long strideK = (long)S.P.ld * S.P.Npad;
+        for (int b = 0; b < batch; ++b) {
+            SQPHIP_HIP_OK(hipMemcpy2DAsync(A + (long)b * N * N, sizeof(double) * N, S.K + b * strideK,
+                                           sizeof(double) * S.P.ld, sizeof(double) * N, N,
+                                           hipMemcpyDeviceToHost, S.P.stream));
+            SQPHIP_HIP_OK(hipMemcpyAsync(dinv + (long)b * N, S.dinv + (long)b * S.P.Npad, sizeof(double) * N,
+                                         hipMemcpyDeviceToHost, S.P.stream));
+        }
+        SQPHIP_HIP_OK(hipMemcpyAsync(npos, S.npos, sizeof(int) * batch, hipMemcpyDeviceToHost, S.P.stream));
+        SQPHIP_HIP_OK(hipStreamSynchronize(S.P.stream));
+        return SQPHIP_OK;
+    } catch (const std::string &e) {
+        fprintf(stderr, "sqphip: %s\n", e.c_str());
+        return SQPHIP_EHIP;
+    }
+}
+
+extern "C" int sqphip_ldlt_solve_host(int32_t device, int32_t batch, int64_t N, const double *A, double *rhs)
+{
+    try {
+        SQPHIP_HIP_OK(hipSetDevice(device));
+        Scratch S;
+        S.alloc(batch, N);
+        S.upload(A);
+        SQPHIP_HIP_OK(hipMemsetAsync(S.x, 0, sizeof(double) * (size_t)batch * S.P.Npad, S.P.stream));
+        for (int b = 0; b < batch; ++b)
+            SQPHIP_HIP_OK(hipMemcpyAsync(S.x + (long)b * S.P.Npad, rhs + (long)b * N, sizeof(double) * N,
+                                         hipMemcpyHostToDevice, S.P.stream));
+        ldlt_factor(S.P, S.K, S.dinv, nullptr, 0, nullptr);
+        ldlt_solve(S.P, S.K, S.dinv, S.x, S.v, nullptr, 0);
+        for (int b = 0; b < batch; ++b)
+            SQPHIP_HIP_OK(hipMemcpyAsync(rhs + (long)b * N, S.x + (long)b * S.P.Npad, sizeof(double) * N,
+                                         hipMemcpyDeviceToHost, S.P.stream));
+        SQPHIP_HIP_OK(hipStreamSynchronize(S.P.stream));
+        return SQPHIP_OK;
+    } catch (const std::string &e) {
+        fprintf(stderr, "sqphip: %s\n", e.c_str());
+        return SQPHIP_EHIP;
+    }
+}
+
+namespace {
+// diagonally dominant quasi-definite fill: K = [W J'; J -D], n1 = N*2/5 like the ACOPF shape
+__global__ void k_fill_qd(double *K, long strideK, int ld, int N, int Npad, unsigned seed)
+{
+    const int inst = blockIdx.y;
+    const int j = blockIdx.x;
+    if (j >= Npad) return;
+    double *col = K + (long)inst * strideK + (long)j * ld;
+    const int n1 = N * 2 / 5;
+    for (int i = j + threadIdx.x; i < Npad; i += blockDim.x) {
+        unsigned h = (unsigned)(i * 2654435761u) ^ (unsigned)(j * 40503u) ^ (seed + inst * 7919u);
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        double u = (double)(h & 0xFFFFFF) / 16777216.0 - 0.5;
+        double val;
+        if (i >= N || j >= N) val = (i == j) ? 1.0 : 0.0;
+        else if (i == j) val = (j < n1 ? 1.0 : -1.0) * (0.05 * N + 1.0 + u);
+        else val = 0.1 * u;
+        col[i] = val;
+    }
+}
+}  // namespace
+
+extern "C" int sqphip_ldlt_bench(int32_t device, int32_t batch, int64_t N, int32_t reps,
+                                 double *sec_per_factor, double *sec_trailing, int64_t *trailing_launches)
+{
+    try {
+        SQPHIP_HIP_OK(hipSetDevice(device));
+        Scratch S;
+        S.alloc(batch, N);
+        const long strideK = (long)S.P.ld * S.P.Npad;
+        Timers tm;
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        double total = 0.0;
+        for (int rep = -1; rep < reps; ++rep) {
+            hipLaunchKernelGGL(k_fill_qd, dim3(S.P.Npad, batch), dim3(128), 0, S.P.stream, S.K, strideK, S.P.ld,
+                               S.P.N, S.P.Npad, 1234u + rep);
+            tm.enabled = rep >= 0;
+            hipEventRecord(e0, S.P.stream);
+            ldlt_factor(S.P, S.K, S.dinv, nullptr, 0, &tm);
+            hipEventRecord(e1, S.P.stream);
+            SQPHIP_HIP_OK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, e0, e1);
+            if (rep >= 0) total += 1e-3 * ms; else tm.trailing_launches = 0;
+        }
+        tm.flush();
+        *sec_per_factor = total / reps;
+        *sec_trailing = tm.trailing_seconds / reps;
+        *trailing_launches = tm.trailing_launches / reps;
+        hipEventDestroy(e0); hipEventDestroy(e1);
+        return SQPHIP_OK;
+    } catch (const std::string &e) {
+        fprintf(stderr, "sqphip: %s\n", e.c_str());
+        return SQPHIP_EHIP;
+    }
+}

@@ -1,0 +1,73 @@
+// sqphip_internal.hpp -- shared declarations of libsqphip's translation units (not part of the ABI)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+namespace sqphip {
+
+struct Timers {
+    bool enabled = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;   // recycled event pairs
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_trailing, pending_factor, pending_solve;
+    double trailing_seconds = 0, factor_seconds = 0, solve_seconds = 0;
+    long trailing_launches = 0, n_factor = 0;
+    std::pair<hipEvent_t, hipEvent_t> get()
+    {
+        if (!pool.empty()) { auto p = pool.back(); pool.pop_back(); return p; }
+        hipEvent_t a, b;
+        hipEventCreate(&a); hipEventCreate(&b);
+        return {a, b};
+    }
+    static double drain(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v,
+                        std::vector<std::pair<hipEvent_t, hipEvent_t>> &pool)
+    {
+        double s = 0;
+        for (auto &p : v) {
+            hipEventSynchronize(p.second);
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, p.first, p.second);
+            s += 1e-3 * (double)ms;
+            pool.push_back(p);
+        }
+        v.clear();
+        return s;
+    }
+    void flush()
+    {
+        trailing_seconds += drain(pending_trailing, pool);
+        factor_seconds += drain(pending_factor, pool);
+        solve_seconds += drain(pending_solve, pool);
+    }
+    ~Timers()
+    {
+        flush();
+        for (auto &p : pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    }
+};
+
+struct LdltPlan {
+    int N = 0, Npad = 0, T = 0, ld = 0, B = 0;
+    double *Wbuf = nullptr;     // [B][64][Npad] : W = L D of the current panel
+    hipStream_t stream = nullptr;
+};
+
+// phase-filtered launches: kernels skip instances whose phase[inst] != want (phase may be null)
+void ldlt_factor(const LdltPlan &P, double *K, double *dinv, const int *phase, int want, Timers *tm);
+void ldlt_solve(const LdltPlan &P, const double *K, const double *dinv, double *x, double *v,
+                const int *phase, int want);
+
+#define SQPHIP_HIP_OK(expr)                                                                    \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            char buf_[512];                                                                    \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                     __FILE__, __LINE__);                                                      \
+            throw std::string(buf_);                                                           \
+        }                                                                                      \
+    } while (0)
+
+}  // namespace sqphip
