@@ -158,6 +158,8 @@ typedef struct {
 } sqphip_counters;
 int sqphip_get_counters(sqphip_ctx *ctx, sqphip_counters *c);
 int sqphip_reset_counters(sqphip_ctx *ctx);
+/* HIP-event timing of the factor / trailing-update / solve kernels (off by default) */
+int sqphip_set_timing(sqphip_ctx *ctx, int32_t enabled);
 
 /* ---- kernel-level entry points (parity tests, micro-benchmarks) -------------------------------
  * Batched dense LDL^T without pivoting of `batch` symmetric N x N matrices given as full

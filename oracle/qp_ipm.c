@@ -16,8 +16,11 @@
  * Rows the mode treats as hard carry the exact-penalty weight rho_big; if elastic mass remains on a
  * hard row a phase-1 solve decides between "infeasible" and "raise rho_big".  With elastics on every
  * row the reduced KKT matrix  K = [W J'; J -D]  (W = H + hd + Sigma_p + delta_w I, D > 0) is
- * quasi-definite whenever W > 0, so an LDL' without pivoting exists; wrong inertia (a non-positive
- * pivot among the first n or a non-negative one among the last m) raises delta_w.
+ * quasi-definite whenever W > 0, so an LDL' without pivoting exists; inertia is judged on the total
+ * pivot signs (n positive, m negative) and a wrong count raises delta_w.  A fixed primal-dual
+ * regularisation (1e-8 on both diagonal blocks) keeps the pivots of rank-deficient row sets away
+ * from round-off.  Steps are plain fraction-to-boundary lengths (an Armijo search on the barrier
+ * merit was tried and rejected: it failed more sub-problems than it rescued).
  * Multipliers are kept in the JuMP sign: stationarity reads  H p + c = J'y + zl - zu.
  */
 #include "sqp_oracle.h"
@@ -44,6 +47,7 @@ struct ora_qp {
     double sf;
     /* iterate */
     double *p, *zl, *zu, *s, *tp, *tm, *y, *vl, *vu;
+    double *zp, *zm;   /* elastic duals wp - y, wm + y, carried explicitly (no cancellation near 0) */
     /* directions: affine and final */
     double *dp, *dzl, *dzu, *ds, *dtp, *dtm, *dy, *dvl, *dvu;
     /* second-order correction products */
@@ -91,7 +95,7 @@ ora_qp *ora_qp_create(int64_t n, int64_t m, int64_t num_linear,
     q->hard = (int *)calloc((size_t)(m + 1), sizeof(int));
     q->p = dalloc(n); q->zl = dalloc(n); q->zu = dalloc(n);
     q->s = dalloc(m); q->tp = dalloc(m); q->tm = dalloc(m); q->y = dalloc(m);
-    q->vl = dalloc(m); q->vu = dalloc(m);
+    q->vl = dalloc(m); q->vu = dalloc(m); q->zp = dalloc(m); q->zm = dalloc(m);
     q->dp = dalloc(n); q->dzl = dalloc(n); q->dzu = dalloc(n);
     q->ds = dalloc(m); q->dtp = dalloc(m); q->dtm = dalloc(m); q->dy = dalloc(m);
     q->dvl = dalloc(m); q->dvu = dalloc(m);
@@ -110,7 +114,7 @@ void ora_qp_destroy(ora_qp *q)
         q->c, q->hv, q->hd, q->jv, q->lb, q->ub, q->lo, q->hi, q->wp, q->wm, q->rtype, q->hard,
         q->p, q->zl, q->zu, q->s, q->tp, q->tm, q->y, q->vl, q->vu, q->dp, q->dzl, q->dzu, q->ds,
         q->dtp, q->dtm, q->dy, q->dvl, q->dvu, q->k_gl, q->k_gu, q->k_al, q->k_au, q->k_tp, q->k_tm,
-        q->K, q->dinv, q->rhs, q->sol, q->res, q->sigp, q->D };
+        q->K, q->dinv, q->rhs, q->sol, q->res, q->sigp, q->D, q->zp, q->zm };
     for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) free(ptrs[i]);
     free(q);
 }
@@ -262,13 +266,17 @@ static void jact_mul_add(const ora_qp *q, const double *w, double sign, double *
 }
 
 /* ------------------------------------------------------------------ KKT assembly / solve */
+/* primal-dual regularisation of the Newton system (part of the method, not of the residuals) */
+static double ipm_reg_p(void) { return 1e-8; }
+static double ipm_reg_d(void) { return 1e-8; }
+
 static void kkt_assemble(ora_qp *q, double delta_w)
 {
     int64_t n = q->n, m = q->m, N = q->N, ld = q->ld;
     memset(q->K, 0, sizeof(double) * (size_t)(ld * N));
     for (int64_t j = 0; j < n; ++j) {
         double *col = q->K + j * ld;
-        col[j] = q->hd[j] + q->sigp[j] + delta_w;
+        col[j] = q->hd[j] + q->sigp[j] + delta_w + ipm_reg_p();
         for (int64_t k = q->hcolptr[j]; k < q->hcolptr[j + 1]; ++k) {
             int64_t i = q->hrowval[k];
             if (i >= j) col[i] += q->hv[k];
@@ -279,7 +287,7 @@ static void kkt_assemble(ora_qp *q, double delta_w)
         }
     }
     for (int64_t i = 0; i < m; ++i)
-        q->K[(n + i) * ld + n + i] = q->rtype[i] == ROW_FREE ? -1.0 : -q->D[i];
+        q->K[(n + i) * ld + n + i] = q->rtype[i] == ROW_FREE ? -1.0 : -(q->D[i] + ipm_reg_d());
 }
 
 /* res = rhs - K sol  with K applied through its sparse pieces */
@@ -289,14 +297,14 @@ static double kkt_residual(const ora_qp *q, double delta_w, const double *rhs, c
     int64_t n = q->n, m = q->m;
     double *tmp = (double *)malloc(sizeof(double) * (size_t)(q->N));
     double *ext = (double *)malloc(sizeof(double) * (size_t)n);
-    for (int64_t j = 0; j < n; ++j) ext[j] = q->sigp[j] + delta_w;
+    for (int64_t j = 0; j < n; ++j) ext[j] = q->sigp[j] + delta_w + ipm_reg_p();
     hess_mul(q, ext, sol, tmp);
     jact_mul_add(q, sol + n, 1.0, tmp);
     jac_mul(q, sol, tmp + n);
     double nrm = 0.0;
     for (int64_t j = 0; j < n; ++j) { res[j] = rhs[j] - tmp[j]; nrm = fmax(nrm, fabs(res[j])); }
     for (int64_t i = 0; i < m; ++i) {
-        double d = q->rtype[i] == ROW_FREE ? 1.0 : q->D[i];
+        double d = q->rtype[i] == ROW_FREE ? 1.0 : q->D[i] + ipm_reg_d();
         res[n + i] = rhs[n + i] - (tmp[n + i] - d * sol[n + i]);
         nrm = fmax(nrm, fabs(res[n + i]));
     }
@@ -328,6 +336,14 @@ static int kkt_factor(ora_qp *q, double dw_floor, double *delta_w_out)
         else dw *= (q->delta_w_last == 0.0 ? 100.0 : 8.0);
         if (dw > 1e40) break;
     }
+    if (getenv("ORA_IPM_DEBUG")) {
+        int64_t p1 = 0, p2 = 0, bad = 0;
+        for (int64_t j = 0; j < q->N; ++j) {
+            if (!isfinite(q->dinv[j]) || q->dinv[j] == 0.0) { if (bad < 4) fprintf(stderr, "   bad pivot %ld dinv=%g\n", (long)j, q->dinv[j]); ++bad; }
+            else if (q->dinv[j] > 0) { if (j < q->n) ++p1; else ++p2; }
+        }
+        fprintf(stderr, "   kkt_factor gave up: dw=%.1e pos(W)=%ld/%ld pos(rows)=%ld bad=%ld\n", dw, (long)p1, (long)q->n, (long)p2, (long)bad);
+    }
     return -1;
 }
 
@@ -340,13 +356,13 @@ static double kkt_solve(ora_qp *q, double delta_w, const double *rhs, double *so
     double rn = 0.0, en = 0.0;
     for (int64_t i = 0; i < N; ++i) rn = fmax(rn, fabs(rhs[i]));
     rn = fmax(1.0, rn);
-    for (int it = 0; it < 6; ++it) {
+    /* at most two refinement solves, stop at 1e-11 relative (same policy as the HIP path) */
+    for (int it = 0; it < 3; ++it) {
         en = kkt_residual(q, delta_w, rhs, sol, q->res);
-        if (!(en > 1e-13 * rn)) break;
+        if (it == 2 || !(en > 1e-11 * rn)) break;
         ora_ldlt_solve(N, q->K, q->ld, q->dinv, q->res);
         for (int64_t i = 0; i < N; ++i) sol[i] += q->res[i];
     }
-    en = kkt_residual(q, delta_w, rhs, sol, q->res);
     return en / rn;
 }
 
@@ -397,8 +413,8 @@ static void ipm_measure(ora_qp *q, double *rd_vec, double *rp_vec, ipm_meas *ms)
         if (q->rtype[i] == ROW_FREE) { rp_vec[i] = 0.0; continue; }
         rp_vec[i] += q->tp[i] - q->tm[i] - q->s[i];
         rp = fmax(rp, fabs(rp_vec[i]));
-        CP(q->wp[i] - q->y[i], q->tp[i]);
-        CP(q->wm[i] + q->y[i], q->tm[i]);
+        CP(q->zp[i], q->tp[i]);
+        CP(q->zm[i], q->tm[i]);
         dl1 += fabs(q->y[i]);
         if (q->rtype[i] == ROW_INEQ) {
             if (isfinite(q->lo[i])) CP(q->vl[i], q->s[i] - q->lo[i]);
@@ -421,8 +437,8 @@ static double ipm_compl_err(const ora_qp *q, double mu)
     }
     for (int64_t i = 0; i < q->m; ++i) {
         if (q->rtype[i] == ROW_FREE) continue;
-        CE(q->wp[i] - q->y[i], q->tp[i]);
-        CE(q->wm[i] + q->y[i], q->tm[i]);
+        CE(q->zp[i], q->tp[i]);
+        CE(q->zm[i], q->tm[i]);
         if (q->rtype[i] == ROW_INEQ) {
             if (isfinite(q->lo[i])) CE(q->vl[i], q->s[i] - q->lo[i]);
             if (isfinite(q->hi[i])) CE(q->vu[i], q->hi[i] - q->s[i]);
@@ -447,7 +463,7 @@ static double ipm_direction(ora_qp *q, double delta_w, double tgt,
     }
     for (int64_t i = 0; i < m; ++i) {
         if (q->rtype[i] == ROW_FREE) { q->rhs[n + i] = 0.0; continue; }
-        double zp = q->wp[i] - q->y[i], zm = q->wm[i] + q->y[i];
+        double zp = q->zp[i], zm = q->zm[i];
         double cp = tgt - zp * q->tp[i], cm = tgt - zm * q->tm[i];
         double b = -rp_vec[i] - cp / zp + cm / zm;
         if (q->rtype[i] == ROW_INEQ) {
@@ -470,7 +486,7 @@ static double ipm_direction(ora_qp *q, double delta_w, double tgt,
         q->dy[i] = q->ds[i] = q->dtp[i] = q->dtm[i] = q->dvl[i] = q->dvu[i] = 0.0;
         if (q->rtype[i] == ROW_FREE) continue;
         double dy = -q->sol[n + i];
-        double zp = q->wp[i] - q->y[i], zm = q->wm[i] + q->y[i];
+        double zp = q->zp[i], zm = q->zm[i];
         q->dy[i] = dy;
         q->dtp[i] = (tgt - zp * q->tp[i] + q->tp[i] * dy) / zp;
         q->dtm[i] = (tgt - zm * q->tm[i] - q->tm[i] * dy) / zm;
@@ -506,8 +522,8 @@ static void ipm_max_steps(const ora_qp *q, double *ap, double *ad)
         if (q->rtype[i] == ROW_FREE) continue;
         a = ratio(q->tp[i], q->dtp[i], a);
         a = ratio(q->tm[i], q->dtm[i], a);
-        d = ratio(q->wp[i] - q->y[i], -q->dy[i], d);
-        d = ratio(q->wm[i] + q->y[i], q->dy[i], d);
+        d = ratio(q->zp[i], -q->dy[i], d);
+        d = ratio(q->zm[i], q->dy[i], d);
         if (q->rtype[i] == ROW_INEQ) {
             if (isfinite(q->lo[i])) { a = ratio(q->s[i] - q->lo[i], q->ds[i], a); d = ratio(q->vl[i], q->dvl[i], d); }
             if (isfinite(q->hi[i])) { a = ratio(q->hi[i] - q->s[i], -q->ds[i], a); d = ratio(q->vu[i], q->dvu[i], d); }
@@ -516,27 +532,13 @@ static void ipm_max_steps(const ora_qp *q, double *ap, double *ad)
     *ap = a; *ad = d;
 }
 
-/* barrier part of the merit function along the primal direction: sum of w't - mu*sum(log gaps) */
-static double ipm_barrier(const ora_qp *q, double mu, double a)
+/* keep a primal variable a few ulps inside its box: p + a dp may round onto the bound although the
+ * fraction-to-boundary rule holds in exact arithmetic */
+static double nudge_inside(double v, double lo, double hi)
 {
-    double lin = 0.0, lg = 0.0;
-    for (int64_t j = 0; j < q->n; ++j) {
-        double pj = q->p[j] + a * q->dp[j];
-        if (isfinite(q->lb[j])) lg += log(pj - q->lb[j]);
-        if (isfinite(q->ub[j])) lg += log(q->ub[j] - pj);
-    }
-    for (int64_t i = 0; i < q->m; ++i) {
-        if (q->rtype[i] == ROW_FREE) continue;
-        double tp = q->tp[i] + a * q->dtp[i], tm = q->tm[i] + a * q->dtm[i];
-        lin += q->wp[i] * tp + q->wm[i] * tm;
-        lg += log(tp) + log(tm);
-        if (q->rtype[i] == ROW_INEQ) {
-            double s = q->s[i] + a * q->ds[i];
-            if (isfinite(q->lo[i])) lg += log(s - q->lo[i]);
-            if (isfinite(q->hi[i])) lg += log(q->hi[i] - s);
-        }
-    }
-    return lin - mu * lg;
+    if (isfinite(lo)) { double g = 1e-15 * fmax(1.0, fabs(lo)); if (v - lo < g) v = lo + g; }
+    if (isfinite(hi)) { double g = 1e-15 * fmax(1.0, fabs(hi)); if (hi - v < g) v = hi - g; }
+    return v;
 }
 
 static void ipm_init(ora_qp *q, const double *p_start)
@@ -552,6 +554,7 @@ static void ipm_init(ora_qp *q, const double *p_start)
     jac_mul(q, q->p, v);
     for (int64_t i = 0; i < m; ++i) {
         q->s[i] = q->tp[i] = q->tm[i] = q->y[i] = q->vl[i] = q->vu[i] = 0.0;
+        q->zp[i] = q->zm[i] = 1.0;
         if (q->rtype[i] == ROW_FREE) continue;
         double s = q->rtype[i] == ROW_EQ ? q->lo[i] : push_inside(v[i], q->lo[i], q->hi[i]);
         double d = s - v[i];
@@ -567,6 +570,7 @@ static void ipm_init(ora_qp *q, const double *p_start)
             }
         }
         q->s[i] = s; q->y[i] = y;
+        q->zp[i] = q->wp[i] - y; q->zm[i] = q->wm[i] + y;
         q->tp[i] = fmax(d, 0.0) + mu0 / (q->wp[i] - y);
         q->tm[i] = fmax(-d, 0.0) + mu0 / (q->wm[i] + y);
         /* keep the row equation exact: tp - tm = d */
@@ -575,17 +579,15 @@ static void ipm_init(ora_qp *q, const double *p_start)
     }
 }
 
-/* Monotone (Fiacco-McCormick) barrier method with a primal-feasible start: every constraint of the
- * canonical programme is linear and the start satisfies the row equations exactly, so the barrier
- * objective itself is the merit function of the Armijo search.  Constants follow the published
- * Ipopt defaults (kappa_eps=10, kappa_mu=0.2, theta_mu=1.5, tau_min=0.99, eta=1e-4).
+/* Monotone (Fiacco-McCormick) barrier method with a primal-feasible interior start (the elastic
+ * variables absorb every row residual).  Constants follow the published Ipopt defaults
+ * (kappa_eps=10, kappa_mu=0.2, theta_mu=1.5, tau_min=0.99).
  * returns 0 converged, 1 iteration limit, 2 numerical failure */
 static int ipm_run(ora_qp *q, const double *p_start)
 {
     int64_t n = q->n, m = q->m;
     double *rd = (double *)malloc(sizeof(double) * (size_t)(n + 1));
     double *rp = (double *)malloc(sizeof(double) * (size_t)(m + 1));
-    double *hdp = (double *)malloc(sizeof(double) * (size_t)(n + 1));
     ipm_init(q, p_start);
     q->delta_w_last = 0.0;
     int rc = 1;
@@ -616,7 +618,7 @@ static int ipm_run(ora_qp *q, const double *p_start)
         }
         for (int64_t i = 0; i < m; ++i) {
             if (q->rtype[i] == ROW_FREE) { q->D[i] = 1.0; continue; }
-            double d = q->tp[i] / (q->wp[i] - q->y[i]) + q->tm[i] / (q->wm[i] + q->y[i]);
+            double d = q->tp[i] / q->zp[i] + q->tm[i] / q->zm[i];
             if (q->rtype[i] == ROW_INEQ) {
                 double sig = 0.0;
                 if (isfinite(q->lo[i])) sig += q->vl[i] / (q->s[i] - q->lo[i]);
@@ -625,62 +627,25 @@ static int ipm_run(ora_qp *q, const double *p_start)
             }
             q->D[i] = d;
         }
-        /* direction; retried with a larger delta_w if it is not a descent direction */
+        /* Newton direction of the regularised system; a larger delta_w is tried if the solve is
+         * inaccurate.  Steps are the fraction-to-boundary lengths (primal and dual separately). */
         double dw = 0.0, alpha = 0.0, a_d = 0.0, relres = 0.0;
-        int ok = 0, nls = 0;
+        int ok = 0;
         double dw_floor = 0.0;
         for (int attempt = 0; attempt < 12 && !ok; ++attempt) {
             if (kkt_factor(q, dw_floor, &dw) != 0) break;
             relres = ipm_direction(q, dw, mu, rd, rp);
             double apm, adm;
             ipm_max_steps(q, &apm, &adm);
-            double a_p = fmin(1.0, tau * apm);
+            alpha = fmin(1.0, tau * apm);
             a_d = fmin(1.0, tau * adm);
-            /* merit along the line: q(p + a dp) is an exact quadratic in a */
-            hess_mul(q, NULL, q->dp, hdp);
-            double g0 = 0.0, h0 = 0.0;
-            for (int64_t j = 0; j < n; ++j) {
-                /* c + H p = rd + J'y + zl - zu ; recompute directly instead */
-                h0 += q->dp[j] * hdp[j];
-            }
-            {
-                double *hp = q->res;
-                hess_mul(q, NULL, q->p, hp);
-                for (int64_t j = 0; j < n; ++j) g0 += (q->c[j] + hp[j]) * q->dp[j];
-            }
-            /* directional derivative of the barrier objective */
-            double dphi = g0;
-            for (int64_t j = 0; j < n; ++j) {
-                if (isfinite(q->lb[j])) dphi -= mu * q->dp[j] / (q->p[j] - q->lb[j]);
-                if (isfinite(q->ub[j])) dphi += mu * q->dp[j] / (q->ub[j] - q->p[j]);
-            }
-            for (int64_t i = 0; i < m; ++i) {
-                if (q->rtype[i] == ROW_FREE) continue;
-                dphi += (q->wp[i] - mu / q->tp[i]) * q->dtp[i] + (q->wm[i] - mu / q->tm[i]) * q->dtm[i];
-                if (q->rtype[i] == ROW_INEQ) {
-                    if (isfinite(q->lo[i])) dphi -= mu * q->ds[i] / (q->s[i] - q->lo[i]);
-                    if (isfinite(q->hi[i])) dphi += mu * q->ds[i] / (q->hi[i] - q->s[i]);
-                }
-            }
-            double phi0 = ipm_barrier(q, mu, 0.0);
-            double a = a_p;
-            nls = 0;
-            if (isfinite(dphi) && isfinite(relres) && relres < 1e-6) {
-                double slack = 10.0 * 2.2e-16 * fabs(phi0);
-                for (; nls < 40; ++nls) {
-                    double phia = ipm_barrier(q, mu, a) + a * g0 + 0.5 * a * a * h0;
-                    if (isfinite(phia) && phia - phi0 <= 1e-4 * a * dphi + slack) { ok = 1; break; }
-                    a *= 0.5;
-                }
-            }
-            if (ok) { alpha = a; break; }
-            /* not a descent direction (or bad solve): convexify further and retry */
+            if (isfinite(relres) && relres < 1e-6 && isfinite(alpha) && isfinite(a_d)) { ok = 1; break; }
             dw_floor = dw > 0.0 ? 8.0 * dw : (q->delta_w_last > 0.0 ? q->delta_w_last : 1e-4);
             if (dw_floor > 1e20) break;
         }
         if (!ok) { rc = 2; break; }
         for (int64_t j = 0; j < n; ++j) {
-            q->p[j] += alpha * q->dp[j];
+            q->p[j] = nudge_inside(q->p[j] + alpha * q->dp[j], q->lb[j], q->ub[j]);
             q->zl[j] += a_d * q->dzl[j];
             q->zu[j] += a_d * q->dzu[j];
         }
@@ -688,15 +653,17 @@ static int ipm_run(ora_qp *q, const double *p_start)
             if (q->rtype[i] == ROW_FREE) continue;
             q->tp[i] += alpha * q->dtp[i]; q->tm[i] += alpha * q->dtm[i];
             q->s[i] += alpha * q->ds[i];
+            if (q->rtype[i] == ROW_INEQ) q->s[i] = nudge_inside(q->s[i], q->lo[i], q->hi[i]);
             q->vl[i] += a_d * q->dvl[i]; q->vu[i] += a_d * q->dvu[i];
             if (q->rtype[i] == ROW_INEQ) q->y[i] = q->vl[i] - q->vu[i];
             else q->y[i] += a_d * q->dy[i];
+            q->zp[i] -= a_d * q->dy[i]; q->zm[i] += a_d * q->dy[i];
         }
         if (verbose)
-            fprintf(stderr, "  ipm %3d mu=%.2e e0=%.2e rd=%.2e rp=%.1e cmax=%.2e a=%.3f ad=%.3f ls=%d dw=%.1e rr=%.1e\n",
-                    it, mu, e0, ms.rd, ms.rp, ms.cmax, alpha, a_d, nls, dw, relres);
+            fprintf(stderr, "  ipm %3d mu=%.2e e0=%.2e rd=%.2e rp=%.1e cmax=%.2e a=%.3f ad=%.3f dw=%.1e rr=%.1e\n",
+                    it, mu, e0, ms.rd, ms.rp, ms.cmax, alpha, a_d, dw, relres);
     }
-    free(rd); free(rp); free(hdp);
+    free(rd); free(rp);
     return rc;
 }
 

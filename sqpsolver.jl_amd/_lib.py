@@ -93,6 +93,7 @@ def lib():
             L.sqphip_sqp_trace.argtypes = [vp, C.c_int32, dp, C.c_int32, ip]
             L.sqphip_get_counters.argtypes = [vp, C.POINTER(Counters)]
             L.sqphip_reset_counters.argtypes = [vp]
+            L.sqphip_set_timing.argtypes = [vp, C.c_int32]
         _lib = L
     return _lib
 
@@ -104,6 +105,6 @@ EXPORTS = [
     "sqphip_compute_qmodel", "sqphip_compute_derivative", "sqphip_tr_update",
     "sqphip_acopf_attach", "sqphip_acopf_set_instance", "sqphip_acopf_eval", "sqphip_sqp_reset",
     "sqphip_sqp_run", "sqphip_sqp_get", "sqphip_sqp_status", "sqphip_sqp_trace",
-    "sqphip_get_counters", "sqphip_reset_counters", "sqphip_ldlt_factor_host",
+    "sqphip_get_counters", "sqphip_reset_counters", "sqphip_set_timing", "sqphip_ldlt_factor_host",
     "sqphip_ldlt_solve_host", "sqphip_ldlt_bench",
 ]

@@ -313,7 +313,9 @@ def acopf_layout(net: Network) -> NlpLayout:
     gL[O0:] = 0.0; gU[O0:] = 0.0
     # start: midpoint of finite boxes, 0 otherwise
     # (/root/reference/examples/acopf/init_opf.jl:25-47)
-    x0 = np.where(np.isfinite(xL) & np.isfinite(xU), 0.5 * (xL + xU), 0.0)
+    boxed = np.isfinite(xL) & np.isfinite(xU)
+    x0 = np.zeros(n)
+    x0[boxed] = 0.5 * (xL[boxed] + xU[boxed])
     x0[VM:VM + nb] = 1.0
     return NlpLayout(n=n, m=m, num_linear=T0, jrow=jrow, jcol=jcol, hrow=hrow, hcol=hcol,
                      xL=xL, xU=xU, gL=gL, gU=gU, x0=x0,

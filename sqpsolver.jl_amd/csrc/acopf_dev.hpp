@@ -1,0 +1,131 @@
+// acopf_dev.hpp -- device-side ACOPF evaluator (see acopf.hip for the seat in the reference)
+#pragma once
+#include "ctx.hpp"
+#include "dev_util.hpp"
+#include <cmath>
+
+namespace sqphip {
+
+struct Ohm { double A, Bc, Bs; int self_t; };
+static __device__ __forceinline__ Ohm ohm_coef(double g, double b, double bs, int k)
+{
+    switch (k) {
+    case 0: return {g, -g, -b, 0};
+    case 1: return {-(b + bs), b, -g, 0};
+    case 2: return {g, -g, b, 1};
+    default: return {-(b + bs), b, g, 1};
+    }
+}
+
+// any of f_out, grad, gv, jv, hv may be null
+static __device__ void acopf_eval(const DV &d, int inst, const double *__restrict__ x, double sigma,
+                           const double *__restrict__ lam, double *f_out, double *grad, double *gv,
+                           double *jv, double *hv)
+{
+    const int nb = d.nb, ng = d.ng, nl = d.nl;
+    const int VA = 0, VM = nb, PG = 2 * nb, QG = 2 * nb + ng, PF = 2 * nb + 2 * ng;
+    const int PT = PF + nl, QF = PF + 2 * nl, QT = PF + 3 * nl;
+    const int T0 = 2 * nl + 1 + 2 * nb, O0 = T0 + 2 * nl;
+    const double *bg = d.br_g + (long)inst * nl, *bb = d.br_b + (long)inst * nl,
+                 *bs = d.br_bsh + (long)inst * nl;
+    const double *c2 = d.c2 + (long)inst * ng, *c1 = d.c1 + (long)inst * ng;
+    (void)QG;
+    // objective and gradient
+    if (f_out) {
+        double f = 0.0;
+        for (int g = threadIdx.x; g < ng; g += TPB) f += c2[g] * x[PG + g] * x[PG + g] + c1[g] * x[PG + g];
+        f = block_reduce<OpSum>(f);
+        if (threadIdx.x == 0) *f_out = f;
+    }
+    if (grad) {
+        for (int j = threadIdx.x; j < d.n; j += TPB) grad[j] = 0.0;
+        __syncthreads();
+        for (int g = threadIdx.x; g < ng; g += TPB) grad[PG + g] = 2 * c2[g] * x[PG + g] + c1[g];
+    }
+    if (hv) {
+        for (int g = threadIdx.x; g < ng; g += TPB) hv[g] = sigma * 2 * c2[g];
+    }
+    // bus rows
+    if (gv) {
+        if (threadIdx.x == 0) gv[2 * nl] = x[VA + d.ref_bus];
+        for (int i = threadIdx.x; i < nb; i += TPB) {
+            double sp = 0.0, sq = 0.0;
+            for (int k = d.bal_ptr[i]; k < d.bal_ptr[i + 1]; ++k) {
+                sp += d.bal_coef[k] * x[d.bal_colP[k]];
+                sq += d.bal_coef[k] * x[d.bal_colQ[k]];
+            }
+            gv[2 * nl + 1 + 2 * i] = sp; gv[2 * nl + 2 + 2 * i] = sq;
+        }
+    }
+    if (jv) {
+        if (threadIdx.x == 0) jv[4 * nl] = 1.0;
+        const int B0 = 4 * nl + 1;
+        for (int i = threadIdx.x; i < nb; i += TPB) {
+            const int s = d.bal_ptr[i], e = d.bal_ptr[i + 1];
+            double *dst = jv + B0 + 2 * s;
+            for (int k = s; k < e; ++k) { dst[k - s] = d.bal_coef[k]; dst[(e - s) + (k - s)] = d.bal_coef[k]; }
+        }
+    }
+    // branch rows
+    const int TH = 4 * nl + 1 + 2 * d.bal_ptr[nb], OH = TH + 4 * nl;
+    const int HO = ng + 4 * nl;
+    for (int l = threadIdx.x; l < nl; l += TPB) {
+        const int fb = d.f_bus[l], tb = d.t_bus[l];
+        const double th = x[VA + fb] - x[VA + tb];
+        const double vf = x[VM + fb], vt = x[VM + tb];
+        const double pf = x[PF + l], qf = x[QF + l], pt = x[PT + l], qt = x[QT + l];
+        double sn, cs;
+        sincos(th, &sn, &cs);
+        const double uu = vf * vt;
+        if (gv) {
+            gv[l] = th; gv[nl + l] = th;
+            gv[T0 + 2 * l] = pf * pf + qf * qf;
+            gv[T0 + 2 * l + 1] = pt * pt + qt * qt;
+        }
+        if (jv) {
+            jv[2 * l] = 1.0; jv[2 * l + 1] = -1.0;
+            jv[2 * nl + 2 * l] = 1.0; jv[2 * nl + 2 * l + 1] = -1.0;
+            jv[TH + 2 * l] = 2 * pf; jv[TH + 2 * l + 1] = 2 * qf;
+            jv[TH + 2 * nl + 2 * l] = 2 * pt; jv[TH + 2 * nl + 2 * l + 1] = 2 * qt;
+        }
+        if (hv) {
+            const double wf = 2 * lam[T0 + 2 * l], wt = 2 * lam[T0 + 2 * l + 1];
+            hv[ng + 2 * l] = wf; hv[ng + 2 * l + 1] = wf;
+            hv[ng + 2 * nl + 2 * l] = wt; hv[ng + 2 * nl + 2 * l + 1] = wt;
+        }
+        const double own[4] = {pf, qf, pt, qt};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const Ohm o = ohm_coef(bg[l], bb[l], bs[l], k);
+            const double T0v = o.Bc * cs + o.Bs * sn, T1 = -o.Bc * sn + o.Bs * cs;
+            if (gv) {
+                const double vs = o.self_t ? vt : vf;
+                gv[O0 + 4 * l + k] = own[k] - (o.A * vs * vs + uu * T0v);
+            }
+            if (jv) {
+                double *e = jv + OH + (long)k * 5 * nl + 5 * l;
+                e[0] = 1.0;
+                e[1] = -(uu * T1);
+                e[2] = uu * T1;
+                e[3] = -((o.self_t ? 0.0 : 2 * o.A * vf) + vt * T0v);
+                e[4] = -((o.self_t ? 2 * o.A * vt : 0.0) + vf * T0v);
+            }
+            if (hv) {
+                double *blk = hv + HO + (long)k * 10 * nl;
+                const double w = -lam[O0 + 4 * l + k];
+                blk[0 * nl + l] = w * (-uu * T0v);
+                blk[1 * nl + l] = w * (uu * T0v);
+                blk[2 * nl + l] = w * (-uu * T0v);
+                blk[3 * nl + l] = w * (vt * T1);
+                blk[4 * nl + l] = w * (-vt * T1);
+                blk[5 * nl + l] = w * (o.self_t ? 0.0 : 2 * o.A);
+                blk[6 * nl + l] = w * (vf * T1);
+                blk[7 * nl + l] = w * (-vf * T1);
+                blk[8 * nl + l] = w * T0v;
+                blk[9 * nl + l] = w * (o.self_t ? 2 * o.A : 0.0);
+            }
+        }
+    }
+}
+
+}  // namespace sqphip

@@ -1,0 +1,542 @@
+// api.hip -- the extern "C" boundary of libsqphip.so (declared in include/sqphip.h).
+// Builds the shared sparsity structure once on the host (what `sparse(I,J,V)` does in
+// /root/reference/src/algorithms/sqp_trust_region.jl:47-48,56-57 plus the symmetric mirroring of
+// sqp.jl:96-101), lays the batch out in HBM and forwards to the kernels.
+#include "ctx.hpp"
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <tuple>
+
+using namespace sqphip;
+
+struct sqphip_ctx { Ctx c; };
+
+Ctx::~Ctx()
+{
+    tm.flush();
+    for (void *p : allocs) hipFree(p);
+    if (h_counters) hipHostFree(h_counters);
+    if (stream) hipStreamDestroy(stream);
+}
+
+namespace {
+
+struct Pattern {
+    std::vector<int> colptr, rowval, g_ptr, g_src;     // CSC + per-slot gather lists over COO indices
+};
+
+Pattern build_pattern(int64_t ncols, int64_t nnz, const int64_t *row, const int64_t *col, bool sym)
+{
+    std::vector<std::tuple<int64_t, int64_t, int64_t>> e;   // (col, row, coo index)
+    e.reserve(sym ? 2 * nnz : nnz);
+    for (int64_t k = 0; k < nnz; ++k) {
+        e.emplace_back(col[k] - 1, row[k] - 1, k);
+        if (sym && row[k] != col[k]) e.emplace_back(row[k] - 1, col[k] - 1, k);
+    }
+    std::sort(e.begin(), e.end());
+    Pattern P;
+    P.colptr.assign(ncols + 1, 0);
+    P.g_ptr.push_back(0);
+    for (size_t i = 0; i < e.size(); ++i) {
+        const bool fresh = i == 0 || std::get<0>(e[i]) != std::get<0>(e[i - 1]) ||
+                           std::get<1>(e[i]) != std::get<1>(e[i - 1]);
+        if (fresh) {
+            if (i) P.g_ptr.push_back((int)P.g_src.size());
+            P.rowval.push_back((int)std::get<1>(e[i]));
+            P.colptr[std::get<0>(e[i]) + 1]++;
+        }
+        P.g_src.push_back((int)std::get<2>(e[i]));
+    }
+    P.g_ptr.push_back((int)P.g_src.size());
+    if (e.empty()) P.g_ptr.assign(1, 0);
+    for (int64_t j = 0; j < ncols; ++j) P.colptr[j + 1] += P.colptr[j];
+    return P;
+}
+
+template <class F> int guarded(sqphip_ctx *h, F &&f)
+{
+    try {
+        SQPHIP_HIP_OK(hipSetDevice(h->c.opt.device));
+        return f(h->c);
+    } catch (const std::string &e) {
+        h->c.err = e;
+        return SQPHIP_EHIP;
+    } catch (const std::bad_alloc &) {
+        h->c.err = "out of host memory";
+        return SQPHIP_ENOMEM;
+    }
+}
+
+void h2d(Ctx &C, double *dst, const double *src, size_t k)
+{
+    if (src && k) SQPHIP_HIP_OK(hipMemcpyAsync(dst, src, sizeof(double) * k, hipMemcpyHostToDevice, C.stream));
+}
+void d2h(Ctx &C, double *dst, const double *src, size_t k)
+{
+    if (dst && k) SQPHIP_HIP_OK(hipMemcpyAsync(dst, src, sizeof(double) * k, hipMemcpyDeviceToHost, C.stream));
+}
+
+__global__ void k_qp_request(DV d, int inst, int mode, double delta, double mu_pen)
+{
+    for (int i = threadIdx.x; i < d.B; i += blockDim.x) d.ist[i].start = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        IpmState &I = d.ist[inst];
+        I.mode = mode; I.delta = delta; I.mu_pen = mu_pen;
+        I.stage = 0; I.rho_big = 1e4; I.start = 1; I.ipm_iters = 0; I.n_factor = 0; I.status = 0;
+    }
+}
+
+}  // namespace
+
+extern "C" void sqphip_default_options(sqphip_options *o)
+{
+    // /root/reference/src/parameters.jl:17-29
+    o->tol_direction = 1e-8; o->tol_residual = 1e-8; o->tol_infeas = 1e-8;
+    o->init_mu = 1.0; o->max_mu = 1e10; o->tr_size = 10.0;
+    o->rho = 0.8; o->eta = 0.4; o->tau = 0.9; o->min_alpha = 1e-6;
+    o->max_iter = 3000; o->use_soc = 0; o->literal_quirks = 1;
+    o->ipm_tol = 1e-9; o->ipm_max_iter = 200; o->device = 0;
+}
+
+extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num_linear, int64_t nnzJ,
+                             const int64_t *jrow, const int64_t *jcol, int64_t nnzH, const int64_t *hrow,
+                             const int64_t *hcol, const double *xL, const double *xU, const double *gL,
+                             const double *gU, const sqphip_options *opt, int32_t batch)
+{
+    if (!out || n <= 0 || m < 0 || batch <= 0 || !opt || num_linear < 0 || num_linear > m) return SQPHIP_EINVAL;
+    for (int64_t k = 0; k < nnzJ; ++k)
+        if (jrow[k] < 1 || jrow[k] > m || jcol[k] < 1 || jcol[k] > n) return SQPHIP_EINVAL;
+    for (int64_t k = 0; k < nnzH; ++k)
+        if (hrow[k] < 1 || hrow[k] > n || hcol[k] < 1 || hcol[k] > n) return SQPHIP_EINVAL;
+    // rows unbounded on both sides create no constraint upstream and shift its indexing
+    // (SURVEY.md App. C #15): rejected
+    for (int64_t i = 0; i < m; ++i)
+        if (gL[i] == -INFINITY && gU[i] == INFINITY) return SQPHIP_EINVAL;
+    sqphip_ctx *h = new (std::nothrow) sqphip_ctx();
+    if (!h) return SQPHIP_ENOMEM;
+    h->c.opt = *opt;
+    int rc = guarded(h, [&](Ctx &C) {
+        SQPHIP_HIP_OK(hipStreamCreate(&C.stream));
+        SQPHIP_HIP_OK(hipHostMalloc((void **)&C.h_counters, 8 * sizeof(int)));
+        DV &d = C.d;
+        std::memset(&d, 0, sizeof(d));
+        C.n = n; C.m = m;
+        const int B = batch;
+        d.n = (int)n; d.m = (int)m; d.nlin = (int)num_linear; d.N = (int)(n + m);
+        d.Npad = (d.N + 63) / 64 * 64; d.ld = d.Npad; d.B = B;
+        d.nnzj_coo = (int)nnzJ; d.nnzh_coo = (int)nnzH;
+        Pattern PJ = build_pattern(n, nnzJ, jrow, jcol, false);
+        Pattern PH = build_pattern(n, nnzH, hrow, hcol, true);
+        d.nnzjc = (int)PJ.rowval.size(); d.nnzhc = (int)PH.rowval.size();
+        // CSR view of J
+        std::vector<int> rptr(m + 1, 0), rcol(d.nnzjc), rslot(d.nnzjc);
+        for (int s = 0; s < d.nnzjc; ++s) rptr[PJ.rowval[s] + 1]++;
+        for (int64_t i = 0; i < m; ++i) rptr[i + 1] += rptr[i];
+        {
+            std::vector<int> fill(rptr.begin(), rptr.end() - 1);
+            for (int j = 0; j < (int)n; ++j)
+                for (int s = PJ.colptr[j]; s < PJ.colptr[j + 1]; ++s) {
+                    const int i = PJ.rowval[s];
+                    rcol[fill[i]] = j; rslot[fill[i]] = s; fill[i]++;
+                }
+        }
+        d.jcolptr = C.upload(PJ.colptr); d.jrowval = C.upload(PJ.rowval);
+        d.jrowptr = C.upload(rptr); d.jrcol = C.upload(rcol); d.jrslot = C.upload(rslot);
+        d.hcolptr = C.upload(PH.colptr); d.hrowval = C.upload(PH.rowval);
+        d.jg_ptr = C.upload(PJ.g_ptr); d.jg_src = C.upload(PJ.g_src);
+        d.hg_ptr = C.upload(PH.g_ptr); d.hg_src = C.upload(PH.g_src);
+        const size_t Bn = (size_t)B * n, Bm = (size_t)B * m, BN = (size_t)B * d.Npad;
+        d.xL = C.dalloc<double>(Bn); d.xU = C.dalloc<double>(Bn);
+        d.gL = C.dalloc<double>(Bm); d.gU = C.dalloc<double>(Bm);
+        for (int b = 0; b < B; ++b) {
+            h2d(C, d.xL + (size_t)b * n, xL, n); h2d(C, d.xU + (size_t)b * n, xU, n);
+            h2d(C, d.gL + (size_t)b * m, gL, m); h2d(C, d.gU + (size_t)b * m, gU, m);
+        }
+        d.xk = C.dalloc<double>(Bn); d.cin = C.dalloc<double>(Bn); d.bE = C.dalloc<double>(Bm);
+        d.jcoo = C.dalloc<double>((size_t)B * nnzJ); d.hcoo = C.dalloc<double>((size_t)B * nnzH);
+        d.jv = C.dalloc<double>((size_t)B * d.nnzjc); d.hv = C.dalloc<double>((size_t)B * d.nnzhc);
+        double **nvec[] = { &d.c, &d.hd, &d.lb, &d.ub, &d.p, &d.zl, &d.zu, &d.dp, &d.dzl, &d.dzu, &d.rd,
+                            &d.sigp, &d.wn, &d.op, &d.omxU, &d.omxL, &d.x, &d.mxL, &d.mxU, &d.df, &d.pstep,
+                            &d.psoc, &d.pmxL, &d.pmxU, &d.tmpx, &d.x0 };
+        for (auto pp : nvec) *pp = C.dalloc<double>(Bn);
+        double **mvec[] = { &d.lo, &d.hi, &d.wp, &d.wm, &d.s, &d.tp, &d.tm, &d.y, &d.vl, &d.vu, &d.ds,
+                            &d.dtp, &d.dtm, &d.dy, &d.dvl, &d.dvu, &d.rp, &d.Dd, &d.olam, &d.lambda, &d.E,
+                            &d.plam, &d.Esoc, &d.tmpE, &d.hlam, &d.zp, &d.zm, &d.rdir };
+        for (auto pp : mvec) *pp = C.dalloc<double>(Bm);
+        d.oslack = C.dalloc<double>(2 * Bm);
+        d.rtype = C.dalloc<int>(Bm); d.rbase = C.dalloc<int>(Bm); d.hard = C.dalloc<int>(Bm);
+        d.rhs = C.dalloc<double>(BN); d.sol = C.dalloc<double>(BN); d.wN = C.dalloc<double>(BN);
+        d.xv = C.dalloc<double>(BN); d.vv = C.dalloc<double>(BN); d.dinv = C.dalloc<double>(BN);
+        d.K = C.dalloc<double>((size_t)B * d.ld * d.Npad);
+        d.ist = C.dalloc<IpmState>(B); d.sst = C.dalloc<SqpState>(B);
+        d.phase = C.dalloc<int>(B); d.counters = C.dalloc<int>(8);
+        d.trace = C.dalloc<double>((size_t)B * SQPHIP_TRACE_CAP * SQPHIP_TRACE_COLS);
+        d.ipm_tol = opt->ipm_tol; d.ipm_max_iter = opt->ipm_max_iter;
+        d.tol_direction = opt->tol_direction; d.tol_residual = opt->tol_residual;
+        d.tol_infeas = opt->tol_infeas; d.init_mu = opt->init_mu; d.tr_size = opt->tr_size;
+        d.max_iter = opt->max_iter; d.use_soc = opt->use_soc; d.literal_quirks = opt->literal_quirks;
+        C.plan.N = d.N; C.plan.Npad = d.Npad; C.plan.T = d.Npad / 64; C.plan.ld = d.ld; C.plan.B = B;
+        C.plan.stream = C.stream;
+        C.plan.Wbuf = C.dalloc<double>((size_t)B * d.Npad * 64);
+        SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        return SQPHIP_OK;
+    });
+    if (rc != SQPHIP_OK) {
+        fprintf(stderr, "sqphip_create: %s\n", h->c.err.c_str());
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return SQPHIP_OK;
+}
+
+extern "C" void sqphip_destroy(sqphip_ctx *h)
+{
+    if (!h) return;
+    hipSetDevice(h->c.opt.device);
+    delete h;
+}
+
+extern "C" const char *sqphip_last_error(const sqphip_ctx *h) { return h ? h->c.err.c_str() : "null context"; }
+
+extern "C" int sqphip_set_bounds(sqphip_ctx *h, int32_t inst, const double *xL, const double *xU,
+                                 const double *gL, const double *gU)
+{
+    if (!h || inst < 0 || inst >= h->c.d.B) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) {
+        DV &d = C.d;
+        h2d(C, d.xL + (size_t)inst * d.n, xL, d.n); h2d(C, d.xU + (size_t)inst * d.n, xU, d.n);
+        h2d(C, d.gL + (size_t)inst * d.m, gL, d.m); h2d(C, d.gU + (size_t)inst * d.m, gU, d.m);
+        SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        return SQPHIP_OK;
+    });
+}
+
+extern "C" int sqphip_qp_solve(sqphip_ctx *h, int32_t mode, const double *x_k, double delta, double mu,
+                               const double *df, const double *E, const double *Jval, const double *Hval,
+                               double *p, double *lambda, double *mult_x_U, double *mult_x_L, double *slack,
+                               int32_t *moi_status)
+{
+    if (!h || !x_k || !Jval || !p || !lambda || !mult_x_U || !mult_x_L || !moi_status) return SQPHIP_EINVAL;
+    if (mode < 0 || mode > SQPHIP_MODE_INFEAS) return SQPHIP_EINVAL;
+    if (mode != SQPHIP_MODE_LP && (!df || !E)) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) {
+        DV &d = C.d;
+        auto t0 = std::chrono::steady_clock::now();
+        h2d(C, d.xk, x_k, d.n);
+        h2d(C, d.cin, df, d.n);
+        h2d(C, d.bE, E, d.m);
+        h2d(C, d.jcoo, Jval, d.nnzj_coo);
+        if (Hval) h2d(C, d.hcoo, Hval, d.nnzh_coo);
+        else SQPHIP_HIP_OK(hipMemsetAsync(d.hcoo, 0, sizeof(double) * (size_t)d.nnzh_coo, C.stream));
+        hipLaunchKernelGGL(k_qp_request, dim3(1), dim3(64), 0, C.stream, d, 0, (int)mode, delta, mu);
+        launch_qp_gather(C);
+        ipm_run_all(C);
+        IpmState st;
+        SQPHIP_HIP_OK(hipMemcpyAsync(&st, d.ist, sizeof(IpmState), hipMemcpyDeviceToHost, C.stream));
+        d2h(C, p, d.op, d.n); d2h(C, lambda, d.olam, d.m);
+        d2h(C, mult_x_U, d.omxU, d.n); d2h(C, mult_x_L, d.omxL, d.n);
+        d2h(C, slack, d.oslack, 2 * (size_t)d.m);
+        SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        *moi_status = st.status;
+        C.last_ipm_iters = st.ipm_iters; C.last_n_factor = st.n_factor;
+        C.n_qp += 1; C.n_ipm_iter += st.ipm_iters; C.n_factor += st.n_factor;
+        C.total_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return SQPHIP_OK;
+    });
+}
+
+extern "C" int sqphip_qp_stats(const sqphip_ctx *h, int32_t *ipm_iters, int32_t *n_factor)
+{
+    if (!h) return SQPHIP_EINVAL;
+    if (ipm_iters) *ipm_iters = h->c.last_ipm_iters;
+    if (n_factor) *n_factor = h->c.last_n_factor;
+    return SQPHIP_OK;
+}
+
+// ---- merit path -------------------------------------------------------------------------------
+extern "C" int sqphip_norm_violations(sqphip_ctx *h, const double *E, const double *x, int32_t pnorm, double *out)
+{
+    if (!h || !E || !x || !out || pnorm < 0 || pnorm > 2) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) {
+        h2d(C, C.d.E, E, C.d.m); h2d(C, C.d.x, x, C.d.n);
+        merit_eval(C, 0, 0.0, 0.0, pnorm, out);
+        return SQPHIP_OK;
+    });
+}
+
+extern "C" int sqphip_kt_residuals(sqphip_ctx *h, const double *df, const double *lambda, const double *mult_x_U,
+                                   const double *mult_x_L, const double *Jval, double *out)
+{
+    if (!h || !df || !lambda || !mult_x_U || !mult_x_L || !Jval || !out) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) {
+        DV &d = C.d;
+        h2d(C, d.df, df, d.n); h2d(C, d.lambda, lambda, d.m); h2d(C, d.mxU, mult_x_U, d.n);
+        h2d(C, d.mxL, mult_x_L, d.n); h2d(C, d.jcoo, Jval, d.nnzj_coo);
+        merit_eval(C, 1, 0.0, 0.0, 0, out);
+        return SQPHIP_OK;
+    });
+}
+
+extern "C" int sqphip_norm_complementarity(sqphip_ctx *h, const double *E, const double *lambda, int32_t pnorm,
+                                           double *out)
+{
+    if (!h || !E || !lambda || !out || pnorm < 0 || pnorm > 2) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) {
+        h2d(C, C.d.E, E, C.d.m); h2d(C, C.d.lambda, lambda, C.d.m);
+        merit_eval(C, 2, 0.0, 0.0, pnorm, out);
+        return SQPHIP_OK;
+    });
+}
+
+extern "C" int sqphip_compute_phi(sqphip_ctx *h, double f_trial, const double *E_trial, const double *x_trial,
+                                  double mu, int32_t feasibility_restoration, double *phi)
+{
+    if (!h || !E_trial || !x_trial || !phi) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) {
+        h2d(C, C.d.E, E_trial, C.d.m); h2d(C, C.d.x, x_trial, C.d.n);
+        merit_eval(C, 3, f_trial, mu, feasibility_restoration, phi);
+        return SQPHIP_OK;
+    });
+}
+
+extern "C" int sqphip_compute_qmodel(sqphip_ctx *h, const double *x, const double *p, const double *df,
+                                     const double *E, const double *Jval, const double *Hval, double mu,
+                                     int32_t with_step, double *q)
+{
+    if (!h || !x || !E || !q) return SQPHIP_EINVAL;
+    if (with_step && (!p || !df || !Jval)) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) {
+        DV &d = C.d;
+        h2d(C, d.x, x, d.n); h2d(C, d.E, E, d.m);
+        if (with_step) {
+            h2d(C, d.pstep, p, d.n); h2d(C, d.df, df, d.n); h2d(C, d.jcoo, Jval, d.nnzj_coo);
+            if (Hval) h2d(C, d.hcoo, Hval, d.nnzh_coo);
+            else SQPHIP_HIP_OK(hipMemsetAsync(d.hcoo, 0, sizeof(double) * (size_t)d.nnzh_coo, C.stream));
+        }
+        merit_eval(C, 4, 0.0, mu, with_step, q);
+        return SQPHIP_OK;
+    });
+}
+
+extern "C" int sqphip_compute_derivative(sqphip_ctx *h, const double *df, const double *p, const double *E,
+                                         double mu, double *D)
+{
+    if (!h || !df || !p || !E || !D) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) {
+        h2d(C, C.d.df, df, C.d.n); h2d(C, C.d.pstep, p, C.d.n); h2d(C, C.d.E, E, C.d.m);
+        merit_eval(C, 5, 0.0, mu, 0, D);
+        return SQPHIP_OK;
+    });
+}
+
+extern "C" int sqphip_tr_update(double ared, double pred, double delta, double pnorm_inf, double delta_max,
+                                double tol_direction, int32_t *accept_out, double *delta_out)
+{
+    if (!accept_out || !delta_out) return SQPHIP_EINVAL;
+    // sqp_trust_region.jl:529-538, :574-577; isapprox with rtol = sqrt(eps)
+    const double rho = ared / pred;
+    const bool acc = ared > 0 && rho > 0;
+    double dn = delta;
+    if (acc) {
+        const bool approx = delta == pnorm_inf ||
+                            (std::isfinite(delta) && std::isfinite(pnorm_inf) &&
+                             std::fabs(delta - pnorm_inf) <=
+                                 1.4901161193847656e-08 * std::fmax(std::fabs(delta), std::fabs(pnorm_inf)));
+        if (approx) dn = std::fmin(2 * delta, delta_max);
+    } else {
+        dn = std::fmax(0.5 * std::fmin(delta, pnorm_inf), 0.1 * tol_direction);
+    }
+    *accept_out = acc ? 1 : 0;
+    *delta_out = dn;
+    return SQPHIP_OK;
+}
+
+// ---- ACOPF evaluator + batched SQP -----------------------------------------------------------------
+extern "C" int sqphip_acopf_attach(sqphip_ctx *h, int32_t nb, int32_t ng, int32_t nl, const int32_t *f_bus,
+                                   const int32_t *t_bus, const int32_t *gen_bus, const int32_t *bal_ptr,
+                                   const int32_t *bal_colP, const int32_t *bal_colQ, const double *bal_coef,
+                                   int32_t ref_bus)
+{
+    if (!h || nb <= 0 || ng <= 0 || nl <= 0) return SQPHIP_EINVAL;
+    Ctx &C0 = h->c;
+    if (C0.d.n != 2 * nb + 2 * ng + 4 * nl || C0.d.m != 1 + 2 * nb + 8 * nl) return SQPHIP_EINVAL;
+    const int nbal = bal_ptr[nb];
+    if (C0.d.nnzj_coo != 32 * nl + 2 * ng + 1 || nbal != 2 * nl + ng || C0.d.nnzh_coo != ng + 44 * nl)
+        return SQPHIP_EINVAL;
+    for (int l = 0; l < nl; ++l)
+        if (f_bus[l] < 0 || f_bus[l] >= nb || t_bus[l] < 0 || t_bus[l] >= nb) return SQPHIP_EINVAL;
+    for (int k = 0; k < nbal; ++k)
+        if (bal_colP[k] < 0 || bal_colP[k] >= C0.d.n || bal_colQ[k] < 0 || bal_colQ[k] >= C0.d.n) return SQPHIP_EINVAL;
+    if (ref_bus < 0 || ref_bus >= nb) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) {
+        DV &d = C.d;
+        d.nb = nb; d.ng = ng; d.nl = nl; d.ref_bus = ref_bus;
+        d.f_bus = C.upload(std::vector<int>(f_bus, f_bus + nl));
+        d.t_bus = C.upload(std::vector<int>(t_bus, t_bus + nl));
+        d.gen_bus = C.upload(std::vector<int>(gen_bus, gen_bus + ng));
+        d.bal_ptr = C.upload(std::vector<int>(bal_ptr, bal_ptr + nb + 1));
+        d.bal_colP = C.upload(std::vector<int>(bal_colP, bal_colP + nbal));
+        d.bal_colQ = C.upload(std::vector<int>(bal_colQ, bal_colQ + nbal));
+        d.bal_coef = C.upload(std::vector<double>(bal_coef, bal_coef + nbal));
+        d.br_g = C.dalloc<double>((size_t)d.B * nl); d.br_b = C.dalloc<double>((size_t)d.B * nl);
+        d.br_bsh = C.dalloc<double>((size_t)d.B * nl);
+        d.c2 = C.dalloc<double>((size_t)d.B * ng); d.c1 = C.dalloc<double>((size_t)d.B * ng);
+        SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        C.acopf_attached = true;
+        return SQPHIP_OK;
+    });
+}
+
+extern "C" int sqphip_acopf_set_instance(sqphip_ctx *h, int32_t inst, const double *g, const double *b,
+                                         const double *bsh, const double *c2, const double *c1, const double *x0)
+{
+    if (!h || !h->c.acopf_attached || inst < 0 || inst >= h->c.d.B) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) {
+        DV &d = C.d;
+        h2d(C, d.br_g + (size_t)inst * d.nl, g, d.nl); h2d(C, d.br_b + (size_t)inst * d.nl, b, d.nl);
+        h2d(C, d.br_bsh + (size_t)inst * d.nl, bsh, d.nl);
+        h2d(C, d.c2 + (size_t)inst * d.ng, c2, d.ng); h2d(C, d.c1 + (size_t)inst * d.ng, c1, d.ng);
+        h2d(C, d.x0 + (size_t)inst * d.n, x0, d.n);
+        SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        return SQPHIP_OK;
+    });
+}
+
+extern "C" int sqphip_acopf_eval(sqphip_ctx *h, int32_t inst, const double *x, double sigma, const double *lambda,
+                                 double *f, double *grad, double *g, double *jval, double *hval)
+{
+    if (!h || !h->c.acopf_attached || inst < 0 || inst >= h->c.d.B || !x) return SQPHIP_EINVAL;
+    if (hval && !lambda) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) {
+        DV &d = C.d;
+        // staging in instance-`inst` scratch vectors
+        double *xd = d.tmpx + (size_t)inst * d.n, *ld = d.hlam + (size_t)inst * d.m;
+        double *gd = d.tmpE + (size_t)inst * d.m, *grd = d.wn + (size_t)inst * d.n;
+        double *jd = d.jcoo + (size_t)inst * d.nnzj_coo, *hd = d.hcoo + (size_t)inst * d.nnzh_coo;
+        double *fd = d.wN + (size_t)inst * d.Npad;
+        h2d(C, xd, x, d.n);
+        if (lambda) h2d(C, ld, lambda, d.m);
+        launch_acopf_eval_point(C, inst, xd, sigma, lambda ? ld : nullptr, f ? fd : nullptr, grad ? grd : nullptr,
+                                g ? gd : nullptr, jval ? jd : nullptr, hval ? hd : nullptr);
+        d2h(C, f, fd, 1); d2h(C, grad, grd, d.n); d2h(C, g, gd, d.m);
+        d2h(C, jval, jd, d.nnzj_coo); d2h(C, hval, hd, d.nnzh_coo);
+        SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        return SQPHIP_OK;
+    });
+}
+
+extern "C" int sqphip_sqp_reset(sqphip_ctx *h)
+{
+    if (!h || !h->c.acopf_attached) return SQPHIP_ESTATE;
+    return guarded(h, [&](Ctx &C) { sqp_reset(C); return SQPHIP_OK; });
+}
+
+extern "C" int sqphip_sqp_run(sqphip_ctx *h, int32_t max_outer)
+{
+    if (!h || !h->c.acopf_attached) return SQPHIP_ESTATE;
+    return guarded(h, [&](Ctx &C) {
+        auto t0 = std::chrono::steady_clock::now();
+        sqp_run(C, max_outer);
+        C.total_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return SQPHIP_OK;
+    });
+}
+
+extern "C" int sqphip_sqp_get(sqphip_ctx *h, int32_t inst, double *x, double *g, double *mult_g, double *mult_x_L,
+                              double *mult_x_U, double *obj_val, int32_t *status, int32_t *iter)
+{
+    if (!h || inst < 0 || inst >= h->c.d.B) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) {
+        DV &d = C.d;
+        SqpState S;
+        SQPHIP_HIP_OK(hipMemcpyAsync(&S, d.sst + inst, sizeof(SqpState), hipMemcpyDeviceToHost, C.stream));
+        d2h(C, x, d.x + (size_t)inst * d.n, d.n); d2h(C, g, d.E + (size_t)inst * d.m, d.m);
+        d2h(C, mult_g, d.lambda + (size_t)inst * d.m, d.m);
+        d2h(C, mult_x_L, d.mxL + (size_t)inst * d.n, d.n); d2h(C, mult_x_U, d.mxU + (size_t)inst * d.n, d.n);
+        SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        // sqp_trust_region.jl:219-220: mult_g = -lambda, mult_x_U = -mult_x_U
+        if (mult_g) for (int i = 0; i < d.m; ++i) mult_g[i] = -mult_g[i];
+        if (mult_x_U) for (int j = 0; j < d.n; ++j) mult_x_U[j] = -mult_x_U[j];
+        if (obj_val) *obj_val = S.obj_val;
+        if (status) *status = S.ret;
+        if (iter) *iter = S.iter;
+        return SQPHIP_OK;
+    });
+}
+
+extern "C" int sqphip_sqp_status(sqphip_ctx *h, int32_t *ret_codes, int32_t *iters, int32_t *done)
+{
+    if (!h) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) {
+        std::vector<SqpState> S(C.d.B);
+        SQPHIP_HIP_OK(hipMemcpyAsync(S.data(), C.d.sst, sizeof(SqpState) * C.d.B, hipMemcpyDeviceToHost, C.stream));
+        SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        for (int b = 0; b < C.d.B; ++b) {
+            if (ret_codes) ret_codes[b] = S[b].ret;
+            if (iters) iters[b] = S[b].iter;
+            if (done) done[b] = S[b].done;
+        }
+        return SQPHIP_OK;
+    });
+}
+
+extern "C" int sqphip_sqp_trace(sqphip_ctx *h, int32_t inst, double *rows, int32_t cap, int32_t *len)
+{
+    if (!h || inst < 0 || inst >= h->c.d.B || !len) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) {
+        SqpState S;
+        SQPHIP_HIP_OK(hipMemcpyAsync(&S, C.d.sst + inst, sizeof(SqpState), hipMemcpyDeviceToHost, C.stream));
+        SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        *len = S.trace_len;
+        const int k = std::min<int>({cap, S.trace_len, SQPHIP_TRACE_CAP});
+        if (rows && k > 0)
+            d2h(C, rows, C.d.trace + (size_t)inst * SQPHIP_TRACE_CAP * SQPHIP_TRACE_COLS,
+                (size_t)k * SQPHIP_TRACE_COLS);
+        SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        return SQPHIP_OK;
+    });
+}
+
+extern "C" int sqphip_get_counters(sqphip_ctx *h, sqphip_counters *c)
+{
+    if (!h || !c) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) {
+        std::vector<SqpState> S(C.d.B);
+        SQPHIP_HIP_OK(hipMemcpyAsync(S.data(), C.d.sst, sizeof(SqpState) * C.d.B, hipMemcpyDeviceToHost, C.stream));
+        SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        C.tm.flush();
+        int64_t nqp = C.n_qp, nip = C.n_ipm_iter, nf = C.n_factor;
+        for (auto &s : S) { nqp += s.n_qp; nip += s.tot_ipm; nf += s.tot_fac; }
+        c->n_qp = nqp; c->n_ipm_iter = nip; c->n_factor = nf;
+        const double N = (double)C.d.N;
+        c->ldlt_flops = (double)nf * N * N * N / 3.0;
+        c->ldlt_seconds = C.tm.factor_seconds; c->trailing_seconds = C.tm.trailing_seconds;
+        c->solve_seconds = C.tm.solve_seconds; c->total_seconds = C.total_seconds;
+        c->trailing_launches = C.tm.trailing_launches;
+        return SQPHIP_OK;
+    });
+}
+
+extern "C" int sqphip_reset_counters(sqphip_ctx *h)
+{
+    if (!h) return SQPHIP_EINVAL;
+    Ctx &C = h->c;
+    C.tm.flush();
+    C.tm.trailing_seconds = C.tm.factor_seconds = C.tm.solve_seconds = 0;
+    C.tm.trailing_launches = 0; C.tm.n_factor = 0;
+    C.n_qp = C.n_ipm_iter = C.n_factor = 0; C.total_seconds = 0;
+    return SQPHIP_OK;
+}
+
+// enable / disable HIP-event timing of the factor, trailing-update and solve kernels
+extern "C" int sqphip_set_timing(sqphip_ctx *h, int32_t enabled)
+{
+    if (!h) return SQPHIP_EINVAL;
+    h->c.tm.flush();
+    h->c.tm.enabled = enabled != 0;
+    return SQPHIP_OK;
+}

@@ -1,0 +1,131 @@
+// ctx.hpp -- the library context: device memory layout for a batch of NLP instances that share
+// dimensions and sparsity, and the per-instance state machines of the interior-point method and
+// of the SQP-TR outer loop.  Everything numerical lives in HBM; the host only sequences kernels.
+#pragma once
+#include "../../include/sqphip.h"
+#include "sqphip_internal.hpp"
+
+namespace sqphip {
+
+// interior-point phases of one instance (kernels act only on instances in the phase they serve)
+enum { PH_IDLE = 0, PH_PREP = 1, PH_FACTOR = 2, PH_SOLVE = 3, PH_STEP = 4, PH_DONE = 9 };
+enum { ROW_FREE = 0, ROW_EQ = 1, ROW_INEQ = 2 };
+
+struct IpmState {
+    // request
+    int mode, start, stage;        // stage 0 = programme itself, 1 = phase-1 feasibility check
+    double delta, mu_pen;
+    // set-up
+    double sf, rho_big, soft_w, hsc;
+    // iteration
+    double mu, tau, dw, dw_last, dw_floor, cn, relres, rn, e0;
+    int iter, rc, fac_attempt, dir_attempt, refine_it;
+    // outcome
+    int status, ipm_iters, n_factor;
+    double elastic;
+};
+
+// SQP-TR state of one instance: the scalar fields of SqpTR
+// (/root/reference/src/algorithms/sqp_trust_region.jl:6-24, sqp.jl:16-59)
+struct SqpState {
+    double f, phi, mu, Delta, prim_infeas, dual_infeas, pnorm, obj_val;
+    double f_trial, phi_k, q0, ared, pred;
+    int iter, ret, step_acceptance, fr, sub_status, done, stage, need_qp, qp_mode, want_eval;
+    int n_qp, trace_len, it_ipm, soc_pending, lp_pending, started;
+    long tot_ipm, tot_fac;
+};
+
+#define SQPHIP_TRACE_COLS 12
+#define SQPHIP_TRACE_CAP 4096
+
+// everything kernels need, by value
+struct DV {
+    int n, m, nlin, N, Npad, ld, B;
+    int nnzj_coo, nnzh_coo, nnzjc, nnzhc;
+    // shared structure
+    const int *jcolptr, *jrowval, *jrowptr, *jrcol, *jrslot;
+    const int *hcolptr, *hrowval;
+    const int *jg_ptr, *jg_src, *hg_ptr, *hg_src;
+    // per-instance NLP bounds
+    double *xL, *xU, *gL, *gU;
+    // per-instance QP request
+    double *xk, *cin, *bE, *jcoo, *hcoo, *jv, *hv;
+    // canonical programme
+    double *c, *hd, *lb, *ub, *lo, *hi, *wp, *wm;
+    int *rtype, *rbase, *hard;
+    // iterate, directions, work vectors
+    double *p, *zl, *zu, *s, *tp, *tm, *y, *vl, *vu, *zp, *zm, *rdir;
+    double *dp, *dzl, *dzu, *ds, *dtp, *dtm, *dy, *dvl, *dvu;
+    double *rd, *rp, *sigp, *Dd, *rhs, *sol, *wn, *wN;
+    // linear algebra
+    double *K, *dinv, *xv, *vv;
+    // QP outputs
+    double *op, *olam, *omxU, *omxL, *oslack;
+    IpmState *ist;
+    int *phase;
+    int *counters;      // [0] instances iterating, [1] start flags, [2] SQP not done, [3] start flags
+    double ipm_tol;
+    int ipm_max_iter;
+    // ---- SQP level
+    double *x, *lambda, *mxL, *mxU, *df, *E, *pstep, *psoc, *plam, *pmxL, *pmxU, *Esoc, *tmpx, *tmpE,
+        *hlam;
+    SqpState *sst;
+    double *trace;      // [B][CAP][COLS]
+    // ---- ACOPF evaluator data
+    int nb, ng, nl, ref_bus;
+    const int *f_bus, *t_bus, *gen_bus, *bal_ptr, *bal_colP, *bal_colQ;
+    const double *bal_coef;
+    double *br_g, *br_b, *br_bsh, *c2, *c1, *x0;   // per instance
+    // options
+    double tol_direction, tol_residual, tol_infeas, init_mu, tr_size;
+    int max_iter, use_soc, literal_quirks;
+};
+
+struct Ctx {
+    sqphip_options opt;
+    DV d;                       // device view (pointers into the arenas below)
+    LdltPlan plan;
+    Timers tm;
+    std::vector<void *> allocs;
+    std::string err;
+    hipStream_t stream = nullptr;
+    int *h_counters = nullptr;  // pinned
+    bool acopf_attached = false;
+    // host copies of structure for misc use
+    int64_t n = 0, m = 0;
+    // counters
+    int64_t n_qp = 0, n_ipm_iter = 0, n_factor = 0;
+    double total_seconds = 0;
+    int last_ipm_iters = 0, last_n_factor = 0;
+
+    template <class T> T *dalloc(size_t count)
+    {
+        void *p = nullptr;
+        SQPHIP_HIP_OK(hipMalloc(&p, sizeof(T) * (count ? count : 1)));
+        SQPHIP_HIP_OK(hipMemsetAsync(p, 0, sizeof(T) * (count ? count : 1), stream));
+        allocs.push_back(p);
+        return (T *)p;
+    }
+    template <class T> T *upload(const std::vector<T> &v)
+    {
+        T *p = dalloc<T>(v.size());
+        if (!v.empty())
+            SQPHIP_HIP_OK(hipMemcpyAsync(p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, stream));
+        return p;
+    }
+    ~Ctx();
+};
+
+// ipm.hip
+void ipm_run_all(Ctx &C);            // runs every instance whose IpmState.start is set, to completion
+void launch_qp_gather(Ctx &C);       // COO -> CSC for instances with start set (stage 0)
+// acopf.hip
+void launch_acopf_eval_point(Ctx &C, int inst, const double *x_dev, double sigma, const double *lam_dev,
+                             double *f_dev, double *grad_dev, double *g_dev, double *jcoo_dev,
+                             double *hcoo_dev);
+// sqp.hip
+void sqp_reset(Ctx &C);
+void sqp_run(Ctx &C, int max_outer);
+void merit_eval(Ctx &C, int op, double a0, double a1, int flag, double *out_host);
+
+}  // namespace sqphip

@@ -1,0 +1,656 @@
+// ipm.hip -- batched primal-dual interior-point method for the trust-region QP sub-problems.
+//
+// Seat in the reference: everything behind `JuMP.optimize!(qp.model)` in
+// /root/reference/src/algorithms/subproblem_JuMP.jl:178,209,336,388,418 (Ipopt + its linear solver,
+// neither vendored).  The mathematical programmes are those of SURVEY.md Appendix A:
+//   rows typed as subproblem_JuMP.jl:79-112, shifted as :492-505, trust-region box :432-456,
+//   FR slack rule :365-380, L1QP / INFEAS :324-330 / :407-413, LP phase :185-244,
+//   results reported as collect_solution! does (:514-563).
+//
+// Method (DESIGN.md section "IPM"): every row carries elastic variables tp, tm >= 0 so the programme
+// always has a strict interior and the start satisfies the (linear) row equations exactly; hard rows
+// are priced at rho_big (exact penalty) and a phase-1 run separates "infeasible" from "penalty too
+// small".  Monotone Fiacco-McCormick barrier updates, one Newton direction per iteration from the
+// reduced KKT system K = [W J'; J -D] factorised by the batched dense LDL^T (ldlt.hip), inertia
+// judged on pivot signs (n positive, m negative) with delta_w escalation, a fixed primal-dual
+// regularisation of 1e-8, fraction-to-boundary step lengths.  One 256-thread workgroup owns an instance in the vector kernels; wave-level
+// shuffles + a 4-entry LDS exchange do the reductions.
+#include "ctx.hpp"
+#include "dev_util.hpp"
+#include <cmath>
+
+namespace sqphip {
+
+#define RHO_BIG0 1e4
+#define RHO_BIG_MAX 1e10
+#define ELASTIC_TOL 1e-8
+// primal-dual regularisation of the Newton matrix (part of the method; residuals are unregularised)
+#define IPM_REG_P 1e-8
+#define IPM_REG_D 1e-8
+
+// out_j = hsc * (H v)_j + hd_j v_j   (H full symmetric CSC, gather by column)
+__device__ void hess_mul(const DV &d, int inst, double hsc, const double *v, double *out)
+{
+    const double *hv = d.hv + (long)inst * d.nnzhc, *hd = d.hd + (long)inst * d.n;
+    for (int j = threadIdx.x; j < d.n; j += TPB) {
+        double acc = 0.0;
+        for (int k = d.hcolptr[j]; k < d.hcolptr[j + 1]; ++k) acc += hv[k] * v[d.hrowval[k]];
+        out[j] = hsc * acc + hd[j] * v[j];
+    }
+}
+// out_i = J_i v over active rows (CSR view)
+__device__ void jac_mul(const DV &d, int inst, const double *v, double *out)
+{
+    const double *jv = d.jv + (long)inst * d.nnzjc;
+    const int *rt = d.rtype + (long)inst * d.m;
+    for (int i = threadIdx.x; i < d.m; i += TPB) {
+        double acc = 0.0;
+        if (rt[i] != ROW_FREE)
+            for (int k = d.jrowptr[i]; k < d.jrowptr[i + 1]; ++k) acc += jv[d.jrslot[k]] * v[d.jrcol[k]];
+        out[i] = acc;
+    }
+}
+// (J' w)_j over active rows
+__device__ __forceinline__ double jact_col(const DV &d, const double *jv, const int *rt, const double *w, int j)
+{
+    double acc = 0.0;
+    for (int k = d.jcolptr[j]; k < d.jcolptr[j + 1]; ++k) {
+        const int i = d.jrowval[k];
+        if (rt[i] != ROW_FREE) acc += jv[k] * w[i];
+    }
+    return acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: COO -> CSC with duplicate summation by precomputed gather lists (sqp.jl:94-102, :113-116)
+__global__ __launch_bounds__(TPB) void k_qp_gather(DV d)
+{
+    const int inst = blockIdx.x;
+    const IpmState &st = d.ist[inst];
+    if (!st.start || st.stage != 0) return;
+    const double *jc = d.jcoo + (long)inst * d.nnzj_coo, *hc = d.hcoo + (long)inst * d.nnzh_coo;
+    double *jv = d.jv + (long)inst * d.nnzjc, *hv = d.hv + (long)inst * d.nnzhc;
+    for (int s = threadIdx.x; s < d.nnzjc; s += TPB) {
+        double a = 0.0;
+        for (int k = d.jg_ptr[s]; k < d.jg_ptr[s + 1]; ++k) a += jc[d.jg_src[k]];
+        jv[s] = a;
+    }
+    for (int s = threadIdx.x; s < d.nnzhc; s += TPB) {
+        double a = 0.0;
+        for (int k = d.hg_ptr[s]; k < d.hg_ptr[s + 1]; ++k) a += hc[d.hg_src[k]];
+        hv[s] = a;
+    }
+}
+
+__device__ __forceinline__ double push_inside(double v, double lo, double hi)
+{
+    const double k1 = 1e-2, k2 = 1e-2;
+    const bool hl = fin(lo), hu = fin(hi);
+    if (hl && hu) {
+        const double w = hi - lo;
+        const double pl = fmin(k1 * fmax(1.0, fabs(lo)), k2 * w);
+        const double pu = fmin(k1 * fmax(1.0, fabs(hi)), k2 * w);
+        if (v < lo + pl) v = lo + pl;
+        if (v > hi - pu) v = hi - pu;
+    } else if (hl) {
+        const double pl = k1 * fmax(1.0, fabs(lo));
+        if (v < lo + pl) v = lo + pl;
+    } else if (hu) {
+        const double pu = k1 * fmax(1.0, fabs(hi));
+        if (v > hi - pu) v = hi - pu;
+    }
+    return v;
+}
+
+// keep a primal variable a few ulps inside its box (p + a dp may round onto the bound)
+__device__ __forceinline__ double nudge_inside(double v, double lo, double hi)
+{
+    if (fin(lo)) { const double g = 1e-15 * fmax(1.0, fabs(lo)); if (v - lo < g) v = lo + g; }
+    if (fin(hi)) { const double g = 1e-15 * fmax(1.0, fabs(hi)); if (hi - v < g) v = hi - g; }
+    return v;
+}
+
+#define INST_PTRS                                                                                   \
+    const long on = (long)inst * d.n, om = (long)inst * d.m;                                       \
+    double *c = d.c + on, *hd = d.hd + on, *lb = d.lb + on, *ub = d.ub + on;                        \
+    double *lo = d.lo + om, *hi = d.hi + om, *wp = d.wp + om, *wm = d.wm + om;                      \
+    int *rt = d.rtype + om, *rb = d.rbase + om, *hard = d.hard + om;                                \
+    double *p = d.p + on, *zl = d.zl + on, *zu = d.zu + on;                                         \
+    double *s = d.s + om, *tp = d.tp + om, *tm = d.tm + om, *y = d.y + om, *vl = d.vl + om,         \
+           *vu = d.vu + om;                                                                         \
+    double *dp = d.dp + on, *dzl = d.dzl + on, *dzu = d.dzu + on;                                   \
+    double *ds = d.ds + om, *dtp = d.dtp + om, *dtm = d.dtm + om, *dy = d.dy + om,                  \
+           *dvl = d.dvl + om, *dvu = d.dvu + om;                                                    \
+    double *rd = d.rd + on, *rp = d.rp + om, *sigp = d.sigp + on, *Dd = d.Dd + om;                  \
+    double *rhs = d.rhs + (long)inst * d.Npad, *sol = d.sol + (long)inst * d.Npad;                  \
+    double *wn = d.wn + on, *wN = d.wN + (long)inst * d.Npad;                                       \
+    double *zpv = d.zp + om, *zmv = d.zm + om, *rdir = d.rdir + om;                                 \
+    (void)zpv; (void)zmv; (void)rdir;                                                               \
+    const double *jv = d.jv + (long)inst * d.nnzjc;                                                 \
+    (void)c; (void)hd; (void)lb; (void)ub; (void)lo; (void)hi; (void)wp; (void)wm; (void)rt;        \
+    (void)rb; (void)hard; (void)p; (void)zl; (void)zu; (void)s; (void)tp; (void)tm; (void)y;        \
+    (void)vl; (void)vu; (void)dp; (void)dzl; (void)dzu; (void)ds; (void)dtp; (void)dtm; (void)dy;   \
+    (void)dvl; (void)dvu; (void)rd; (void)rp; (void)sigp; (void)Dd; (void)rhs; (void)sol; (void)wn; \
+    (void)wN; (void)jv;
+
+// ---------------------------------------------------------------------------------------------
+// Mode set-up (stage 0 only computes the request-dependent data), weights, interior start.
+__global__ __launch_bounds__(TPB) void k_ipm_start(DV d)
+{
+    const int inst = blockIdx.x;
+    IpmState &st = d.ist[inst];
+    if (!st.start) return;
+    INST_PTRS
+    const int mode = st.mode;
+    const double delta = st.delta;
+    const double *xk = d.xk + on, *cin = d.cin + on, *bE = d.bE + om;
+    const double *xL = d.xL + on, *xU = d.xU + on, *gL = d.gL + om, *gU = d.gU + om;
+    const bool use_obj = (mode == SQPHIP_MODE_QP || mode == SQPHIP_MODE_SOC || mode == SQPHIP_MODE_L1QP);
+    const bool lp = mode == SQPHIP_MODE_LP;
+    // objective scale from the raw gradient
+    double cm = 0.0;
+    for (int j = threadIdx.x; j < d.n; j += TPB) {
+        const double cj = lp ? -2.0 * xk[j] : (use_obj ? cin[j] : 0.0);
+        cm = fmax(cm, fabs(cj));
+    }
+    cm = block_reduce<OpMax>(cm);
+    const double sf = cm > 100.0 ? 100.0 / cm : 1.0;
+    const double osc = st.stage == 0 ? sf : 0.0;       // phase 1 drops the objective
+    for (int j = threadIdx.x; j < d.n; j += TPB) {
+        double l, u;
+        if (lp) { l = xL[j]; u = xU[j]; }
+        else {
+            const double vl_ = xL[j] - xk[j], vu_ = xU[j] - xk[j];
+            l = fmax(-delta, vl_); u = fmin(delta, vu_);
+            if (l > u) { l = fmax(-delta, fmin(0.0, vl_)); u = fmin(delta, fmax(0.0, vu_)); }
+        }
+        if (fin(l) && fin(u) && u - l < 1e-8) { const double mid = 0.5 * (l + u); l = mid - 5e-9; u = mid + 5e-9; }
+        lb[j] = l; ub[j] = u;
+        c[j] = osc * (lp ? -2.0 * xk[j] : (use_obj ? cin[j] : 0.0));
+        hd[j] = lp ? 2.0 * osc : 0.0;
+    }
+    const double soft_w = (mode == SQPHIP_MODE_L1QP ? st.mu_pen : 1.0) * sf;
+    for (int i = threadIdx.x; i < d.m; i += TPB) {
+        const double gl = gL[i], gu = gU[i];
+        int ty, hd_;
+        if (lp && i >= d.nlin) { ty = ROW_FREE; hd_ = 1; lo[i] = 0.0; hi[i] = 0.0; }
+        else {
+            if (lp) { lo[i] = gl; hi[i] = gu; } else { lo[i] = gl - bE[i]; hi[i] = gu - bE[i]; }
+            if (gl == gu) ty = ROW_EQ;
+            else if (gl > -INFINITY || gu < INFINITY) ty = ROW_INEQ;
+            else ty = ROW_FREE;
+            const bool nonlinear = i >= d.nlin;
+            if (mode == SQPHIP_MODE_FR) hd_ = !(nonlinear && !(bE[i] >= gl && bE[i] <= gu));
+            else if (mode == SQPHIP_MODE_L1QP || mode == SQPHIP_MODE_INFEAS) hd_ = !nonlinear;
+            else hd_ = 1;
+        }
+        rb[i] = ty; hard[i] = hd_;
+        if (st.stage == 1) {      // phase 1: only hard rows, unit weights
+            rt[i] = hd_ ? ty : ROW_FREE;
+            wp[i] = wm[i] = 1.0;
+        } else {
+            rt[i] = ty;
+            wp[i] = wm[i] = hd_ ? st.rho_big : soft_w;
+        }
+    }
+    __syncthreads();
+    // interior start
+    const double mu0 = 1.0;
+    for (int j = threadIdx.x; j < d.n; j += TPB) {
+        const double pj = push_inside(lp ? xk[j] : 0.0, lb[j], ub[j]);
+        p[j] = pj;
+        zl[j] = fin(lb[j]) ? mu0 / (pj - lb[j]) : 0.0;
+        zu[j] = fin(ub[j]) ? mu0 / (ub[j] - pj) : 0.0;
+    }
+    __syncthreads();
+    jac_mul(d, inst, p, rp);      // rp used as scratch for J p0
+    __syncthreads();
+    for (int i = threadIdx.x; i < d.m; i += TPB) {
+        double si = 0, tpi = 0, tmi = 0, yi = 0, vli = 0, vui = 0;
+        if (rt[i] != ROW_FREE) {
+            const double v = rp[i];
+            si = rt[i] == ROW_EQ ? lo[i] : push_inside(v, lo[i], hi[i]);
+            const double dd = si - v;
+            if (rt[i] == ROW_INEQ) {
+                if (fin(lo[i])) vli = mu0 / (si - lo[i]);
+                if (fin(hi[i])) vui = mu0 / (hi[i] - si);
+                yi = vli - vui;
+                const double cap = 0.5 * fmin(wp[i], wm[i]);
+                if (fabs(yi) > cap) { const double sc = cap / fabs(yi); vli *= sc; vui *= sc; yi *= sc; }
+            }
+            tpi = fmax(dd, 0.0) + mu0 / (wp[i] - yi);
+            tmi = fmax(-dd, 0.0) + mu0 / (wm[i] + yi);
+            const double e = (tpi - tmi) - dd;
+            if (e > 0) tmi += e; else tpi -= e;
+        }
+        s[i] = si; tp[i] = tpi; tm[i] = tmi; y[i] = yi; vl[i] = vli; vu[i] = vui;
+        zpv[i] = rt[i] == ROW_FREE ? 1.0 : wp[i] - yi; zmv[i] = rt[i] == ROW_FREE ? 1.0 : wm[i] + yi;
+    }
+    if (threadIdx.x == 0) {
+        st.sf = sf; st.soft_w = soft_w; st.hsc = (st.stage == 0 && use_obj) ? sf : 0.0;
+        st.mu = 1.0; st.iter = 0; st.rc = -1; st.dw_last = 0.0; st.dw = 0.0; st.dw_floor = 0.0;
+        st.cn = 0.0;
+        st.start = 0;
+        d.phase[inst] = PH_PREP;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// top of an interior-point iteration: residuals, convergence test, barrier update, diagonals
+__global__ __launch_bounds__(TPB) void k_ipm_prepare(DV d)
+{
+    const int inst = blockIdx.x;
+    if (d.phase[inst] != PH_PREP) return;
+    IpmState &st = d.ist[inst];
+    INST_PTRS
+    if (st.iter >= d.ipm_max_iter) {
+        if (threadIdx.x == 0) { st.rc = 1; d.phase[inst] = PH_DONE; }
+        return;
+    }
+    const double hsc = st.hsc;
+    hess_mul(d, inst, hsc, p, rd);
+    jac_mul(d, inst, p, rp);
+    __syncthreads();
+    double csum = 0, cmax = 0, rdn = 0, rpn = 0, dl1 = 0, nc = 0;
+    for (int j = threadIdx.x; j < d.n; j += TPB) {
+        double r = rd[j] + c[j] - jact_col(d, jv, rt, y, j);
+        const double g_l = p[j] - lb[j], g_u = ub[j] - p[j];
+        double sg = 0.0;
+        if (fin(lb[j])) { r -= zl[j]; const double cc = zl[j] * g_l; csum += cc; cmax = fmax(cmax, cc); nc += 1; dl1 += zl[j]; sg += zl[j] / g_l; }
+        if (fin(ub[j])) { r += zu[j]; const double cc = zu[j] * g_u; csum += cc; cmax = fmax(cmax, cc); nc += 1; dl1 += zu[j]; sg += zu[j] / g_u; }
+        rd[j] = r; sigp[j] = sg;
+        rdn = fmax(rdn, fabs(r));
+    }
+    for (int i = threadIdx.x; i < d.m; i += TPB) {
+        if (rt[i] == ROW_FREE) { rp[i] = 0.0; Dd[i] = 1.0; continue; }
+        const double r = rp[i] + tp[i] - tm[i] - s[i];
+        rp[i] = r; rpn = fmax(rpn, fabs(r));
+        const double zp = zpv[i], zm = zmv[i];
+        double cc = zp * tp[i]; csum += cc; cmax = fmax(cmax, cc);
+        cc = zm * tm[i]; csum += cc; cmax = fmax(cmax, cc); nc += 2;
+        dl1 += fabs(y[i]);
+        double dd = tp[i] / zp + tm[i] / zm;
+        if (rt[i] == ROW_INEQ) {
+            double sig = 0.0;
+            if (fin(lo[i])) { const double al = s[i] - lo[i]; cc = vl[i] * al; csum += cc; cmax = fmax(cmax, cc); nc += 1; sig += vl[i] / al; }
+            if (fin(hi[i])) { const double au = hi[i] - s[i]; cc = vu[i] * au; csum += cc; cmax = fmax(cmax, cc); nc += 1; sig += vu[i] / au; }
+            dd += 1.0 / sig;
+        }
+        Dd[i] = dd;
+    }
+    csum = block_reduce<OpSum>(csum); cmax = block_reduce<OpMax>(cmax);
+    rdn = block_reduce<OpMax>(rdn); rpn = block_reduce<OpMax>(rpn);
+    dl1 = block_reduce<OpSum>(dl1); nc = block_reduce<OpSum>(nc);
+    const double cavg = nc > 0 ? csum / nc : 0.0;
+    if (!fin(rdn) || !fin(cavg) || !fin(rpn)) {
+        if (threadIdx.x == 0) { st.rc = 2; d.phase[inst] = PH_DONE; }
+        return;
+    }
+    const double sd = fmax(100.0, dl1 / (double)(d.n + d.m)) / 100.0;
+    const double e0 = fmax(fmax(rdn / sd, rpn), cmax / sd);
+    if (e0 <= d.ipm_tol) {
+        if (threadIdx.x == 0) { st.rc = 0; d.phase[inst] = PH_DONE; }
+        return;
+    }
+    // barrier update: mu <- max(mu_min, min(0.2 mu, mu^1.5)) while the barrier problem is solved
+    double mu = st.mu;
+    const double mu_min = d.ipm_tol / 10.0;
+    for (int kk = 0; kk < 20; ++kk) {
+        double ce = 0.0;
+        for (int j = threadIdx.x; j < d.n; j += TPB) {
+            if (fin(lb[j])) ce = fmax(ce, fabs(zl[j] * (p[j] - lb[j]) - mu));
+            if (fin(ub[j])) ce = fmax(ce, fabs(zu[j] * (ub[j] - p[j]) - mu));
+        }
+        for (int i = threadIdx.x; i < d.m; i += TPB) {
+            if (rt[i] == ROW_FREE) continue;
+            ce = fmax(ce, fabs(zpv[i] * tp[i] - mu));
+            ce = fmax(ce, fabs(zmv[i] * tm[i] - mu));
+            if (rt[i] == ROW_INEQ) {
+                if (fin(lo[i])) ce = fmax(ce, fabs(vl[i] * (s[i] - lo[i]) - mu));
+                if (fin(hi[i])) ce = fmax(ce, fabs(vu[i] * (hi[i] - s[i]) - mu));
+            }
+        }
+        ce = block_reduce<OpMax>(ce);
+        const double emu = fmax(fmax(rdn / sd, rpn), ce / sd);
+        if (emu > 10.0 * mu || mu <= mu_min) break;
+        mu = fmax(mu_min, fmin(0.2 * mu, pow(mu, 1.5)));
+    }
+    if (threadIdx.x == 0) {
+        st.mu = mu; st.tau = fmax(0.99, 1.0 - mu); st.e0 = e0;
+        st.ipm_iters++;
+        st.dw = 0.0; st.dw_floor = 0.0; st.fac_attempt = 0; st.dir_attempt = 0;
+        d.phase[inst] = PH_FACTOR;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4: dense KKT assembly, one workgroup per column: zero the column from the diagonal down, then
+// scatter H (lower), J and the diagonals.  Padding columns are identity.
+__global__ __launch_bounds__(128) void k_kkt_assemble(DV d)
+{
+    const int inst = blockIdx.y;
+    if (d.phase[inst] != PH_FACTOR) return;
+    const int j = blockIdx.x;
+    const IpmState &st = d.ist[inst];
+    double *col = d.K + (long)inst * d.ld * d.Npad + (long)j * d.ld;
+    for (int i = j + threadIdx.x; i < d.Npad; i += 128) col[i] = 0.0;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    if (j >= d.N) { col[j] = 1.0; return; }
+    if (j >= d.n) {
+        const int i = j - d.n;
+        col[j] = d.rtype[(long)inst * d.m + i] == ROW_FREE ? -1.0 : -(d.Dd[(long)inst * d.m + i] + IPM_REG_D);
+        return;
+    }
+    const double hsc = st.hsc;
+    const double *hv = d.hv + (long)inst * d.nnzhc, *jv = d.jv + (long)inst * d.nnzjc;
+    const int *rt = d.rtype + (long)inst * d.m;
+    double diag = d.hd[(long)inst * d.n + j] + d.sigp[(long)inst * d.n + j] + st.dw + IPM_REG_P;
+    for (int k = d.hcolptr[j]; k < d.hcolptr[j + 1]; ++k) {
+        const int i = d.hrowval[k];
+        if (i == j) diag += hsc * hv[k];
+        else if (i > j) col[i] += hsc * hv[k];
+    }
+    col[j] = diag;
+    for (int k = d.jcolptr[j]; k < d.jcolptr[j + 1]; ++k) {
+        const int i = d.jrowval[k];
+        if (rt[i] != ROW_FREE) col[d.n + i] += jv[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// after the factorisation: inertia from pivot signs; on success build the Newton right-hand side
+__global__ __launch_bounds__(TPB) void k_inertia_rhs(DV d)
+{
+    const int inst = blockIdx.x;
+    if (d.phase[inst] != PH_FACTOR) return;
+    IpmState &st = d.ist[inst];
+    INST_PTRS
+    const double *dinv = d.dinv + (long)inst * d.Npad;
+    double np = 0, bad = 0;
+    for (int i = threadIdx.x; i < d.N; i += TPB) {
+        const double v = dinv[i];
+        if (!fin(v) || v == 0.0) bad += 1; else if (v > 0) np += 1;
+    }
+    np = block_reduce<OpSum>(np); bad = block_reduce<OpSum>(bad);
+    const bool ok = (np == (double)d.n) && bad == 0;
+    if (!ok) {
+        if (threadIdx.x == 0) {
+            st.n_factor++;
+            st.fac_attempt++;
+            double dw = st.dw;
+            if (dw == 0.0) dw = st.dw_last == 0.0 ? 1e-4 : fmax(1e-20, st.dw_last / 3.0);
+            else dw *= (st.dw_last == 0.0 ? 100.0 : 8.0);
+            st.dw = dw;
+            if (dw > 1e40 || st.fac_attempt >= 60) { st.rc = 2; d.phase[inst] = PH_DONE; }
+        }
+        return;
+    }
+    const double tgt = st.mu;
+    double rn = 0.0;
+    for (int j = threadIdx.x; j < d.n; j += TPB) {
+        double g = -rd[j];
+        if (fin(lb[j])) { const double gl = p[j] - lb[j]; g += (tgt - zl[j] * gl) / gl; }
+        if (fin(ub[j])) { const double gu = ub[j] - p[j]; g -= (tgt - zu[j] * gu) / gu; }
+        rhs[j] = g; rn = fmax(rn, fabs(g));
+    }
+    for (int i = threadIdx.x; i < d.m; i += TPB) {
+        double b = 0.0;
+        if (rt[i] != ROW_FREE) {
+            const double zp = zpv[i], zm = zmv[i];
+            const double cp = tgt - zp * tp[i], cm = tgt - zm * tm[i];
+            b = -rp[i] - cp / zp + cm / zm;
+            if (rt[i] == ROW_INEQ) {
+                double sig = 0.0, t = 0.0;
+                if (fin(lo[i])) { const double al = s[i] - lo[i]; sig += vl[i] / al; t += (tgt - vl[i] * al) / al; }
+                if (fin(hi[i])) { const double au = hi[i] - s[i]; sig += vu[i] / au; t -= (tgt - vu[i] * au) / au; }
+                b += t / sig;
+            }
+        }
+        rhs[d.n + i] = b; rn = fmax(rn, fabs(b));
+    }
+    rn = block_reduce<OpMax>(rn);
+    double *xv = d.xv + (long)inst * d.Npad;
+    for (int i = threadIdx.x; i < d.Npad; i += TPB) {
+        const double v = i < d.N ? rhs[i] : 0.0;
+        xv[i] = v;
+        sol[i] = 0.0;
+    }
+    if (threadIdx.x == 0) {
+        st.n_factor++;
+        if (st.dw > 0.0) st.dw_last = st.dw;
+        st.rn = fmax(1.0, rn);
+        st.refine_it = 0;
+        d.phase[inst] = PH_SOLVE;
+    }
+}
+
+// after a triangular solve: accumulate, form the residual against the sparse operator, decide
+__global__ __launch_bounds__(TPB) void k_refine(DV d, int last)
+{
+    const int inst = blockIdx.x;
+    if (d.phase[inst] != PH_SOLVE) return;
+    IpmState &st = d.ist[inst];
+    INST_PTRS
+    double *xv = d.xv + (long)inst * d.Npad;
+    for (int i = threadIdx.x; i < d.N; i += TPB) sol[i] += xv[i];
+    __syncthreads();
+    const double hsc = st.hsc;
+    // res = rhs - K sol : top block (H + hd + sigp + dw) dp + J' q ; bottom J dp - D q
+    hess_mul(d, inst, hsc, sol, wn);
+    jac_mul(d, inst, sol, wN + d.n);
+    __syncthreads();
+    double en = 0.0;
+    for (int j = threadIdx.x; j < d.n; j += TPB) {
+        const double kx = wn[j] + (sigp[j] + st.dw + IPM_REG_P) * sol[j] + jact_col(d, jv, rt, sol + d.n, j);
+        const double r = rhs[j] - kx;
+        wN[j] = r; en = fmax(en, fabs(r));
+    }
+    for (int i = threadIdx.x; i < d.m; i += TPB) {
+        const double dd = rt[i] == ROW_FREE ? 1.0 : Dd[i] + IPM_REG_D;
+        const double r = rhs[d.n + i] - (wN[d.n + i] - dd * sol[d.n + i]);
+        wN[d.n + i] = r; en = fmax(en, fabs(r));
+    }
+    en = block_reduce<OpMax>(en);
+    const bool stop = last || st.refine_it >= 2 || !(en > 1e-11 * st.rn);
+    if (!stop)
+        for (int i = threadIdx.x; i < d.Npad; i += TPB) xv[i] = i < d.N ? wN[i] : 0.0;
+    if (threadIdx.x == 0) {
+        st.relres = en / st.rn;
+        if (stop) d.phase[inst] = PH_STEP; else st.refine_it++;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double ratio(double x, double dx, double a)
+{
+    if (dx < 0.0) { const double r = -x / dx; if (r < a) a = r; }
+    return a;
+}
+
+// directions, fraction-to-boundary step lengths, update
+__global__ __launch_bounds__(TPB) void k_ipm_step(DV d)
+{
+    const int inst = blockIdx.x;
+    if (d.phase[inst] != PH_STEP) return;
+    IpmState &st = d.ist[inst];
+    INST_PTRS
+    const double tgt = st.mu, mu = st.mu;
+    double ap = 1e300, ad = 1e300;
+    for (int j = threadIdx.x; j < d.n; j += TPB) {
+        const double dpj = sol[j];
+        dp[j] = dpj;
+        double a = 0.0, b = 0.0;
+        if (fin(lb[j])) { const double gl = p[j] - lb[j]; a = (tgt - zl[j] * gl - zl[j] * dpj) / gl; ap = ratio(gl, dpj, ap); ad = ratio(zl[j], a, ad); }
+        if (fin(ub[j])) { const double gu = ub[j] - p[j]; b = (tgt - zu[j] * gu + zu[j] * dpj) / gu; ap = ratio(gu, -dpj, ap); ad = ratio(zu[j], b, ad); }
+        dzl[j] = a; dzu[j] = b;
+    }
+    for (int i = threadIdx.x; i < d.m; i += TPB) {
+        double dyi = 0, dsi = 0, dtpi = 0, dtmi = 0, dvli = 0, dvui = 0;
+        if (rt[i] != ROW_FREE) {
+            dyi = -sol[d.n + i];
+            const double zp = zpv[i], zm = zmv[i];
+            dtpi = (tgt - zp * tp[i] + tp[i] * dyi) / zp;
+            dtmi = (tgt - zm * tm[i] - tm[i] * dyi) / zm;
+            ap = ratio(tp[i], dtpi, ap); ap = ratio(tm[i], dtmi, ap);
+            ad = ratio(zp, -dyi, ad); ad = ratio(zm, dyi, ad);
+            if (rt[i] == ROW_INEQ) {
+                double sig = 0, t = 0, al = 0, au = 0, cl = 0, cu = 0;
+                const bool hl = fin(lo[i]), hu = fin(hi[i]);
+                if (hl) { al = s[i] - lo[i]; cl = tgt - vl[i] * al; sig += vl[i] / al; t += cl / al; }
+                if (hu) { au = hi[i] - s[i]; cu = tgt - vu[i] * au; sig += vu[i] / au; t -= cu / au; }
+                dsi = (t - dyi) / sig;
+                if (hl) { dvli = (cl - vl[i] * dsi) / al; ap = ratio(al, dsi, ap); ad = ratio(vl[i], dvli, ad); }
+                if (hu) { dvui = (cu + vu[i] * dsi) / au; ap = ratio(au, -dsi, ap); ad = ratio(vu[i], dvui, ad); }
+            }
+        }
+        dy[i] = dyi; ds[i] = dsi; dtp[i] = dtpi; dtm[i] = dtmi; dvl[i] = dvli; dvu[i] = dvui;
+    }
+    ap = block_reduce<OpMin>(ap); ad = block_reduce<OpMin>(ad);
+    // plain fraction-to-boundary step lengths, primal and dual separately
+    const double a = fmin(1.0, st.tau * ap), a_d = fmin(1.0, st.tau * ad);
+    const bool ok = fin(st.relres) && st.relres < 1e-6 && fin(a) && fin(a_d);
+    if (!ok) {
+        if (threadIdx.x == 0) {
+            st.dir_attempt++;
+            const double fl = st.dw > 0.0 ? 8.0 * st.dw : (st.dw_last > 0.0 ? st.dw_last : 1e-4);
+            st.dw_floor = fl; st.dw = fl; st.fac_attempt = 0;
+            if (st.dir_attempt >= 12 || fl > 1e20) { st.rc = 2; d.phase[inst] = PH_DONE; }
+            else d.phase[inst] = PH_FACTOR;
+        }
+        return;
+    }
+    for (int j = threadIdx.x; j < d.n; j += TPB) {
+        p[j] = nudge_inside(p[j] + a * dp[j], lb[j], ub[j]); zl[j] += a_d * dzl[j]; zu[j] += a_d * dzu[j];
+    }
+    for (int i = threadIdx.x; i < d.m; i += TPB) {
+        if (rt[i] == ROW_FREE) continue;
+        tp[i] += a * dtp[i]; tm[i] += a * dtm[i]; s[i] += a * ds[i];
+        if (rt[i] == ROW_INEQ) s[i] = nudge_inside(s[i], lo[i], hi[i]);
+        vl[i] += a_d * dvl[i]; vu[i] += a_d * dvu[i];
+        if (rt[i] == ROW_INEQ) y[i] = vl[i] - vu[i]; else y[i] += a_d * dy[i];
+        zpv[i] -= a_d * dy[i]; zmv[i] += a_d * dy[i];
+    }
+    if (threadIdx.x == 0) { st.iter++; d.phase[inst] = PH_PREP; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// outcome of a finished interior-point run: accept, phase 1, penalty escalation, or infeasible;
+// final results in the JuMP sign convention (collect_solution!, subproblem_JuMP.jl:514-563)
+__global__ __launch_bounds__(TPB) void k_qp_finish(DV d)
+{
+    const int inst = blockIdx.x;
+    if (d.phase[inst] != PH_DONE) return;
+    IpmState &st = d.ist[inst];
+    INST_PTRS
+    double el = 0.0;
+    for (int i = threadIdx.x; i < d.m; i += TPB)
+        if (rt[i] != ROW_FREE && hard[i]) el = fmax(el, fmax(tp[i], tm[i]));
+    el = block_reduce<OpMax>(el);
+    int status = -1;       // -1: another run requested
+    if (st.stage == 0) {
+        if (st.rc == 1) status = SQPHIP_MOI_ITERATION_LIMIT;
+        else if (st.rc == 2) status = SQPHIP_MOI_NUMERICAL_ERROR;
+        else if (el <= ELASTIC_TOL) status = SQPHIP_MOI_LOCALLY_SOLVED;
+        if (threadIdx.x == 0) st.elastic = el;
+    } else {
+        const bool infeasible = st.rc != 0 || el > ELASTIC_TOL;
+        if (infeasible || st.rho_big >= RHO_BIG_MAX) status = SQPHIP_MOI_LOCALLY_INFEASIBLE;
+    }
+    __syncthreads();
+    if (status < 0) {
+        if (threadIdx.x == 0) {
+            if (st.stage == 0) st.stage = 1;
+            else { st.stage = 0; st.rho_big *= 100.0; }
+            st.start = 1;
+            d.phase[inst] = PH_IDLE;
+        }
+        return;
+    }
+    double *op = d.op + on, *olam = d.olam + om, *oU = d.omxU + on, *oL = d.omxL + on;
+    double *osl = d.oslack + 2 * om;
+    if (status == SQPHIP_MOI_LOCALLY_SOLVED) {
+        const double sf = st.sf;
+        for (int j = threadIdx.x; j < d.n; j += TPB) {
+            op[j] = p[j];
+            const double rc = ((fin(lb[j]) ? zl[j] : 0.0) - (fin(ub[j]) ? zu[j] : 0.0)) / sf;
+            oL[j] = rc > 0 ? rc : 0.0;
+            oU[j] = rc < 0 ? rc : 0.0;
+        }
+        for (int i = threadIdx.x; i < d.m; i += TPB) {
+            olam[i] = rt[i] == ROW_FREE ? 0.0 : y[i] / sf;
+            osl[i] = tp[i]; osl[d.m + i] = tm[i];
+        }
+    } else {
+        for (int j = threadIdx.x; j < d.n; j += TPB) { op[j] = 0.0; oL[j] = 0.0; oU[j] = 0.0; }
+        for (int i = threadIdx.x; i < d.m; i += TPB) { olam[i] = 0.0; osl[i] = 0.0; osl[d.m + i] = 0.0; }
+    }
+    if (threadIdx.x == 0) { st.status = status; d.phase[inst] = PH_IDLE; }
+}
+
+__global__ void k_count(DV d)
+{
+    // counters[0] = instances still iterating, [1] = instances requesting a (re)start
+    int run = 0, start = 0;
+    for (int i = threadIdx.x; i < d.B; i += blockDim.x) {
+        const int ph = d.phase[i];
+        if (ph != PH_DONE && ph != PH_IDLE) ++run;
+        if (d.ist[i].start) ++start;
+    }
+    __shared__ int sr[64], ss[64];
+    sr[threadIdx.x] = run; ss[threadIdx.x] = start;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int a = 0, b = 0;
+        for (int k = 0; k < (int)blockDim.x; ++k) { a += sr[k]; b += ss[k]; }
+        d.counters[0] = a; d.counters[1] = b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+void launch_qp_gather(Ctx &C)
+{
+    hipLaunchKernelGGL(k_qp_gather, dim3(C.d.B), dim3(TPB), 0, C.stream, C.d);
+}
+
+static void read_counters(Ctx &C)
+{
+    hipLaunchKernelGGL(k_count, dim3(1), dim3(64), 0, C.stream, C.d);
+    SQPHIP_HIP_OK(hipMemcpyAsync(C.h_counters, C.d.counters, 2 * sizeof(int), hipMemcpyDeviceToHost, C.stream));
+    SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+}
+
+// Runs every instance whose IpmState.start flag is set until each has a final MOI status.
+void ipm_run_all(Ctx &C)
+{
+    DV &d = C.d;
+    hipStream_t s = C.stream;
+    const dim3 gB(d.B), bT(TPB);
+    for (int guard = 0; guard < 64; ++guard) {          // (re)starts: main run, phase 1, escalation
+        read_counters(C);
+        if (C.h_counters[1] == 0) break;
+        hipLaunchKernelGGL(k_ipm_start, gB, bT, 0, s, d);
+        for (long sweep = 0; sweep < 100000; ++sweep) {
+            hipLaunchKernelGGL(k_ipm_prepare, gB, bT, 0, s, d);
+            hipLaunchKernelGGL(k_kkt_assemble, dim3(d.Npad, d.B), dim3(128), 0, s, d);
+            std::pair<hipEvent_t, hipEvent_t> ev;
+            if (C.tm.enabled) { ev = C.tm.get(); hipEventRecord(ev.first, s); }
+            ldlt_factor(C.plan, d.K, d.dinv, d.phase, PH_FACTOR, &C.tm);
+            if (C.tm.enabled) { hipEventRecord(ev.second, s); C.tm.pending_factor.push_back(ev); }
+            hipLaunchKernelGGL(k_inertia_rhs, gB, bT, 0, s, d);
+            if (C.tm.enabled) { ev = C.tm.get(); hipEventRecord(ev.first, s); }
+            for (int r = 0; r < 3; ++r) {
+                ldlt_solve(C.plan, d.K, d.dinv, d.xv, d.vv, d.phase, PH_SOLVE);
+                hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, r == 2 ? 1 : 0);
+            }
+            if (C.tm.enabled) { hipEventRecord(ev.second, s); C.tm.pending_solve.push_back(ev); }
+            hipLaunchKernelGGL(k_ipm_step, gB, bT, 0, s, d);
+            read_counters(C);
+            if (C.tm.pending_trailing.size() > 4096) C.tm.flush();
+            if (C.h_counters[0] == 0) break;
+        }
+        hipLaunchKernelGGL(k_qp_finish, gB, bT, 0, s, d);
+    }
+}
+
+}  // namespace sqphip

@@ -1,0 +1,548 @@
+// sqp.hip -- device-resident SQP-TR outer loop for a batch of instances, and the merit kernels.
+//
+// Restates, per instance and entirely in HBM, what `run!(sqp::AbstractSqpTrOptimizer)` does
+// (/root/reference/src/algorithms/sqp_trust_region.jl:98-223) with the state of
+// sqp_trust_region.jl:26-91, plus
+//   violation_of_linear_constraints :237-254,  sub_optimize_lp! :264-304 (dropzeros! utils.jl:16-22),
+//   compute_step! :370-380,  sub_optimize_soc! :341-360,  compute_qmodel :487-508,  do_step! :515-579,
+//   eval_functions! sqp.jl:86-104,  compute_phi sqp.jl:170-183,  terminate_by_iterlimit sqp.jl:215-224,
+//   norm_violations / KT_residuals common.jl:54-77 / :14-23.
+// The quirks of the reference are reproduced; `literal_quirks = 0` switches
+// #2/#3 to the textbook signs.  The callbacks are the device ACOPF evaluator (acopf_dev.hpp).
+// One 256-thread workgroup per instance; the host only sequences the kernels and the sub-solves.
+#include "ctx.hpp"
+#include "dev_util.hpp"
+#include "acopf_dev.hpp"
+#include <cmath>
+
+namespace sqphip {
+
+enum { SQ_RUN = 0, SQ_SKIP = 1, SQ_SOC = 2 };
+
+#define SQP_PTRS                                                                                     \
+    const long on = (long)inst * d.n, om = (long)inst * d.m;                                        \
+    SqpState &S = d.sst[inst];                                                                       \
+    IpmState &I = d.ist[inst];                                                                       \
+    double *x = d.x + on, *lam = d.lambda + om, *mxL = d.mxL + on, *mxU = d.mxU + on;                \
+    double *df = d.df + on, *E = d.E + om, *ps = d.pstep + on, *psoc = d.psoc + on;                  \
+    double *plam = d.plam + om, *pmxL = d.pmxL + on, *pmxU = d.pmxU + on, *Esoc = d.Esoc + om;       \
+    double *tmpx = d.tmpx + on, *tmpE = d.tmpE + om, *hlam = d.hlam + om;                            \
+    const double *xL = d.xL + on, *xU = d.xU + on, *gL = d.gL + om, *gU = d.gU + om;                 \
+    double *jcoo = d.jcoo + (long)inst * d.nnzj_coo, *hcoo = d.hcoo + (long)inst * d.nnzh_coo;       \
+    double *jv = d.jv + (long)inst * d.nnzjc, *hv = d.hv + (long)inst * d.nnzhc;                     \
+    (void)x; (void)lam; (void)mxL; (void)mxU; (void)df; (void)E; (void)ps; (void)psoc; (void)plam;   \
+    (void)pmxL; (void)pmxU; (void)Esoc; (void)tmpx; (void)tmpE; (void)hlam; (void)xL; (void)xU;      \
+    (void)gL; (void)gU; (void)jcoo; (void)hcoo; (void)jv; (void)hv; (void)I; (void)S;
+
+// Julia isapprox(a,b): rtol = sqrt(eps), atol = 0 (sqp_trust_region.jl:146,:200,:535)
+static __device__ __forceinline__ bool isapprox_d(double a, double b)
+{
+    if (a == b) return true;
+    if (!fin(a) || !fin(b)) return false;
+    return fabs(a - b) <= 1.4901161193847656e-08 * fmax(fabs(a), fabs(b));
+}
+
+// common.jl:54-77 with p = 1
+static __device__ double viol1(const DV &d, const double *E, const double *gL, const double *gU,
+                               const double *x, const double *xL, const double *xU)
+{
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < d.m; i += TPB) {
+        if (E[i] > gU[i]) acc += E[i] - gU[i];
+        else if (E[i] < gL[i]) acc += gL[i] - E[i];
+    }
+    for (int j = threadIdx.x; j < d.n; j += TPB) {
+        if (x[j] > xU[j]) acc += x[j] - xU[j];
+        else if (x[j] < xL[j]) acc += xL[j] - x[j];
+    }
+    return block_reduce<OpSum>(acc);
+}
+
+static __device__ double norm_inf(const double *v, int k)
+{
+    double a = 0.0;
+    for (int i = threadIdx.x; i < k; i += TPB) a = fmax(a, fabs(v[i]));
+    return block_reduce<OpMax>(a);
+}
+
+static __device__ void gather_csc(const DV &d, const double *jcoo, const double *hcoo, double *jv, double *hv)
+{
+    for (int s = threadIdx.x; s < d.nnzjc; s += TPB) {
+        double a = 0.0;
+        for (int k = d.jg_ptr[s]; k < d.jg_ptr[s + 1]; ++k) a += jcoo[d.jg_src[k]];
+        jv[s] = a;
+    }
+    if (hv)
+        for (int s = threadIdx.x; s < d.nnzhc; s += TPB) {
+            double a = 0.0;
+            for (int k = d.hg_ptr[s]; k < d.hg_ptr[s + 1]; ++k) a += hcoo[d.hg_src[k]];
+            hv[s] = a;
+        }
+}
+
+// common.jl:14-23 on the CSC Jacobian; sgn = +1 literal, -1 textbook (lambda and mult_x_U negated)
+static __device__ double kt_residuals(const DV &d, const double *df, const double *lam, const double *mxU,
+                                      const double *mxL, const double *jv, double sgn, double *rowsq)
+{
+    for (int i = threadIdx.x; i < d.m; i += TPB) {
+        double a = 0.0;
+        for (int k = d.jrowptr[i]; k < d.jrowptr[i + 1]; ++k) { const double v = jv[d.jrslot[k]]; a += v * v; }
+        rowsq[i] = a;
+    }
+    double res = 0.0, sc = 1.0;
+    for (int j = threadIdx.x; j < d.n; j += TPB) {
+        double jtl = 0.0;
+        for (int k = d.jcolptr[j]; k < d.jcolptr[j + 1]; ++k) jtl += jv[k] * lam[d.jrowval[k]];
+        res = fmax(res, fabs(df[j] + sgn * jtl + sgn * mxU[j] - mxL[j]));
+        sc = fmax(sc, fmax(fabs(df[j]), fmax(fabs(mxU[j]), fabs(mxL[j]))));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < d.m; i += TPB) sc = fmax(sc, fabs(lam[i]) * sqrt(rowsq[i]));
+    res = block_reduce<OpMax>(res);
+    sc = block_reduce<OpMax>(sc);
+    return res / sc;
+}
+
+static __device__ void push_trace(const DV &d, int inst, SqpState &S, double pn)
+{
+    if (threadIdx.x == 0) {
+        if (S.trace_len < SQPHIP_TRACE_CAP) {
+            double *r = d.trace + ((long)inst * SQPHIP_TRACE_CAP + S.trace_len) * SQPHIP_TRACE_COLS;
+            r[0] = S.iter; r[1] = S.step_acceptance; r[2] = S.fr; r[3] = S.sub_status; r[4] = S.it_ipm;
+            r[5] = S.f; r[6] = S.phi; r[7] = S.mu; r[8] = S.Delta; r[9] = pn; r[10] = S.prim_infeas;
+            r[11] = S.dual_infeas;
+        }
+        S.trace_len++;
+    }
+}
+
+static __device__ void qp_request(IpmState &I, int mode, double delta, double mu_pen)
+{
+    I.mode = mode; I.delta = delta; I.mu_pen = mu_pen;
+    I.stage = 0; I.rho_big = 1e4; I.start = 1; I.ipm_iters = 0; I.n_factor = 0; I.status = 0;
+}
+
+// sqp_trust_region.jl:215-222
+static __device__ void finalize(const DV &d, int inst, SqpState &S, const double *x)
+{
+    double f;
+    __shared__ double fsh;
+    acopf_eval(d, inst, x, 1.0, nullptr, &fsh, nullptr, nullptr, nullptr, nullptr);
+    __syncthreads();
+    f = fsh;
+    if (threadIdx.x == 0) { S.obj_val = f; S.done = 1; S.stage = SQ_SKIP; }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_sqp_reset(DV d)
+{
+    const int inst = blockIdx.x;
+    SQP_PTRS
+    const double *x0 = d.x0 + on;
+    for (int j = threadIdx.x; j < d.n; j += TPB) { x[j] = x0[j]; mxL[j] = 0; mxU[j] = 0; ps[j] = 0; psoc[j] = 0; }
+    for (int i = threadIdx.x; i < d.m; i += TPB) { lam[i] = 0; E[i] = 0; }
+    if (threadIdx.x == 0) {
+        SqpState z = {};
+        z.phi = 1e20; z.mu = d.init_mu; z.Delta = d.tr_size;
+        z.prim_infeas = INFINITY; z.dual_infeas = INFINITY;
+        z.step_acceptance = 1; z.fr = 0; z.iter = 1; z.ret = -5;
+        S = z;
+        I.start = 0;
+        d.phase[inst] = PH_IDLE;
+    }
+}
+
+// run! prologue: sqp_trust_region.jl:100-122
+__global__ __launch_bounds__(TPB) void k_sqp_begin(DV d)
+{
+    const int inst = blockIdx.x;
+    SQP_PTRS
+    if (S.started || S.done) return;
+    __shared__ double fsh;
+    acopf_eval(d, inst, x, 1.0, nullptr, &fsh, nullptr, E, nullptr, nullptr);
+    __syncthreads();
+    const double f = fsh;
+    double lpv = 0.0;                                     // :244-253
+    for (int i = threadIdx.x; i < d.nlin; i += TPB) { lpv += fmax(0.0, gL[i] - E[i]); lpv -= fmin(0.0, gU[i] - E[i]); }
+    for (int j = threadIdx.x; j < d.n; j += TPB) { lpv += fmax(0.0, xL[j] - x[j]); lpv -= fmin(0.0, xU[j] - x[j]); }
+    lpv = block_reduce<OpSum>(lpv);
+    if (threadIdx.x == 0) { S.f = f; S.started = 1; S.it_ipm = 0; }
+    if (isnan(f)) {                                       // :113-115
+        if (threadIdx.x == 0) { S.ret = -13; S.done = 1; S.stage = SQ_SKIP; }
+        return;
+    }
+    if (lpv > d.tol_infeas) {                             // :116-119 -> sub_optimize_lp! :264-304
+        acopf_eval(d, inst, x, 1.0, nullptr, nullptr, df, nullptr, jcoo, nullptr);
+        double *xk = d.xk + on;
+        for (int j = threadIdx.x; j < d.n; j += TPB) xk[j] = x[j];
+        if (threadIdx.x == 0) { qp_request(I, SQPHIP_MODE_LP, S.Delta, S.mu); S.lp_pending = 1; }
+    }
+}
+
+__global__ __launch_bounds__(TPB) void k_sqp_lp_finish(DV d)
+{
+    const int inst = blockIdx.x;
+    SQP_PTRS
+    if (!S.lp_pending) return;
+    const double *op = d.op + on, *ol = d.olam + om, *oU = d.omxU + on, *oL = d.omxL + on;
+    auto dz = [](double v) { return fabs(v) < 1e-10 ? 0.0 : v; };   // utils.jl:16-22
+    for (int j = threadIdx.x; j < d.n; j += TPB) { x[j] = dz(op[j]); mxU[j] = dz(oU[j]); mxL[j] = dz(oL[j]); }
+    for (int i = threadIdx.x; i < d.m; i += TPB) lam[i] = dz(ol[i]);
+    if (threadIdx.x == 0) {
+        S.sub_status = I.status; S.lp_pending = 0; S.n_qp++; S.it_ipm = I.ipm_iters;
+        S.tot_ipm += I.ipm_iters; S.tot_fac += I.n_factor;
+    }
+    __syncthreads();
+    push_trace(d, inst, S, norm_inf(ps, d.n));            // print(sqp, "LP")
+}
+
+// top of the loop: iteration limit, eval_functions!, infeasibility measures, QP request
+// (sqp_trust_region.jl:126-141)
+__global__ __launch_bounds__(TPB) void k_sqp_top(DV d)
+{
+    const int inst = blockIdx.x;
+    SQP_PTRS
+    if (S.done) return;
+    if (threadIdx.x == 0) { S.stage = SQ_RUN; S.it_ipm = 0; }
+    __syncthreads();
+    if (S.iter > d.max_iter) {                            // sqp.jl:215-224
+        if (threadIdx.x == 0) S.ret = S.prim_infeas <= d.tol_infeas ? 6 : -1;
+        __syncthreads();
+        finalize(d, inst, S, x);
+        return;
+    }
+    if (S.step_acceptance) {                              // :134-138, sqp.jl:86-104
+        const double hs = d.literal_quirks ? 1.0 : -1.0;
+        for (int i = threadIdx.x; i < d.m; i += TPB) hlam[i] = hs * lam[i];
+        __syncthreads();
+        __shared__ double fsh;
+        acopf_eval(d, inst, x, 1.0, hlam, &fsh, df, E, jcoo, d.nnzh_coo ? hcoo : nullptr);
+        __syncthreads();
+        gather_csc(d, jcoo, hcoo, jv, d.nnzh_coo ? hv : nullptr);
+        __syncthreads();
+        const double pr = viol1(d, E, gL, gU, x, xL, xU);
+        const double du = kt_residuals(d, df, lam, mxU, mxL, jv, hs, tmpE);
+        if (threadIdx.x == 0) { S.f = fsh; S.prim_infeas = pr; S.dual_infeas = du; }
+    }
+    // QP request: QpData(sqp) sqp.jl:66-79, dispatch :314-331
+    double *xk = d.xk + on, *cin = d.cin + on, *bE = d.bE + om;
+    for (int j = threadIdx.x; j < d.n; j += TPB) { xk[j] = x[j]; cin[j] = df[j]; }
+    for (int i = threadIdx.x; i < d.m; i += TPB) bE[i] = E[i];
+    if (threadIdx.x == 0) qp_request(I, S.fr ? SQPHIP_MODE_FR : SQPHIP_MODE_QP, S.Delta, S.mu);
+}
+
+// q(p) of sqp_trust_region.jl:487-508 (with_step = true); tmpx/tmpE are scratch
+static __device__ double qmodel_step(const DV &d, int inst, const SqpState &S, const double *p,
+                                     const double *x, const double *df, const double *E, const double *jv,
+                                     const double *hv, const double *gL, const double *gU, const double *xL,
+                                     const double *xU, double *tmpx, double *tmpE)
+{
+    double acc = 0.0;
+    for (int j = threadIdx.x; j < d.n; j += TPB) {
+        double hp = 0.0;
+        for (int k = d.hcolptr[j]; k < d.hcolptr[j + 1]; ++k) hp += hv[k] * p[d.hrowval[k]];
+        acc += df[j] * p[j] + 0.5 * p[j] * hp;
+        tmpx[j] = x[j] + p[j];
+    }
+    for (int i = threadIdx.x; i < d.m; i += TPB) {
+        double jp = 0.0;
+        for (int k = d.jrowptr[i]; k < d.jrowptr[i + 1]; ++k) jp += jv[d.jrslot[k]] * p[d.jrcol[k]];
+        tmpE[i] = E[i] + jp;
+    }
+    acc = block_reduce<OpSum>(acc);
+    __syncthreads();
+    return acc + S.mu * viol1(d, tmpE, gL, gU, tmpx, xL, xU);
+}
+
+static __device__ void accept_step(const DV &d, double *x, double *lam, double *mxL, double *mxU,
+                                   const double *step, const double *plam, const double *pmxL,
+                                   const double *pmxU)
+{
+    for (int j = threadIdx.x; j < d.n; j += TPB) { x[j] += step[j]; mxL[j] += pmxL[j]; mxU[j] += pmxU[j]; }
+    for (int i = threadIdx.x; i < d.m; i += TPB) lam[i] += plam[i];
+}
+
+// after the QP: compute_step!, status branches, phi, termination tests, do_step!
+// (sqp_trust_region.jl:141-213, :370-380, :515-579)
+__global__ __launch_bounds__(TPB) void k_sqp_mid(DV d)
+{
+    const int inst = blockIdx.x;
+    SQP_PTRS
+    if (S.done || S.stage != SQ_RUN) return;
+    const double *op = d.op + on, *ol = d.olam + om, *oU = d.omxU + on, *oL = d.omxL + on;
+    // compute_step! :373-378
+    for (int j = threadIdx.x; j < d.n; j += TPB) { ps[j] = op[j]; pmxL[j] = oL[j] - mxL[j]; pmxU[j] = oU[j] - mxU[j]; }
+    for (int i = threadIdx.x; i < d.m; i += TPB) plam[i] = ol[i] - lam[i];
+    __syncthreads();
+    const double nl_ = norm_inf(lam, d.m), nL = norm_inf(mxL, d.n), nU = norm_inf(mxU, d.n);
+    const double pn = norm_inf(ps, d.n);
+    const int st = I.status;
+    if (threadIdx.x == 0) {
+        S.mu = fmax(fmax(S.mu, nl_), fmax(nL, nU));
+        S.sub_status = st; S.n_qp++; S.it_ipm += I.ipm_iters;
+        S.tot_ipm += I.ipm_iters; S.tot_fac += I.n_factor;
+    }
+    __syncthreads();
+    if (st == SQPHIP_MOI_LOCALLY_SOLVED) {
+        if (S.Delta == 1e8 && isapprox_d(pn, S.Delta)) {            // :146-150
+            if (threadIdx.x == 0) S.ret = 4;
+            __syncthreads();
+            finalize(d, inst, S, x);
+            return;
+        }
+    } else if (st == SQPHIP_MOI_LOCALLY_INFEASIBLE) {
+        if (S.fr) {                                                    // :152-159
+            if (threadIdx.x == 0) S.ret = S.prim_infeas <= d.tol_infeas ? 6 : 2;
+            __syncthreads();
+            finalize(d, inst, S, x);
+        } else {                                                       // :160-168
+            if (threadIdx.x == 0) S.fr = 1;
+            __syncthreads();
+            push_trace(d, inst, S, pn);
+            if (threadIdx.x == 0) { S.iter += 1; S.stage = SQ_SKIP; }
+        }
+        return;
+    } else {                                                           // :169-178 (quirk #1)
+        if (threadIdx.x == 0 && S.prim_infeas <= d.tol_infeas * 10.0) S.ret = 6;
+        __syncthreads();
+        finalize(d, inst, S, x);
+        return;
+    }
+    if (S.step_acceptance) {                                           // :180-182, sqp.jl:170-183 alpha = 0
+        const double v = viol1(d, E, gL, gU, x, xL, xU);
+        if (threadIdx.x == 0) S.phi = S.fr ? v : S.f + S.mu * v;
+    }
+    __syncthreads();
+    push_trace(d, inst, S, pn);                                        // :184
+    if (pn <= d.tol_direction) {                                       // :187-196
+        if (S.fr) {
+            if (threadIdx.x == 0) { S.fr = 0; S.iter += 1; S.stage = SQ_SKIP; }
+        } else {
+            if (threadIdx.x == 0) S.ret = 0;
+            __syncthreads();
+            finalize(d, inst, S, x);
+        }
+        return;
+    }
+    if (S.prim_infeas <= d.tol_infeas && S.dual_infeas <= d.tol_residual && !isapprox_d(S.Delta, pn) &&
+        !S.fr) {                                                       // :198-204
+        if (threadIdx.x == 0) S.ret = 0;
+        __syncthreads();
+        finalize(d, inst, S, x);
+        return;
+    }
+    // do_step! :515-579
+    for (int j = threadIdx.x; j < d.n; j += TPB) tmpx[j] = x[j] + ps[j];
+    __syncthreads();
+    __shared__ double fsh;
+    acopf_eval(d, inst, tmpx, 1.0, nullptr, &fsh, nullptr, tmpE, nullptr, nullptr);
+    __syncthreads();
+    const double c_k = viol1(d, tmpE, gL, gU, tmpx, xL, xU);
+    const double phi_k = S.fr ? c_k : fsh + S.mu * c_k;
+    double ared = S.phi - phi_k, pred = 1.0, q0 = 0.0;
+    if (!S.fr) {
+        q0 = S.mu * viol1(d, E, gL, gU, x, xL, xU);                    // compute_qmodel(sqp, false)
+        const double qk = qmodel_step(d, inst, S, ps, x, df, E, jv, hv, gL, gU, xL, xU, tmpx, tmpE);
+        pred = q0 - qk;
+    }
+    const double rho = ared / pred;
+    if (ared > 0 && rho > 0) {                                         // :530-538
+        accept_step(d, x, lam, mxL, mxU, ps, plam, pmxL, pmxU);
+        if (threadIdx.x == 0) {
+            if (isapprox_d(S.Delta, pn)) S.Delta = fmin(2 * S.Delta, 1e8);
+            S.step_acceptance = 1;
+        }
+    } else {
+        if (d.use_soc && c_k > 0 && !S.fr) {                           // :544-549 -> sub_optimize_soc! :341-360
+            for (int j = threadIdx.x; j < d.n; j += TPB) tmpx[j] = x[j] + ps[j];
+            __syncthreads();
+            acopf_eval(d, inst, tmpx, 1.0, nullptr, nullptr, nullptr, Esoc, nullptr, nullptr);
+            __syncthreads();
+            double *bE = d.bE + om;
+            for (int i = threadIdx.x; i < d.m; i += TPB) {
+                double jp = 0.0;
+                for (int k = d.jrowptr[i]; k < d.jrowptr[i + 1]; ++k) jp += jv[d.jrslot[k]] * ps[d.jrcol[k]];
+                Esoc[i] -= jp;
+                bE[i] = Esoc[i];
+            }
+            if (threadIdx.x == 0) {
+                qp_request(I, SQPHIP_MODE_SOC, S.Delta, S.mu);
+                S.soc_pending = 1; S.q0 = q0; S.pnorm = pn; S.stage = SQ_SOC;
+            }
+            return;
+        }
+        if (threadIdx.x == 0) {                                        // :574-577
+            S.Delta = fmax(0.5 * fmin(S.Delta, pn), 0.1 * d.tol_direction);
+            S.step_acceptance = 0;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (S.fr && S.step_acceptance) S.fr = 0;                       // :209-211
+        S.iter += 1;                                                   // :213
+    }
+}
+
+// second half of do_step! for instances that requested a second-order correction (:551-572)
+__global__ __launch_bounds__(TPB) void k_sqp_soc_finish(DV d)
+{
+    const int inst = blockIdx.x;
+    SQP_PTRS
+    if (S.done || !S.soc_pending) return;
+    const double *op = d.op + on;
+    for (int j = threadIdx.x; j < d.n; j += TPB) { psoc[j] = ps[j] + op[j]; tmpx[j] = x[j] + ps[j] + op[j]; }
+    __syncthreads();
+    __shared__ double fsh;
+    acopf_eval(d, inst, tmpx, 1.0, nullptr, &fsh, nullptr, tmpE, nullptr, nullptr);
+    __syncthreads();
+    const double c_s = viol1(d, tmpE, gL, gU, tmpx, xL, xU);
+    const double phi_soc = S.fr ? c_s : fsh + S.mu * c_s;
+    const double ared = S.phi - phi_soc;
+    const double qs = qmodel_step(d, inst, S, psoc, x, df, E, jv, hv, gL, gU, xL, xU, tmpx, tmpE);
+    const double pred = S.q0 - qs;
+    const double rho = ared / pred;
+    if (threadIdx.x == 0) { S.n_qp++; S.it_ipm += I.ipm_iters; S.tot_ipm += I.ipm_iters; S.tot_fac += I.n_factor; }
+    if (ared > 0 && rho > 0) {
+        accept_step(d, x, lam, mxL, mxU, psoc, plam, pmxL, pmxU);
+        if (threadIdx.x == 0) S.step_acceptance = 1;
+    } else if (threadIdx.x == 0) {
+        S.Delta = fmax(0.5 * fmin(S.Delta, S.pnorm), 0.1 * d.tol_direction);
+        S.step_acceptance = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (S.fr && S.step_acceptance) S.fr = 0;
+        S.iter += 1;
+        S.soc_pending = 0; S.stage = SQ_RUN;
+    }
+}
+
+__global__ void k_sqp_count(DV d)
+{
+    int nd = 0, ns = 0;
+    for (int i = threadIdx.x; i < d.B; i += blockDim.x) { if (!d.sst[i].done) ++nd; if (d.ist[i].start) ++ns; }
+    __shared__ int a[64], b[64];
+    a[threadIdx.x] = nd; b[threadIdx.x] = ns;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int s0 = 0, s1 = 0;
+        for (int k = 0; k < (int)blockDim.x; ++k) { s0 += a[k]; s1 += b[k]; }
+        d.counters[2] = s0; d.counters[3] = s1;
+    }
+}
+
+static void read_sqp_counters(Ctx &C)
+{
+    hipLaunchKernelGGL(k_sqp_count, dim3(1), dim3(64), 0, C.stream, C.d);
+    SQPHIP_HIP_OK(hipMemcpyAsync(C.h_counters + 2, C.d.counters + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, C.stream));
+    SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+}
+
+void sqp_reset(Ctx &C)
+{
+    hipLaunchKernelGGL(k_sqp_reset, dim3(C.d.B), dim3(TPB), 0, C.stream, C.d);
+    SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+}
+
+void sqp_run(Ctx &C, int max_outer)
+{
+    DV &d = C.d;
+    hipStream_t s = C.stream;
+    const dim3 gB(d.B), bT(TPB);
+    hipLaunchKernelGGL(k_sqp_begin, gB, bT, 0, s, d);
+    read_sqp_counters(C);
+    if (C.h_counters[3] > 0) {
+        launch_qp_gather(C);
+        ipm_run_all(C);
+        hipLaunchKernelGGL(k_sqp_lp_finish, gB, bT, 0, s, d);
+    }
+    for (int outer = 0; max_outer <= 0 || outer < max_outer; ++outer) {
+        read_sqp_counters(C);
+        if (C.h_counters[2] == 0) break;
+        hipLaunchKernelGGL(k_sqp_top, gB, bT, 0, s, d);
+        launch_qp_gather(C);
+        ipm_run_all(C);
+        hipLaunchKernelGGL(k_sqp_mid, gB, bT, 0, s, d);
+        if (d.use_soc) {
+            read_sqp_counters(C);
+            if (C.h_counters[3] > 0) {
+                ipm_run_all(C);
+                hipLaunchKernelGGL(k_sqp_soc_finish, gB, bT, 0, s, d);
+            }
+        }
+    }
+    SQPHIP_HIP_OK(hipStreamSynchronize(s));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Merit / acceptance reductions for the drop-in path: operands are staged in instance 0's vectors
+// (x, E, df, lambda, mult_x_U, mult_x_L, pstep, jcoo, hcoo) by the host wrapper.
+//   op 0 norm_violations (common.jl:54-77)      op 1 KT_residuals (common.jl:14-23)
+//   op 2 norm_complementarity (common.jl:30-47) op 3 compute_phi (sqp.jl:170-183)
+//   op 4 compute_qmodel (sqp_trust_region.jl:487-508)  op 5 compute_derivative (merit.jl:15, sqp.jl:203-212)
+__global__ __launch_bounds__(TPB) void k_merit(DV d, int op, double a0, double a1, int flag, double *out)
+{
+    const int inst = 0;
+    SQP_PTRS
+    double r = 0.0;
+    if (op == 0 || op == 2) {
+        double acc = 0.0, den = 0.0;
+        if (op == 0) {
+            for (int i = threadIdx.x; i < d.m; i += TPB) {
+                double v = 0.0;
+                if (E[i] > gU[i]) v = E[i] - gU[i]; else if (E[i] < gL[i]) v = gL[i] - E[i];
+                acc = flag == 1 ? acc + v : (flag == 2 ? acc + v * v : fmax(acc, v));
+            }
+            for (int j = threadIdx.x; j < d.n; j += TPB) {
+                double v = 0.0;
+                if (x[j] > xU[j]) v = x[j] - xU[j]; else if (x[j] < xL[j]) v = xL[j] - x[j];
+                acc = flag == 1 ? acc + v : (flag == 2 ? acc + v * v : fmax(acc, v));
+            }
+        } else {
+            for (int i = threadIdx.x; i < d.m; i += TPB) {
+                double c = 0.0;
+                if (gL[i] != gU[i]) { c = fmin(E[i] - gL[i], gU[i] - E[i]) * lam[i]; den += lam[i] * lam[i]; }
+                c = fabs(c);
+                acc = flag == 1 ? acc + c : (flag == 2 ? acc + c * c : fmax(acc, c));
+            }
+        }
+        acc = flag == 0 ? block_reduce<OpMax>(acc) : block_reduce<OpSum>(acc);
+        if (flag == 2) acc = sqrt(acc);
+        if (op == 2) { den = block_reduce<OpSum>(den); acc = acc / (1.0 + sqrt(den)); }
+        r = acc;
+    } else if (op == 1) {
+        gather_csc(d, jcoo, hcoo, jv, nullptr);
+        __syncthreads();
+        r = kt_residuals(d, df, lam, mxU, mxL, jv, 1.0, tmpE);
+    } else if (op == 3) {
+        const double v = viol1(d, E, gL, gU, x, xL, xU);
+        r = flag ? v : a0 + a1 * v;          // a0 = f(x + alpha p), a1 = mu, flag = feasibility restoration
+    } else if (op == 4) {
+        SqpState tmp = S;
+        tmp.mu = a1;
+        if (flag) {
+            gather_csc(d, jcoo, hcoo, jv, d.nnzh_coo ? hv : nullptr);
+            __syncthreads();
+            r = qmodel_step(d, inst, tmp, ps, x, df, E, jv, hv, gL, gU, xL, xU, tmpx, tmpE);
+        } else {
+            r = a1 * viol1(d, E, gL, gU, x, xL, xU);
+        }
+    } else if (op == 5) {
+        double dfp = 0.0, cv = 0.0;
+        for (int j = threadIdx.x; j < d.n; j += TPB) dfp += df[j] * ps[j];
+        for (int i = threadIdx.x; i < d.m; i += TPB) cv += fmax(0.0, fmax(E[i] - gU[i], gL[i] - E[i]));
+        dfp = block_reduce<OpSum>(dfp); cv = block_reduce<OpSum>(cv);
+        r = dfp - a1 * cv;
+    }
+    if (threadIdx.x == 0) *out = r;
+}
+
+void merit_eval(Ctx &C, int op, double a0, double a1, int flag, double *out_host)
+{
+    double *o = C.d.wN;     // scratch scalar slot
+    hipLaunchKernelGGL(k_merit, dim3(1), dim3(TPB), 0, C.stream, C.d, op, a0, a1, flag, o);
+    SQPHIP_HIP_OK(hipMemcpyAsync(out_host, o, sizeof(double), hipMemcpyDeviceToHost, C.stream));
+    SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+}
+
+}  // namespace sqphip
