@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark: QP sub-problems per second of the batched SQP-TR hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one SQP-TR outer iteration of every instance of the rank's batch: device ACOPF
+evaluation, the trust-region QP (or feasibility-restoration / second-order-correction) sub-problem
+solved by the on-device interior-point method, merit + ratio test.  Workload at N = 1: the per-GPU
+shard of BASELINE.json configs[3] -- 64 IEEE-118-shaped ACOPF contingency scenarios (512 over 8 GPUs,
+weak scaling: 64 per rank), dense KKT N = 2813, fp64, synthetic data of that shape, SQP options of
+/root/reference/examples/acopf/opf.jl:76-79.  Inputs are resident in HBM before the timed region.
+Ranks never exchange iterates; each step ends with one all-gather of (ret, iter, done) per instance
+over RCCL.  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+_ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, _ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet fp64 matrix peak; MI355X_MICROARCH.md has no fp64 row.
+                               # bench prints the on-box register-resident MFMA probe next to it.
+
+
+def trailing_alg_flops(N: int) -> float:
+    """Algorithmic flops of the trailing updates of one blocked LDL^T of order N (64-wide panels):
+    lower triangle incl. diagonal of every Schur update, 2 flops per multiply-add."""
+    T = (N + 63) // 64
+    tot = 0.0
+    for k in range(T - 1):
+        r = (T - k - 1) * 64
+        tot += r * (r + 1) * 64.0
+    return tot
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="case118", choices=["case14", "case118"])
+    ap.add_argument("--batch", type=int, default=64, help="instances per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--literal-quirks", type=int, default=1)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import sqpsolver_jl_amd as pkg
+    from sqpsolver_jl_amd.acopf_synth import acopf_synth, acopf_layout, contingency, CASES
+    from sqpsolver_jl_amd.shard import shard_range, gather_status
+    from sqpsolver_jl_amd import _lib
+
+    nb, ng, nl, seed = CASES[args.workload]
+    B = args.batch
+    total = B * world
+    lo, hi = shard_range(total, world, rank)
+    base = acopf_synth(nb, ng, nl, seed)
+    lay0 = acopf_layout(base)
+    # examples/acopf/opf.jl:72-80
+    opts = pkg.default_options(tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, max_iter=3000,
+                               literal_quirks=args.literal_quirks, device=local_rank)
+    ctx = pkg.Context(lay0.n, lay0.m, lay0.num_linear, lay0.jrow, lay0.jcol, lay0.hrow, lay0.hcol,
+                      lay0.xL, lay0.xU, lay0.gL, lay0.gU, opts, batch=hi - lo)
+    ctx.acopf_attach(base, lay0)
+    nets = []
+    for b, s in enumerate(range(lo, hi)):
+        net = base if s == 0 else contingency(base, s, seed)
+        lay = acopf_layout(net)
+        ctx.acopf_set_instance(b, net, lay)
+        nets.append((net, lay))
+    ctx.sqp_reset()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    dev = torch.device("cuda", local_rank)
+
+    def one_step():
+        ctx.sqp_run(1)
+        ret, it, done = ctx.sqp_status()
+        return gather_status(ret, it, done, total, device=dev)
+
+    for _ in range(args.warmup):
+        one_step()
+    c0 = ctx.counters()
+    ctx.set_timing(True)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        g_ret, g_it, g_done = one_step()
+    sync()
+    t1 = time.perf_counter()
+    ctx.set_timing(False)
+    c1 = ctx.counters()
+
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    stats = torch.tensor([c1["n_qp"] - c0["n_qp"], c1["n_ipm_iter"] - c0["n_ipm_iter"],
+                          c1["n_factor"] - c0["n_factor"]], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+    elapsed = float(elapsed.item())
+    n_qp, n_ipm, n_fac = (float(v) for v in stats.tolist())
+
+    # roofline of the dominant kernel (k_trailing, fp64 MFMA), rank-0 local measurement
+    N = lay0.n + lay0.m
+    loc_fac = c1["n_factor"] - c0["n_factor"]
+    tr_sec = c1["trailing_seconds"] - c0["trailing_seconds"]
+    tr_launch = c1["trailing_launches"] - c0["trailing_launches"]
+    achieved = loc_fac * trailing_alg_flops(N) / tr_sec / 1e12 if tr_sec > 0 else 0.0
+    probe = None
+    if rank == 0:
+        import ctypes as C
+        v = C.c_double()
+        if _lib.lib().sqphip_mfma_f64_peak(local_rank, C.byref(v)) == 0:
+            probe = v.value
+    traffic = None
+    tpath = os.path.join(_ROOT, "profiles", "trailing_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # CPU restatement (NOT Julia/Ipopt) on a bounded sample: instance 0, first 2 outer iterations
+        from oracle import oracle as O
+        try:
+            cores = max(1, min(16, len(os.sched_getaffinity(0))))   # the GPU box grants 16 host cores per GPU
+        except AttributeError:
+            cores = max(1, min(16, os.cpu_count() or 1))
+        oo = O.default_options(max_iter=2, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1,
+                               literal_quirks=args.literal_quirks, num_threads=cores)
+        ro = O.sqp_solve(O.problem_acopf(*nets[0]), oo)
+        cpu = {"value": ro["n_qp"] / ro["qp_seconds"] if ro["qp_seconds"] > 0 else 0.0,
+               "unit": "QP subproblems/s", "cores": cores, "kind": "port",
+               "sample": f"{args.workload} scenario 0, first 2 SQP-TR iterations = {ro['n_qp']} sub-problems, "
+                         f"{ro['n_factor']} dense LDL^T of order {N}, {ro['qp_seconds']:.1f} s; CPU restatement "
+                         f"(oracle/), not Julia/Ipopt"}
+
+    if rank == 0:
+        out = {
+            "metric": "QP subproblems/sec on batched ACOPF; fp64 KKT LDL^T TFLOPS vs MFMA peak",
+            "value": n_qp / elapsed if elapsed > 0 else 0.0,
+            "unit": "QP subproblems/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / max(1, args.steps),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{B} x IEEE-{nb}-bus-shaped ACOPF contingency scenarios per GPU "
+                                   f"(BASELINE.json configs[3] shard), dense KKT N={N}, SQP-TR outer iterations",
+                       "instances_total": total, "kkt_order": N, "use_soc": 1,
+                       "literal_quirks": args.literal_quirks,
+                       "qp_solved": n_qp, "ipm_iterations": n_ipm, "kkt_factorisations": n_fac,
+                       "ldlt_tflops_wall": n_fac * (N ** 3 / 3.0) / elapsed / 1e12 if elapsed > 0 else 0.0,
+                       "instances_done": int(np.sum(g_done))},
+            "roofline": {"bound": "mfma", "kernel": "k_trailing (v_mfma_f64_16x16x4_f64)",
+                         "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "launches": tr_launch, "avg_launch_ms": 1e3 * tr_sec / tr_launch if tr_launch else None,
+                         "onbox_mfma_probe_tflops": probe},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -175,6 +175,9 @@ int sqphip_ldlt_solve_host(int32_t device, int32_t batch, int64_t N, const doubl
 int sqphip_ldlt_bench(int32_t device, int32_t batch, int64_t N, int32_t reps,
                       double *sec_per_factor, double *sec_trailing, int64_t *trailing_launches);
 
+/* on-box fp64 MFMA issue-rate probe (register-resident v_mfma_f64_16x16x4_f64 loop), TFLOP/s */
+int sqphip_mfma_f64_peak(int32_t device, double *tflops);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,7 @@ def lib():
         L.sqphip_ldlt_factor_host.argtypes = [C.c_int32, C.c_int32, C.c_int64, dp, dp, ip]
         L.sqphip_ldlt_solve_host.argtypes = [C.c_int32, C.c_int32, C.c_int64, dp, dp]
         L.sqphip_ldlt_bench.argtypes = [C.c_int32, C.c_int32, C.c_int64, C.c_int32, dp, dp, lp]
+        L.sqphip_mfma_f64_peak.argtypes = [C.c_int32, dp]
         if hasattr(L, "sqphip_create"):
             L.sqphip_create.argtypes = [C.POINTER(vp), C.c_int64, C.c_int64, C.c_int64,
                                         C.c_int64, lp, lp, C.c_int64, lp, lp, dp, dp, dp, dp,
@@ -106,5 +107,5 @@ EXPORTS = [
     "sqphip_acopf_attach", "sqphip_acopf_set_instance", "sqphip_acopf_eval", "sqphip_sqp_reset",
     "sqphip_sqp_run", "sqphip_sqp_get", "sqphip_sqp_status", "sqphip_sqp_trace",
     "sqphip_get_counters", "sqphip_reset_counters", "sqphip_set_timing", "sqphip_ldlt_factor_host",
-    "sqphip_ldlt_solve_host", "sqphip_ldlt_bench",
+    "sqphip_ldlt_solve_host", "sqphip_ldlt_bench", "sqphip_mfma_f64_peak",
 ]

@@ -175,3 +175,52 @@ extern "C" int sqphip_ldlt_bench(int32_t device, int32_t batch, int64_t N, int32
         return SQPHIP_EHIP;
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// fp64 MFMA issue-rate probe: every wave runs `iters` x 8 independent v_mfma_f64_16x16x4_f64 from
+// registers (no memory traffic).  Gives the on-box ceiling the LDL^T roofline is quoted against.
+namespace {
+typedef double d4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_mfma_f64_probe(double *out, int iters)
+{
+    d4v acc[8];
+    const double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = d4v{0.0, 0.0, 0.0, 0.0};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+}  // namespace
+
+extern "C" int sqphip_mfma_f64_peak(int32_t device, double *tflops)
+{
+    try {
+        SQPHIP_HIP_OK(hipSetDevice(device));
+        const int blocks = 256 * 8, threads = 256, iters = 20000;
+        double *out;
+        SQPHIP_HIP_OK(hipMalloc(&out, sizeof(double) * blocks * threads));
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        hipLaunchKernelGGL(k_mfma_f64_probe, dim3(blocks), dim3(threads), 0, 0, out, 100);
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(k_mfma_f64_probe, dim3(blocks), dim3(threads), 0, 0, out, iters);
+        hipEventRecord(e1, 0);
+        SQPHIP_HIP_OK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        const double flops = (double)blocks * (threads / 64) * (double)iters * 8.0 * 2.0 * 16 * 16 * 4;
+        *tflops = flops / (1e-3 * ms) / 1e12;
+        hipEventDestroy(e0); hipEventDestroy(e1);
+        hipFree(out);
+        return SQPHIP_OK;
+    } catch (const std::string &e) {
+        fprintf(stderr, "sqphip: %s\n", e.c_str());
+        return SQPHIP_EHIP;
+    }
+}

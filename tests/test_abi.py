@@ -1,0 +1,98 @@
+"""CPU tests of the C-ABI boundary: the HIP library loads without a GPU, exports every symbol that
+include/sqphip.h declares (and nothing is declared that is not exported), argument validation that
+needs no device work behaves, and the product never routes through oracle/."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import sqpsolver_jl_amd as pkg
+from sqpsolver_jl_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "sqphip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sqphip_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    _lib.build()
+    L = _lib.lib()
+    declared = _declared()
+    assert len(declared) >= 25
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, missing
+    assert sorted(_lib.EXPORTS) == declared
+
+
+def test_options_defaults_mirror_parameters_jl():
+    o = pkg.default_options()
+    # /root/reference/src/parameters.jl:17-29
+    assert (o.tol_direction, o.tol_residual, o.tol_infeas) == (1e-8, 1e-8, 1e-8)
+    assert (o.max_iter, o.init_mu, o.max_mu, o.tr_size, o.use_soc) == (3000, 1.0, 1e10, 10.0, 0)
+    assert (o.rho, o.eta, o.tau, o.min_alpha) == (0.8, 0.4, 0.9, 1e-6)
+    assert o.literal_quirks == 1
+
+
+def test_tr_update_needs_no_device():
+    """sqp_trust_region.jl:529-538, :574-577 -- pure scalar logic of the ABI."""
+    L = _lib.lib()
+    acc, dn = C.c_int32(), C.c_double()
+    assert L.sqphip_tr_update(1.0, 2.0, 10.0, 10.0, 1e8, 1e-8, C.byref(acc), C.byref(dn)) == 0
+    assert acc.value == 1 and dn.value == 20.0                # accepted at the boundary: radius doubles
+    L.sqphip_tr_update(1.0, 2.0, 10.0, 3.0, 1e8, 1e-8, C.byref(acc), C.byref(dn))
+    assert acc.value == 1 and dn.value == 10.0                # interior step: radius kept
+    L.sqphip_tr_update(-1.0, 2.0, 10.0, 3.0, 1e8, 1e-8, C.byref(acc), C.byref(dn))
+    assert acc.value == 0 and dn.value == 1.5                 # rejected: half of min(delta, |p|)
+    L.sqphip_tr_update(1.0, -2.0, 1e-9, 1e-9, 1e8, 1e-8, C.byref(acc), C.byref(dn))
+    assert acc.value == 0 and dn.value == 1e-9                # floor 0.1 * tol_direction
+    L.sqphip_tr_update(1.0, 2.0, 9e7, 9e7, 1e8, 1e-8, C.byref(acc), C.byref(dn))
+    assert dn.value == 1e8                                    # capped at delta_max
+
+
+def test_create_rejects_bad_arguments_before_touching_the_device():
+    L = _lib.lib()
+    import numpy as np
+    h = C.c_void_p()
+    o = pkg.default_options()
+    one = np.array([1], dtype=np.int64)
+    lp = C.POINTER(C.c_int64)
+    dp = C.POINTER(C.c_double)
+    z = np.zeros(1)
+    inf = np.array([np.inf]); ninf = np.array([-np.inf])
+    d = lambda a: a.ctypes.data_as(dp)
+    l = lambda a: a.ctypes.data_as(lp)
+    # row unbounded on both sides
+    rc = L.sqphip_create(C.byref(h), 1, 1, 0, 1, l(one), l(one), 0, l(one), l(one), d(z), d(z), d(ninf), d(inf),
+                         C.byref(o), 1)
+    assert rc == -1
+    bad = np.array([7], dtype=np.int64)                       # index out of range
+    rc = L.sqphip_create(C.byref(h), 1, 1, 0, 1, l(bad), l(one), 0, l(one), l(one), d(z), d(z), d(z), d(z),
+                         C.byref(o), 1)
+    assert rc == -1
+    assert L.sqphip_create(C.byref(h), 0, 1, 0, 0, l(one), l(one), 0, l(one), l(one), d(z), d(z), d(z), d(z),
+                           C.byref(o), 1) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "SO_PATH", str(tmp_path / "libsqphip.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.lib()
+
+
+def test_product_never_imports_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    pkgdir = os.path.join(ROOT, "sqpsolver.jl_amd")
+    for dirpath, _, files in os.walk(pkgdir):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, fn)).read()
+                code = "\n".join(ln for ln in text.splitlines()
+                                 if not ln.strip().startswith(("#", "//", "*", '"""', "The oracle")))
+                assert "from oracle" not in code and "import oracle" not in code, fn
+                assert "liboracle" not in code and "sqp_oracle.h" not in code, fn

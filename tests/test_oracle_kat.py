@@ -1,0 +1,280 @@
+"""CPU tests of the oracle: the reference's own known answers, the
+committed golden fixtures, and formula-level checks of every restated function against direct numpy
+restatements of the cited reference lines."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import sqpsolver_jl_amd  # noqa: F401
+from sqpsolver_jl_amd.acopf_synth import acopf_synth, acopf_layout, contingency, CASES
+from oracle import oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+PINS = json.load(open(os.path.join(GOLD, "reference_pins.json")))["reference_pins"]
+RUNS = json.load(open(os.path.join(GOLD, "oracle_runs.json")))["oracle_runs"]
+INF = math.inf
+
+
+def _qp_for(P, opts=None):
+    S = P.structure()
+    n = S["n"]
+    jcp, jrv, jslot, _ = O.coo_to_csc(n, S["jrow"], S["jcol"])
+    hcp, hrv, hslot, hslot_t = O.coo_to_csc(n, S["hrow"], S["hcol"], sym=True)
+    q = O.QpSolver(n, S["m"], S["num_linear"], jcp, jrv, hcp, hrv, S["xL"], S["xU"], S["gL"], S["gU"], opts)
+
+    def solve(mode, x, delta, mu, lam, b=None):
+        jv = np.zeros(len(jrv)); np.add.at(jv, jslot, P.eval_jac_g(x))
+        hv = np.zeros(len(hrv))
+        if len(S["hrow"]):
+            hc = P.eval_h(x, 1.0, lam)
+            np.add.at(hv, hslot, hc); ok = hslot_t >= 0; np.add.at(hv, hslot_t[ok], hc[ok])
+        r = q.solve(mode, x, delta, mu, P.eval_grad_f(x), P.eval_g(x) if b is None else b, jv, hv, want_slack=True)
+        r["J"] = sp.csc_matrix((jv, jrv, jcp), shape=(S["m"], n)).toarray()
+        r["H"] = sp.csc_matrix((hv, hrv, hcp), shape=(n, n)).toarray()
+        return r
+    return solve, S
+
+
+# ---------------------------------------------------------------- KAT-1 / KAT-5 / HS071: final answers
+@pytest.mark.parametrize("name", ["toy", "readme1", "hs071"])
+def test_reference_known_answers(name):
+    P = getattr(O, "problem_" + name)()
+    r = O.sqp_solve(P, O.default_options(max_iter=200))
+    pin = PINS[name]
+    assert r["status"] == 0                                  # -> MOI.LOCALLY_SOLVED (runtests.jl:14)
+    assert np.allclose(r["x"], pin["x"], rtol=pin["rtol"], atol=1e-8)
+    if "f" in pin:
+        assert abs(r["obj_val"] - pin["f"]) <= 1e-4 * max(1.0, abs(pin["f"]))
+
+
+def test_kat1_multipliers_of_last_qp():
+    """lambda (JuMP sign) of the QP at x* = (-1,-1) is (0, 1/3, 0, 0); reduced costs vanish."""
+    P = O.problem_toy()
+    solve, S = _qp_for(P)
+    x = np.array([-1.0, -1.0])
+    r = solve(O.MODE_QP, x, 10.0, 1.0, np.array([0, 1 / 3, 0, 0.0]))
+    assert r["status"] == O.MOI_LOCALLY_SOLVED
+    assert np.abs(r["p"]).max() < 1e-7
+    assert np.allclose(r["lam"], PINS["toy"]["lambda_jump_at_solution"], atol=1e-6)
+    assert np.abs(r["mult_x_L"]).max() < 1e-6 and np.abs(r["mult_x_U"]).max() < 1e-6
+
+
+def test_kat2_toy_layout():
+    S = O.problem_toy().structure()
+    pin = PINS["toy"]
+    assert (S["n"], S["m"], S["num_linear"]) == (pin["n"], pin["m"], pin["num_linear"])
+    assert S["gL"].tolist() == pin["g_L"]
+    assert [("inf" if math.isinf(v) else v) for v in S["gU"]] == pin["g_U"]
+    assert O.problem_toy().x0.tolist() == [0.0, 0.0]       # MOI_wrapper.jl:1196-1197
+
+
+def test_kat3_first_iteration_enters_feasibility_restoration():
+    P = O.problem_toy()
+    solve, S = _qp_for(P)
+    x0 = np.zeros(2); lam0 = np.zeros(4)
+    fi = PINS["toy"]["first_iterate"]
+    E = P.eval_g(x0)
+    assert E.tolist() == fi["E"]
+    assert O.norm_violations(E, S["gL"], S["gU"], x0, S["xL"], S["xU"], 1) == fi["viol1"]
+    r = solve(O.MODE_QP, x0, 10.0, 1.0, lam0)
+    assert r["status"] == O.MOI_LOCALLY_INFEASIBLE          # row 3 reads 0*p = 1
+    assert not r["p"].any() and not r["lam"].any()          # subproblem_JuMP.jl:551-555
+    fr = solve(O.MODE_FR, x0, 10.0, 1.0, lam0)
+    assert fr["status"] == O.MOI_LOCALLY_SOLVED
+    assert abs(fr["p"][0] - fi["fr_p1"]) < 1e-6
+    soft = fr["slack"][[1, 2, 4 + 1, 4 + 2]].sum()          # slacks of the violated nonlinear rows
+    assert abs(soft - fi["fr_lp_optimum"]) < 1e-6
+    tr = O.sqp_solve(P, O.default_options(max_iter=100))["trace"]
+    assert tr[0]["sub_status"] == O.MOI_LOCALLY_INFEASIBLE and tr[0]["fr"] == 1 and tr[0]["iter"] == 1
+
+
+# ---------------------------------------------------------------- KAT-4: formulas
+def _viol_np(E, gL, gU, x, xL, xU, p):
+    v = np.concatenate([np.maximum(0, np.maximum(E - gU, gL - E)), np.maximum(0, np.maximum(x - xU, xL - x))])
+    return np.linalg.norm(v, p)
+
+
+@pytest.mark.parametrize("p", [1, 2, np.inf])
+def test_norm_violations_formula(p):
+    rng = np.random.default_rng(0)
+    m, n = 17, 9
+    E = rng.standard_normal(m); x = rng.standard_normal(n)
+    gL = np.where(rng.random(m) < 0.3, -INF, -0.3 * rng.random(m))
+    gU = np.where(rng.random(m) < 0.3, INF, 0.3 * rng.random(m))
+    xL = np.full(n, -0.5); xU = np.full(n, 0.5)
+    assert math.isclose(O.norm_violations(E, gL, gU, x, xL, xU, p), _viol_np(E, gL, gU, x, xL, xU, p),
+                        rel_tol=1e-14)
+
+
+def test_kt_residuals_formula():
+    rng = np.random.default_rng(1)
+    m, n = 7, 5
+    J = sp.random(m, n, density=0.5, random_state=3, format="csc")
+    df = rng.standard_normal(n); lam = rng.standard_normal(m)
+    mu_u = -rng.random(n); mu_l = rng.random(n)
+    Jd = J.toarray()
+    res = np.abs(df + Jd.T @ lam + mu_u - mu_l).max()        # common.jl:17
+    scal = max(1.0, np.abs(df).max(), np.abs(mu_u).max(), np.abs(mu_l).max(),
+               max(abs(lam[i]) * np.linalg.norm(Jd[i]) for i in range(m)))   # :18-21
+    got = O.kt_residuals(df, lam, mu_u, mu_l, J.indptr, J.indices, J.data, m)
+    assert math.isclose(got, res / scal, rel_tol=1e-14)
+
+
+def test_complementarity_derivative_isapprox():
+    L = O.lib()
+    E = np.array([0.5, 1.0, -1.0]); gL = np.array([0.0, 1.0, -2.0]); gU = np.array([1.0, 1.0, INF])
+    lam = np.array([2.0, 5.0, -1.0])
+    comp = np.array([min(0.5, 0.5) * 2.0, 0.0, min(1.0, INF) * -1.0])
+    want = np.abs(comp).max() / (1 + math.sqrt(4 + 1))
+    got = L.ora_norm_complementarity(3, O._d(E), O._d(gL), O._d(gU), O._d(lam), 0)
+    assert math.isclose(got, want, rel_tol=1e-15)
+    cv = np.array([0.25, 0.0, 1.5])
+    assert L.ora_compute_derivative(-2.0, 3.0, 3, O._d(cv)) == -2.0 - 3.0 * cv.sum()   # merit.jl:15
+    assert L.ora_isapprox(1.0, 1.0 + 1e-9) == 1 and L.ora_isapprox(1.0, 1.0 + 1e-7) == 0
+    assert L.ora_isapprox(0.0, 1e-300) == 0                 # atol = 0
+
+
+def test_trust_region_box_repair_and_sign_split():
+    """set_trust_region! lb>ub repair (subproblem_JuMP.jl:441-444) and the reduced-cost split
+    (:543-550), observed through a one-variable LP-like QP."""
+    # min c p  s.t. x_L - x <= p <= x_U - x within +-delta ; no rows of substance
+    jcp = np.array([0, 1]); jrv = np.array([0]); hcp = np.array([0, 0]); hrv = np.array([], dtype=np.int64)
+    q = O.QpSolver(1, 1, 1, jcp, jrv, hcp, hrv, [2.0], [3.0], [-INF], [100.0])
+    # x = 5 violates x_U = 3: lb = max(-d, -3) , ub = min(d, -2) -> with delta = 1: lb=-1 > ub=-2 -> repaired to [-1, 0]
+    r = q.solve(O.MODE_QP, np.array([5.0]), 1.0, 1.0, np.array([1.0]), np.array([5.0]), np.array([1.0]), None)
+    assert r["status"] == O.MOI_LOCALLY_SOLVED
+    assert abs(r["p"][0] + 1.0) < 1e-7                       # pushed to the repaired lower bound -1
+    assert r["mult_x_L"][0] > 0 and r["mult_x_U"][0] == 0.0  # rc = +1 -> lower-bound multiplier
+    r = q.solve(O.MODE_QP, np.array([2.5]), 1.0, 1.0, np.array([-1.0]), np.array([2.5]), np.array([1.0]), None)
+    assert abs(r["p"][0] - 0.5) < 1e-7 and r["mult_x_U"][0] < 0 and r["mult_x_L"][0] == 0.0
+
+
+# ---------------------------------------------------------------- QP: KKT conditions in the JuMP sign
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_qp_kkt_conditions_hs071(seed):
+    P = O.problem_hs071()
+    solve, S = _qp_for(P)
+    rng = np.random.default_rng(seed)
+    x = np.clip(P.x0 + 0.4 * rng.standard_normal(4), 1, 5)
+    lam = 0.2 * rng.standard_normal(2)
+    r = solve(O.MODE_QP, x, 1.5, 1.0, lam)
+    assert r["status"] == O.MOI_LOCALLY_SOLVED
+    p, J, H = r["p"], r["J"], r["H"]
+    rc = r["mult_x_L"] + r["mult_x_U"]
+    stat = H @ p + P.eval_grad_f(x) - J.T @ r["lam"] - rc      # H p + c = J'lambda + rc
+    assert np.abs(stat).max() < 1e-6
+    lb = np.maximum(-1.5, S["xL"] - x); ub = np.minimum(1.5, S["xU"] - x)
+    assert (p >= lb - 1e-8).all() and (p <= ub + 1e-8).all()
+    row = P.eval_g(x) + J @ p
+    assert (row >= S["gL"] - 1e-7).all() and (row <= S["gU"] + 1e-7).all()
+    assert (r["mult_x_L"] >= 0).all() and (r["mult_x_U"] <= 0).all()
+    # complementarity: multiplier of the inequality row only if active at its lower side
+    if row[0] > S["gL"][0] + 1e-6:
+        assert abs(r["lam"][0]) < 1e-6
+    else:
+        assert r["lam"][0] >= -1e-9
+
+
+def test_lp_phase_projects_onto_linear_rows():
+    nb, ng, nl, seed = CASES["case14"]
+    net = acopf_synth(nb, ng, nl, seed); lay = acopf_layout(net)
+    P = O.problem_acopf(net, lay)
+    solve, S = _qp_for(P)
+    r = solve(O.MODE_LP, lay.x0, INF, 1.0, np.zeros(lay.m), b=None)
+    assert r["status"] == O.MOI_LOCALLY_SOLVED
+    x = r["p"]
+    g = P.eval_g(x)[: lay.num_linear]
+    assert (g >= lay.gL[: lay.num_linear] - 1e-7).all() and (g <= lay.gU[: lay.num_linear] + 1e-7).all()
+    assert (x >= lay.xL - 1e-9).all() and (x <= lay.xU + 1e-9).all()
+
+
+# ---------------------------------------------------------------- dense LDL^T
+@pytest.mark.parametrize("N", [5, 64, 130, 257])
+def test_ldlt_against_numpy(N):
+    rng = np.random.default_rng(N)
+    n1 = N * 2 // 5
+    A = rng.standard_normal((N, N)) * 0.2
+    A = (A + A.T) / 2
+    A[np.diag_indices(N)] = np.concatenate([np.ones(n1), -np.ones(N - n1)]) * (2 + 0.3 * np.sqrt(N))
+    a, dinv, npos, _ = O.ldlt_factor(A, N, nthreads=2)
+    Lm = np.tril(a, -1) + np.eye(N)
+    assert np.abs(Lm @ np.diag(1 / dinv) @ Lm.T - A).max() < 1e-12 * N
+    assert npos == n1                                        # Sylvester: inertia from the pivots
+    b = rng.standard_normal(N)
+    assert np.abs(O.ldlt_solve(a, dinv, b) - np.linalg.solve(A, b)).max() < 1e-10
+
+
+# ---------------------------------------------------------------- ACOPF evaluator
+def test_acopf_shapes_and_derivatives():
+    for name in ("case14", "case118"):
+        nb, ng, nl, seed = CASES[name]
+        net = acopf_synth(nb, ng, nl, seed); lay = acopf_layout(net)
+        assert lay.n == 2 * nb + 2 * ng + 4 * nl and lay.m == 1 + 2 * nb + 8 * nl
+        assert lay.num_linear == 2 * nl + 1 + 2 * nb
+        assert len(lay.jrow) == 32 * nl + 2 * ng + 1 and len(lay.hrow) == ng + 44 * nl
+        assert (lay.hrow >= lay.hcol).all()                  # lower-triangular COO, duplicates present
+        assert len(set(zip(lay.hrow.tolist(), lay.hcol.tolist()))) < len(lay.hrow)
+    P = O.problem_acopf(net, lay)
+    rng = np.random.default_rng(0)
+    x = lay.x0 + 0.05 * rng.standard_normal(lay.n); d = rng.standard_normal(lay.n); h = 1e-6
+    J = sp.coo_matrix((P.eval_jac_g(x), (lay.jrow - 1, lay.jcol - 1)), shape=(lay.m, lay.n)).tocsr()
+    fd = (P.eval_g(x + h * d) - P.eval_g(x - h * d)) / (2 * h)
+    assert np.abs(fd - J @ d).max() < 1e-6
+    lam = rng.standard_normal(lay.m)
+    Hl = sp.coo_matrix((P.eval_h(x, 1.0, lam), (lay.hrow - 1, lay.hcol - 1)), shape=(lay.n, lay.n)).toarray()
+    H = Hl + Hl.T - np.diag(np.diag(Hl))
+
+    def gradL(z):
+        Jz = sp.coo_matrix((P.eval_jac_g(z), (lay.jrow - 1, lay.jcol - 1)), shape=(lay.m, lay.n)).tocsr()
+        return P.eval_grad_f(z) + Jz.T @ lam
+    fdh = (gradL(x + h * d) - gradL(x - h * d)) / (2 * h)
+    assert np.abs(fdh - H @ d).max() < 1e-4 * max(1.0, np.abs(H @ d).max())
+
+
+def test_synthetic_networks_are_reproducible():
+    fp = json.load(open(os.path.join(GOLD, "networks.json")))["synthetic_networks"]
+    for name, want in fp.items():
+        nb, ng, nl, seed = CASES[name]
+        net = acopf_synth(nb, ng, nl, seed); lay = acopf_layout(net)
+        assert (lay.n, lay.m, len(lay.jrow), len(lay.hrow)) == (want["n"], want["m"], want["nnzj"], want["nnzh"])
+        assert math.isclose(float(net.pd.sum()), want["sum_pd"], rel_tol=1e-13)
+        assert net.f_bus[:8].tolist() == want["f_bus_head"] and net.t_bus[:8].tolist() == want["t_bus_head"]
+    base = acopf_synth(*CASES["case14"])
+    c = contingency(base, 3, 14)
+    assert c.status.sum() == base.nl - 1 and not np.allclose(c.pd, base.pd)
+
+
+# ---------------------------------------------------------------- golden regression of the oracle itself
+@pytest.mark.parametrize("name", sorted(RUNS))
+def test_oracle_matches_committed_golden(name):
+    g = RUNS[name]
+    if name in ("toy", "readme1", "hs071"):
+        P = getattr(O, "problem_" + name)()
+        r = O.sqp_solve(P, O.default_options(max_iter=100 if name != "hs071" else 200))
+    else:
+        tag, q = name.rsplit("_quirks", 1)
+        nb, ng, nl, seed = CASES["case14"]
+        base = acopf_synth(nb, ng, nl, seed)
+        net = base if tag.endswith("s0") else contingency(base, 3, seed)
+        r = O.sqp_solve(O.problem_acopf(net, acopf_layout(net)),
+                        O.default_options(max_iter=25, tol_infeas=1e-6, tol_residual=1e-4, literal_quirks=int(q)))
+    assert (r["status"], r["iter"], r["n_qp"]) == (g["status"], g["iter"], g["n_qp"])
+    assert np.allclose(r["x"], g["x"], rtol=1e-8, atol=1e-9)
+    got = [[t["iter"], t["accepted"], t["fr"], t["sub_status"]] for t in r["trace"]]
+    assert got == [row[:4] for row in g["trace"]]
+    assert np.allclose([t["delta"] for t in r["trace"]], [row[4] for row in g["trace"]], rtol=1e-10)
+
+
+def test_quirk_flag_switches_hessian_sign():
+    """literal_quirks=1 feeds the JuMP-sign multipliers to eval_h (sqp.jl:93); 0 negates them."""
+    nb, ng, nl, seed = CASES["case14"]
+    net = acopf_synth(nb, ng, nl, seed); lay = acopf_layout(net)
+    P = O.problem_acopf(net, lay)
+    a = O.sqp_solve(P, O.default_options(max_iter=40, tol_infeas=1e-6, tol_residual=1e-4, literal_quirks=0))
+    b = O.sqp_solve(P, O.default_options(max_iter=40, tol_infeas=1e-6, tol_residual=1e-4, literal_quirks=1))
+    assert a["status"] == 0 and a["iter"] < b["iter"]       # textbook sign converges quadratically
+    assert a["trace"][-1]["dual_infeas"] < 1e-6
