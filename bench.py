@@ -28,13 +28,18 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet fp64 matrix peak; MI355X_MICRO
 
 
 def trailing_alg_flops(N: int) -> float:
-    """Algorithmic flops of the trailing updates of one blocked LDL^T of order N (64-wide panels):
-    lower triangle incl. diagonal of every Schur update, 2 flops per multiply-add."""
+    """Algorithmic flops of the k_trailing launches that bench.py times, for one LDL^T of order N:
+    outer panels of two 64-wide sub-panels (ldlt.hip, ldlt_factor); after outer panel q the lower
+    triangle (incl. diagonal) of the matrix right of the panel receives a rank-(64*nsub) update,
+    2 flops per multiply-add.  (The rank-64 update of the panel's own second tile column runs on the
+    look-ahead stream and is neither timed nor counted.)  N = 2813: 6.92 of the 7.42 GFLOP of N^3/3."""
     T = (N + 63) // 64
     tot = 0.0
-    for k in range(T - 1):
-        r = (T - k - 1) * 64
-        tot += r * (r + 1) * 64.0
+    for c0 in range(0, T, 2):
+        nsub = 2 if c0 + 1 < T else 1
+        r = (T - c0 - 2) * 64
+        if r > 0:
+            tot += r * (r + 1) * 64.0 * nsub
     return tot
 
 

@@ -42,7 +42,8 @@ struct Scratch {
         P.N = (int)N; P.Npad = (int)((N + 63) / 64 * 64); P.T = P.Npad / 64; P.ld = P.Npad; P.B = B;
         SQPHIP_HIP_OK(hipStreamCreate(&P.stream));
         SQPHIP_HIP_OK(hipMalloc(&K, sizeof(double) * (size_t)B * P.ld * P.Npad));
-        SQPHIP_HIP_OK(hipMalloc(&P.Wbuf, sizeof(double) * (size_t)B * P.Npad * 64));
+        SQPHIP_HIP_OK(hipMalloc(&P.Wbuf, sizeof(double) * (size_t)4 * B * P.Npad * 64));
+        P.init_lookahead();
         SQPHIP_HIP_OK(hipMalloc(&dinv, sizeof(double) * (size_t)B * P.Npad));
         SQPHIP_HIP_OK(hipMalloc(&x, sizeof(double) * (size_t)B * P.Npad));
         SQPHIP_HIP_OK(hipMalloc(&v, sizeof(double) * (size_t)B * P.Npad));
@@ -61,6 +62,7 @@ struct Scratch {
     ~Scratch()
     {
         hipFree(K); hipFree(P.Wbuf); hipFree(dinv); hipFree(x); hipFree(v); hipFree(npos);
+        P.destroy_lookahead();
         if (P.stream) hipStreamDestroy(P.stream);
     }
 };

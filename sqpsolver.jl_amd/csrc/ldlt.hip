@@ -20,95 +20,152 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------------
-// tile (k,k): unblocked LDL^T, thread r owns row r in registers, column broadcast through LDS
-__global__ __launch_bounds__(64) void k_diag_factor(double *__restrict__ K, long strideK, int ld,
-                                                   double *__restrict__ dinv, int Npad, int k,
-                                                   const int *__restrict__ phase, int want)
+// tile (k,k): unblocked right-looking LDL^T by one 256-thread workgroup.  Thread (r, W) = (tid & 63,
+// tid >> 6) owns row r of the tile restricted to the columns c = W (mod 4): 16 entries in registers.
+// Step j: the owner wave of column j publishes that column (d_j L_rj) through LDS, everybody applies
+// the rank-1 update to its 16 columns.  The per-wave program is specialised on the compile-time wave
+// index W (the kernel dispatches with a wave-uniform switch), so every column test below folds at
+// compile time; lane conditions are predicated, not branched.  Arithmetic per entry is the textbook
+// order.
+template <int W>
+__device__ __forceinline__ void diag_factor_wave(double *__restrict__ A, int ld, double *__restrict__ dinv_out,
+                                                 double (*colbuf)[64], int r)
 {
-    const int inst = blockIdx.x;
-    if (phase && phase[inst] != want) return;
-    const int r = threadIdx.x;
-    double *A = K + (long)inst * strideK + (long)(k * 64) * ld + k * 64;   // tile origin
-    __shared__ double colbuf[64];
-    double a[64];
+    double a[16];
 #pragma unroll
-    for (int c = 0; c < 64; ++c) a[c] = A[(long)c * ld + r];
+    for (int q = 0; q < 16; ++q) a[q] = A[(long)(4 * q + W) * ld + r];
     double my_dinv = 0.0;
 #pragma unroll
     for (int j = 0; j < 64; ++j) {
-        const double dj = __shfl(a[j], j);
-        const double dji = 1.0 / dj;
-        if (r == j) my_dinv = dji;
-        const double l = a[j] * dji;          // L_rj for r > j
+        constexpr int dummy = 0; (void)dummy;
+        const int jq = j >> 2;
+        if ((j & 3) == W) colbuf[j & 1][r] = a[jq];   // d_j L_rj before scaling (row r of column j)
         __syncthreads();
-        colbuf[r] = a[j];                     // d_j * L_rj  (row r of column j before scaling)
-        __syncthreads();
-        if (r > j) {
-            a[j] = l;
-#pragma unroll
-            for (int c = j + 1; c < 64; ++c) a[c] -= l * colbuf[c];
+        const double dj = colbuf[j & 1][j];
+        // reciprocal by v_rcp_f64 + two Newton steps (off the IEEE-division critical path; <= 1 ulp)
+        double dji = __builtin_amdgcn_rcp(dj);
+        dji = fma(fma(-dj, dji, 1.0), dji, dji);
+        dji = fma(fma(-dj, dji, 1.0), dji, dji);
+        const bool below = r > j;
+        const double l = colbuf[j & 1][r] * dji;      // L_rj for r > j
+        const double lm = below ? l : 0.0;
+        if ((j & 3) == W) {
+            my_dinv = (r == j) ? dji : my_dinv;
+            a[jq] = below ? l : a[jq];
         }
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (4 * q + W > j) a[q] -= lm * colbuf[j & 1][4 * q + W];
     }
 #pragma unroll
-    for (int c = 0; c < 64; ++c)
-        if (c < r) A[(long)c * ld + r] = a[c];
-    dinv[(long)inst * Npad + k * 64 + r] = my_dinv;
+    for (int q = 0; q < 16; ++q) {
+        const int c = 4 * q + W;
+        if (c < r) A[(long)c * ld + r] = a[q];
+    }
+    if ((r & 3) == W) dinv_out[r] = my_dinv;          // set by lane r == j of the owner wave of column j
+}
+
+__global__ __launch_bounds__(256) void k_diag_factor(double *__restrict__ K, long strideK, int ld,
+                                                    double *__restrict__ dinv, int Npad, int k,
+                                                    const int *__restrict__ phase, int want)
+{
+    const int inst = blockIdx.x;
+    if (phase && phase[inst] != want) return;
+    const int r = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double *A = K + (long)inst * strideK + (long)(k * 64) * ld + k * 64;   // tile origin
+    double *dout = dinv + (long)inst * Npad + k * 64;
+    __shared__ double colbuf[2][64];
+    switch (w) {
+    case 0: diag_factor_wave<0>(A, ld, dout, colbuf, r); break;
+    case 1: diag_factor_wave<1>(A, ld, dout, colbuf, r); break;
+    case 2: diag_factor_wave<2>(A, ld, dout, colbuf, r); break;
+    default: diag_factor_wave<3>(A, ld, dout, colbuf, r); break;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
-// tiles (i,k), i>k: X L_kk' = A_ik by forward substitution along the row; W = X, L = X D^-1
-__global__ __launch_bounds__(64) void k_panel_trsm(double *__restrict__ K, long strideK, int ld,
-                                                  const double *__restrict__ dinv,
-                                                  double *__restrict__ Wbuf, int Npad, int k,
-                                                  const int *__restrict__ phase, int want)
+// tiles (i,k), i>k: X L_kk' = A_ik, W = X, L = X D^-1.  One 256-thread workgroup per tile; thread
+// (r, W) owns row r restricted to the columns c = W (mod 4).  Right-looking substitution: at step j the
+// owner wave publishes the final x_j through LDS, every wave applies x_c -= x_j L_kk[c][j] to its own
+// columns c > j (same subtraction order per entry as the textbook loop).  Specialised on the
+// compile-time wave index like k_diag_factor.
+template <int W>
+__device__ __forceinline__ void panel_trsm_wave(const double *__restrict__ Lkk, double *__restrict__ A, int ld,
+                                                double *__restrict__ Wout, int Npad,
+                                                const double *__restrict__ di, double *Ls, double (*xs)[64], int r)
+{
+    // packed strict lower triangle: column j holds rows c > j at Ls[tri(j) + c - j - 1]
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        constexpr int dummy = 0; (void)dummy;
+        const int c = 4 * q + W;
+        const double v = Lkk[(long)c * ld + r];
+        if (r > c) Ls[c * 63 - c * (c - 1) / 2 + r - c - 1] = v;
+    }
+    double x[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) x[q] = A[(long)(4 * q + W) * ld + r];
+#pragma unroll
+    for (int j = 0; j < 63; ++j) {
+        if ((j & 3) == W) xs[j & 1][r] = x[j >> 2];
+        __syncthreads();             // also orders the Ls stores of the prologue before their first use
+        const double xj = xs[j & 1][r];
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (4 * q + W > j) x[q] -= xj * Ls[j * 63 - j * (j - 1) / 2 + (4 * q + W) - j - 1];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int c = 4 * q + W;
+        Wout[(long)c * Npad + r] = x[q];
+        A[(long)c * ld + r] = x[q] * di[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_panel_trsm(double *__restrict__ K, long strideK, int ld,
+                                                   const double *__restrict__ dinv,
+                                                   double *__restrict__ Wbuf, int Npad, int k,
+                                                   const int *__restrict__ phase, int want)
 {
     const int inst = blockIdx.y;
     if (phase && phase[inst] != want) return;
     const int i = k + 1 + blockIdx.x;
-    const int r = threadIdx.x;
+    const int r = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double *Kb = K + (long)inst * strideK;
     const double *Lkk = Kb + (long)(k * 64) * ld + k * 64;
     double *A = Kb + (long)(k * 64) * ld + i * 64;
-    __shared__ double Ls[64 * 64];   // Ls[c*64 + j] = L_kk[j][c]  (column c of the tile)
-    __shared__ double dis[64];
-#pragma unroll 8
-    for (int c = 0; c < 64; ++c) Ls[c * 64 + r] = Lkk[(long)c * ld + r];
-    dis[r] = dinv[(long)inst * Npad + k * 64 + r];
-    double x[64];
-#pragma unroll
-    for (int c = 0; c < 64; ++c) x[c] = A[(long)c * ld + r];
-    __syncthreads();
-#pragma unroll
-    for (int j = 1; j < 64; ++j) {
-        double s = x[j];
-#pragma unroll
-        for (int c = 0; c < j; ++c) s -= x[c] * Ls[c * 64 + j];
-        x[j] = s;
-    }
-    double *W = Wbuf + (long)inst * Npad * 64;
-#pragma unroll
-    for (int c = 0; c < 64; ++c) {
-        W[(long)c * Npad + i * 64 + r] = x[c];
-        A[(long)c * ld + r] = x[c] * dis[c];
+    __shared__ double Ls[2016];      // strict lower triangle of L_kk, packed by columns (15.75 KB: the
+                                     // kernel fits beside two resident k_trailing workgroups)
+    __shared__ double xs[2][64];
+    double *Wout = Wbuf + (long)inst * Npad * 64 + i * 64;   // Wbuf already points at this sub-panel's slot
+    const double *di = dinv + (long)inst * Npad + k * 64;
+    switch (w) {
+    case 0: panel_trsm_wave<0>(Lkk, A, ld, Wout, Npad, di, Ls, xs, r); break;
+    case 1: panel_trsm_wave<1>(Lkk, A, ld, Wout, Npad, di, Ls, xs, r); break;
+    case 2: panel_trsm_wave<2>(Lkk, A, ld, Wout, Npad, di, Ls, xs, r); break;
+    default: panel_trsm_wave<3>(Lkk, A, ld, Wout, Npad, di, Ls, xs, r); break;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// trailing update on fp64 MFMA.  One workgroup (4 waves) per 64x64 tile (ti,tj), ti>=tj>k:
-//   A[ti][tj] -= W[ti] * L[tj]'   with a 64-deep inner dimension.
-// MFMA operands are arranged so that the accumulator's lane index runs along i (the contiguous
-// direction of the column-major tile): T[jj][ii] = sum_k L[j][k] W[i][k], A-operand = L, B-operand = W.
-// LDS images are k-major (Ls[k][j], Ws[k][i]) exactly as the columns lie in HBM; an XOR of 16 on
-// the in-row index for odd k puts the two k-rows read by one 32-lane group on disjoint bank halves.
+// Schur update on fp64 MFMA.  One workgroup (4 waves) per 64x64 tile (ti,tj), tj in [jlo,jhi), ti>=tj:
+//   A[ti][tj] -= sum_{t<nsub} W_t[ti] * L[tj][kp+t]'      (nsub 64-wide sub-panels, inner depth 64*nsub)
+// The C tile is read and written ONCE per call whatever nsub is: with the two-level blocking of
+// ldlt_factor (nsub = 2) the bulk update does 16 flops per byte of C traffic instead of 8, which
+// lifts it off the HBM roof.  MFMA operands are arranged so that the accumulator's lane index runs
+// along i (the contiguous direction of the column-major tile): T[jj][ii] = sum_k L[j][k] W[i][k],
+// A-operand = L, B-operand = W.  LDS images are k-major (Ls[k][j], Ws[k][i]) exactly as the columns lie
+// in HBM; an XOR of 16 on the in-row index for odd k puts the two k-rows read by one 32-lane group on
+// disjoint bank halves.
 __device__ __forceinline__ int swz(int k, int i) { return k * 64 + (i ^ ((k & 1) << 4)); }
 
 __global__ __launch_bounds__(256, 2) void k_trailing(double *__restrict__ K, long strideK, int ld,
-                                                    const double *__restrict__ Wbuf, int Npad,
-                                                    int T, int k, int B,
-                                                    const int *__restrict__ phase, int want)
+                                                    const double *__restrict__ Wbuf, long strideW, int Npad,
+                                                    int T, int kp, int nsub, int wslot, int jlo, int jhi,
+                                                    int ntl, int B, const int *__restrict__ phase, int want)
 {
-    const int rem = T - k - 1;
-    const int ntl = rem * (rem + 1) / 2;
     int inst, t;
     const int bid = blockIdx.x;
     if ((B & 7) == 0) {             // keep one instance's tiles on one XCD (its panels stay in that L2)
@@ -120,29 +177,15 @@ __global__ __launch_bounds__(256, 2) void k_trailing(double *__restrict__ K, lon
         t = bid % ntl;
     }
     if (phase && phase[inst] != want) return;
-    // column-major enumeration of the lower triangle of the rem x rem tile grid
-    int c = 0, cnt = rem;
-    while (t >= cnt) { t -= cnt; ++c; --cnt; }
-    const int tj = k + 1 + c, ti = tj + t;
+    // column-major enumeration of the tiles (ti >= tj) of tile columns jlo .. jhi-1
+    int tj = jlo, cnt = T - jlo;
+    while (t >= cnt) { t -= cnt; ++tj; --cnt; }
+    const int ti = tj + t;
 
     __shared__ double Ls[64 * 64];
     __shared__ double Ws[64 * 64];
     double *Kb = K + (long)inst * strideK;
-    const double *Lg = Kb + (long)(k * 64) * ld + tj * 64;                 // L[tj] tile, ld
-    const double *Wg = Wbuf + (long)inst * Npad * 64 + ti * 64;            // W[ti] tile, Npad
     const int tid = threadIdx.x;
-    // stage both operand tiles: thread moves 2 doubles per (column) step; 32 threads cover a column
-    {
-        const int ii = (tid & 31) * 2, kk0 = tid >> 5;     // 8 columns per pass
-#pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {
-            const int kk = pass * 8 + kk0;
-            const d2 lv = *reinterpret_cast<const d2 *>(Lg + (long)kk * ld + ii);
-            const d2 wv = *reinterpret_cast<const d2 *>(Wg + (long)kk * Npad + ii);
-            *reinterpret_cast<d2 *>(&Ls[swz(kk, ii)]) = lv;
-            *reinterpret_cast<d2 *>(&Ws[swz(kk, ii)]) = wv;
-        }
-    }
     const int wave = tid >> 6, lane = tid & 63;
     const int jb = (wave >> 1) * 32, ib = (wave & 1) * 32;
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -156,18 +199,35 @@ __global__ __launch_bounds__(256, 2) void k_trailing(double *__restrict__ K, lon
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr)
                 acc[bj][bi][rr] = Cg[(long)(bj * 16 + l4 + 4 * rr) * ld + bi * 16 + l15];
-    __syncthreads();
+    for (int sub = 0; sub < nsub; ++sub) {
+        const double *Lg = Kb + (long)((kp + sub) * 64) * ld + tj * 64;                        // L[tj][kp+sub]
+        const double *Wg = Wbuf + (long)(wslot + sub) * strideW + (long)inst * Npad * 64 + ti * 64;   // W_sub[ti]
+        if (sub) __syncthreads();
+        // stage both operand tiles: thread moves 2 doubles per (column) step; 32 threads cover a column
+        {
+            const int ii = (tid & 31) * 2, kk0 = tid >> 5;     // 8 columns per pass
+#pragma unroll
+            for (int pass = 0; pass < 8; ++pass) {
+                const int kk = pass * 8 + kk0;
+                const d2 lv = *reinterpret_cast<const d2 *>(Lg + (long)kk * ld + ii);
+                const d2 wv = *reinterpret_cast<const d2 *>(Wg + (long)kk * Npad + ii);
+                *reinterpret_cast<d2 *>(&Ls[swz(kk, ii)]) = lv;
+                *reinterpret_cast<d2 *>(&Ws[swz(kk, ii)]) = wv;
+            }
+        }
+        __syncthreads();
 #pragma unroll 4
-    for (int ks = 0; ks < 16; ++ks) {
-        const int kk = ks * 4 + l4;
-        const double a0 = -Ls[swz(kk, jb + l15)];
-        const double a1 = -Ls[swz(kk, jb + 16 + l15)];
-        const double b0 = Ws[swz(kk, ib + l15)];
-        const double b1 = Ws[swz(kk, ib + 16 + l15)];
-        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        for (int ks = 0; ks < 16; ++ks) {
+            const int kk = ks * 4 + l4;
+            const double a0 = -Ls[swz(kk, jb + l15)];
+            const double a1 = -Ls[swz(kk, jb + 16 + l15)];
+            const double b0 = Ws[swz(kk, ib + l15)];
+            const double b1 = Ws[swz(kk, ib + 16 + l15)];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
     }
 #pragma unroll
     for (int bj = 0; bj < 2; ++bj)
@@ -258,26 +318,71 @@ __global__ __launch_bounds__(64) void k_bwd_step(const double *__restrict__ K, l
 }
 
 // ---------------------------------------------------------------------------------------------
+// number of tiles (ti >= tj) in tile columns [jlo, jhi)
+static int tiles_in_cols(int T, int jlo, int jhi)
+{
+    int n = 0;
+    for (int j = jlo; j < jhi; ++j) n += T - j;
+    return n;
+}
+
+static void launch_update(const LdltPlan &P, hipStream_t s, double *K, int kp, int nsub, int wslot, int jlo,
+                          int jhi, const int *phase, int want, Timers *tm, bool count)
+{
+    if (jhi > P.T) jhi = P.T;
+    if (jlo >= jhi) return;
+    const int ntl = tiles_in_cols(P.T, jlo, jhi);
+    const long strideK = (long)P.ld * P.Npad, strideW = (long)P.B * P.Npad * 64;
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    const bool timed = tm && tm->enabled && count;
+    if (timed) { ev = tm->get(); hipEventRecord(ev.first, s); }
+    hipLaunchKernelGGL(k_trailing, dim3(ntl * P.B), dim3(256), 0, s, K, strideK, P.ld, P.Wbuf, strideW, P.Npad,
+                       P.T, kp, nsub, wslot, jlo, jhi, ntl, P.B, phase, want);
+    if (timed) { hipEventRecord(ev.second, s); tm->pending_trailing.push_back(ev); }
+    if (tm && count) tm->trailing_launches++;
+}
+
+static void launch_panel(const LdltPlan &P, hipStream_t s, double *K, double *dinv, int c, int wslot,
+                         const int *phase, int want)
+{
+    const long strideK = (long)P.ld * P.Npad, strideW = (long)P.B * P.Npad * 64;
+    hipLaunchKernelGGL(k_diag_factor, dim3(P.B), dim3(256), 0, s, K, strideK, P.ld, dinv, P.Npad, c, phase, want);
+    const int rem = P.T - c - 1;
+    if (rem > 0)
+        hipLaunchKernelGGL(k_panel_trsm, dim3(rem, P.B), dim3(256), 0, s, K, strideK, P.ld, dinv,
+                           P.Wbuf + (long)wslot * strideW, P.Npad, c, phase, want);
+}
+
+// Two-level right-looking LDL^T: outer panels of two 64-wide sub-panels, so every pass over the
+// trailing matrix applies a rank-128 update.  Look-ahead: the update is split into the "head" (the two
+// tile columns of the next outer panel) and the "rest"; the latency-bound factorisation of the next
+// panel runs on the auxiliary stream while the main stream streams the rest through the MFMA kernel.
+// W = L D of the current outer panel lives in Wbuf slots {0,1} or {2,3} by panel parity.
 void ldlt_factor(const LdltPlan &P, double *K, double *dinv, const int *phase, int want, Timers *tm)
 {
-    const long strideK = (long)P.ld * P.Npad;
-    hipStream_t s = P.stream;
-    for (int k = 0; k < P.T; ++k) {
-        hipLaunchKernelGGL(k_diag_factor, dim3(P.B), dim3(64), 0, s, K, strideK, P.ld, dinv, P.Npad, k,
-                           phase, want);
-        const int rem = P.T - k - 1;
-        if (rem <= 0) break;
-        hipLaunchKernelGGL(k_panel_trsm, dim3(rem, P.B), dim3(64), 0, s, K, strideK, P.ld, dinv, P.Wbuf,
-                           P.Npad, k, phase, want);
-        const int ntl = rem * (rem + 1) / 2;
-        std::pair<hipEvent_t, hipEvent_t> ev;
-        const bool timed = tm && tm->enabled;
-        if (timed) { ev = tm->get(); hipEventRecord(ev.first, s); }
-        hipLaunchKernelGGL(k_trailing, dim3(ntl * P.B), dim3(256), 0, s, K, strideK, P.ld, P.Wbuf, P.Npad,
-                           P.T, k, P.B, phase, want);
-        if (timed) { hipEventRecord(ev.second, s); tm->pending_trailing.push_back(ev); }
-        if (tm) tm->trailing_launches++;
+    hipStream_t sA = P.stream, sB = P.aux ? P.aux : P.stream;
+    const int T = P.T;
+    const int nq = (T + 1) / 2;
+    hipEvent_t evStart = P.ev[0];
+    if (sB != sA) { hipEventRecord(evStart, sA); hipStreamWaitEvent(sB, evStart, 0); }
+    for (int q = 0; q < nq; ++q) {
+        const int c0 = 2 * q, c1 = c0 + 1, slot = (q & 1) * 2;
+        const int nsub = c1 < T ? 2 : 1;
+        hipEvent_t evPanel = P.ev[1 + (q & 1)], evHead = P.ev[3 + (q & 1)];
+        // ---- stream B: factor the outer panel
+        launch_panel(P, sB, K, dinv, c0, slot, phase, want);
+        if (nsub == 2) {
+            launch_update(P, sB, K, c0, 1, slot, c1, c1 + 1, phase, want, tm, false);   // tile column c1 <- sub-panel c0
+            launch_panel(P, sB, K, dinv, c1, slot + 1, phase, want);
+        }
+        if (c0 + nsub >= T) break;
+        if (sB != sA) { hipEventRecord(evPanel, sB); hipStreamWaitEvent(sA, evPanel, 0); }
+        // ---- stream A: head (next panel's two tile columns), then the rest
+        launch_update(P, sA, K, c0, nsub, slot, c0 + 2, c0 + 4, phase, want, tm, true);
+        if (sB != sA) { hipEventRecord(evHead, sA); hipStreamWaitEvent(sB, evHead, 0); }
+        launch_update(P, sA, K, c0, nsub, slot, c0 + 4, T, phase, want, tm, true);
     }
+    if (sB != sA) { hipEventRecord(P.ev[5], sB); hipStreamWaitEvent(sA, P.ev[5], 0); }
     if (tm) tm->n_factor++;
 }
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -50,8 +51,21 @@ struct Timers {
 
 struct LdltPlan {
     int N = 0, Npad = 0, T = 0, ld = 0, B = 0;
-    double *Wbuf = nullptr;     // [B][64][Npad] : W = L D of the current panel
-    hipStream_t stream = nullptr;
+    double *Wbuf = nullptr;     // 4 slots of [B][64][Npad] : W = L D of the sub-panels of two outer panels
+    hipStream_t stream = nullptr;   // main stream (everything but the panel look-ahead)
+    hipStream_t aux = nullptr;      // panel factorisation of the next outer panel
+    hipEvent_t ev[6] = {};          // start, panel[2], head[2], join
+    void init_lookahead()
+    {
+        if (!getenv("SQPHIP_NO_LOOKAHEAD")) hipStreamCreateWithFlags(&aux, hipStreamNonBlocking);
+        for (auto &e : ev) hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    }
+    void destroy_lookahead()
+    {
+        if (aux) hipStreamDestroy(aux);
+        for (auto &e : ev) if (e) hipEventDestroy(e);
+        aux = nullptr;
+    }
 };
 
 // phase-filtered launches: kernels skip instances whose phase[inst] != want (phase may be null)
