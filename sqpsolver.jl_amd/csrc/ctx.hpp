@@ -33,6 +33,7 @@ struct SqpState {
     int iter, ret, step_acceptance, fr, sub_status, done, stage, need_qp, qp_mode, want_eval;
     int n_qp, trace_len, it_ipm, soc_pending, lp_pending, started;
     long tot_ipm, tot_fac;
+    int budget;          // outer iterations this instance may still start in the current sqp_run call
 };
 
 #define SQPHIP_TRACE_COLS 12
@@ -118,6 +119,8 @@ struct Ctx {
 
 // ipm.hip
 void ipm_run_all(Ctx &C);            // runs every instance whose IpmState.start is set, to completion
+void ipm_sweep(Ctx &C, bool sqp_level);
+void sqp_stage_kernels(Ctx &C);      // sqp.hip: SQP-level kernels of a sweep
 void launch_qp_gather(Ctx &C);       // COO -> CSC for instances with start set (stage 0)
 // acopf.hip
 void launch_acopf_eval_point(Ctx &C, int inst, const double *x_dev, double sigma, const double *lam_dev,

@@ -620,36 +620,52 @@ static void read_counters(Ctx &C)
     SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
 }
 
-// Runs every instance whose IpmState.start flag is set until each has a final MOI status.
-void ipm_run_all(Ctx &C)
+// One sweep = one pass of the fixed kernel sequence.  Every kernel is gated on per-instance state:
+//   k_qp_finish   phase DONE      -> final status (IDLE) or restart request (phase 1 / escalation)
+//   [SQP level]   stage gating    -> merit step of finished sub-problems, next sub-problem request
+//   k_qp_gather / k_ipm_start     -> instances with a start request
+//   k_ipm_prepare phase PREP      -> convergence test, barrier update, diagonals -> FACTOR
+//   assemble, LDL^T, inertia      -> FACTOR -> SOLVE (or delta_w bump, stays FACTOR)
+//   3 x (solve, refine)           -> SOLVE -> STEP
+//   k_ipm_step    phase STEP      -> update -> PREP
+//   k_ipm_prepare again           -> so that a converged instance is recognised in this sweep
+void ipm_sweep(Ctx &C, bool sqp_level)
 {
     DV &d = C.d;
     hipStream_t s = C.stream;
     const dim3 gB(d.B), bT(TPB);
-    for (int guard = 0; guard < 64; ++guard) {          // (re)starts: main run, phase 1, escalation
+    hipLaunchKernelGGL(k_qp_finish, gB, bT, 0, s, d);
+    if (sqp_level) sqp_stage_kernels(C);
+    hipLaunchKernelGGL(k_qp_gather, gB, bT, 0, s, d);
+    hipLaunchKernelGGL(k_ipm_start, gB, bT, 0, s, d);
+    hipLaunchKernelGGL(k_ipm_prepare, gB, bT, 0, s, d);
+    hipLaunchKernelGGL(k_kkt_assemble, dim3(d.Npad, d.B), dim3(128), 0, s, d);
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (C.tm.enabled) { ev = C.tm.get(); hipEventRecord(ev.first, s); }
+    ldlt_factor(C.plan, d.K, d.dinv, d.phase, PH_FACTOR, &C.tm);
+    if (C.tm.enabled) { hipEventRecord(ev.second, s); C.tm.pending_factor.push_back(ev); }
+    hipLaunchKernelGGL(k_inertia_rhs, gB, bT, 0, s, d);
+    if (C.tm.enabled) { ev = C.tm.get(); hipEventRecord(ev.first, s); }
+    for (int r = 0; r < 3; ++r) {
+        ldlt_solve(C.plan, d.K, d.dinv, d.xv, d.vv, d.phase, PH_SOLVE);
+        hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, r == 2 ? 1 : 0);
+    }
+    if (C.tm.enabled) { hipEventRecord(ev.second, s); C.tm.pending_solve.push_back(ev); }
+    hipLaunchKernelGGL(k_ipm_step, gB, bT, 0, s, d);
+    hipLaunchKernelGGL(k_ipm_prepare, gB, bT, 0, s, d);
+}
+
+// Runs every instance whose IpmState.start flag is set until each has a final MOI status
+// (drop-in sqphip_qp_solve path: no SQP-level kernels).
+void ipm_run_all(Ctx &C)
+{
+    for (long sweep = 0; sweep < 100000000L; ++sweep) {
+        ipm_sweep(C, false);
+        // counters[0] = instances iterating, [1] = start requests (phase 1 / escalation restarts)
+        hipLaunchKernelGGL(k_qp_finish, dim3(C.d.B), dim3(TPB), 0, C.stream, C.d);
         read_counters(C);
-        if (C.h_counters[1] == 0) break;
-        hipLaunchKernelGGL(k_ipm_start, gB, bT, 0, s, d);
-        for (long sweep = 0; sweep < 100000; ++sweep) {
-            hipLaunchKernelGGL(k_ipm_prepare, gB, bT, 0, s, d);
-            hipLaunchKernelGGL(k_kkt_assemble, dim3(d.Npad, d.B), dim3(128), 0, s, d);
-            std::pair<hipEvent_t, hipEvent_t> ev;
-            if (C.tm.enabled) { ev = C.tm.get(); hipEventRecord(ev.first, s); }
-            ldlt_factor(C.plan, d.K, d.dinv, d.phase, PH_FACTOR, &C.tm);
-            if (C.tm.enabled) { hipEventRecord(ev.second, s); C.tm.pending_factor.push_back(ev); }
-            hipLaunchKernelGGL(k_inertia_rhs, gB, bT, 0, s, d);
-            if (C.tm.enabled) { ev = C.tm.get(); hipEventRecord(ev.first, s); }
-            for (int r = 0; r < 3; ++r) {
-                ldlt_solve(C.plan, d.K, d.dinv, d.xv, d.vv, d.phase, PH_SOLVE);
-                hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, r == 2 ? 1 : 0);
-            }
-            if (C.tm.enabled) { hipEventRecord(ev.second, s); C.tm.pending_solve.push_back(ev); }
-            hipLaunchKernelGGL(k_ipm_step, gB, bT, 0, s, d);
-            read_counters(C);
-            if (C.tm.pending_trailing.size() > 4096) C.tm.flush();
-            if (C.h_counters[0] == 0) break;
-        }
-        hipLaunchKernelGGL(k_qp_finish, gB, bT, 0, s, d);
+        if (C.tm.pending_trailing.size() > 4096) C.tm.flush();
+        if (C.h_counters[0] == 0 && C.h_counters[1] == 0) break;
     }
 }
 

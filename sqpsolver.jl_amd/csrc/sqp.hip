@@ -17,7 +17,15 @@
 
 namespace sqphip {
 
-enum { SQ_RUN = 0, SQ_SKIP = 1, SQ_SOC = 2 };
+// where an instance stands in run! (sqp_trust_region.jl:124-214); kernels act only on their stage
+enum { ST_TOP = 0, ST_QP = 1, ST_SOC = 2, ST_LP = 3, ST_DONE = 4 };
+
+// the sub-problem requested by this instance has reached a final MOI status
+static __device__ __forceinline__ bool qp_final(const DV &d, int inst)
+{
+    const IpmState &I = d.ist[inst];
+    return d.phase[inst] == PH_IDLE && I.start == 0 && I.status > 0;
+}
 
 #define SQP_PTRS                                                                                     \
     const long on = (long)inst * d.n, om = (long)inst * d.m;                                        \
@@ -130,7 +138,7 @@ static __device__ void finalize(const DV &d, int inst, SqpState &S, const double
     acopf_eval(d, inst, x, 1.0, nullptr, &fsh, nullptr, nullptr, nullptr, nullptr);
     __syncthreads();
     f = fsh;
-    if (threadIdx.x == 0) { S.obj_val = f; S.done = 1; S.stage = SQ_SKIP; }
+    if (threadIdx.x == 0) { S.obj_val = f; S.done = 1; S.stage = ST_DONE; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -166,16 +174,16 @@ __global__ __launch_bounds__(TPB) void k_sqp_begin(DV d)
     for (int i = threadIdx.x; i < d.nlin; i += TPB) { lpv += fmax(0.0, gL[i] - E[i]); lpv -= fmin(0.0, gU[i] - E[i]); }
     for (int j = threadIdx.x; j < d.n; j += TPB) { lpv += fmax(0.0, xL[j] - x[j]); lpv -= fmin(0.0, xU[j] - x[j]); }
     lpv = block_reduce<OpSum>(lpv);
-    if (threadIdx.x == 0) { S.f = f; S.started = 1; S.it_ipm = 0; }
+    if (threadIdx.x == 0) { S.f = f; S.started = 1; S.it_ipm = 0; S.stage = ST_TOP; }
     if (isnan(f)) {                                       // :113-115
-        if (threadIdx.x == 0) { S.ret = -13; S.done = 1; S.stage = SQ_SKIP; }
+        if (threadIdx.x == 0) { S.ret = -13; S.done = 1; S.stage = ST_DONE; }
         return;
     }
     if (lpv > d.tol_infeas) {                             // :116-119 -> sub_optimize_lp! :264-304
         acopf_eval(d, inst, x, 1.0, nullptr, nullptr, df, nullptr, jcoo, nullptr);
         double *xk = d.xk + on;
         for (int j = threadIdx.x; j < d.n; j += TPB) xk[j] = x[j];
-        if (threadIdx.x == 0) { qp_request(I, SQPHIP_MODE_LP, S.Delta, S.mu); S.lp_pending = 1; }
+        if (threadIdx.x == 0) { qp_request(I, SQPHIP_MODE_LP, S.Delta, S.mu); S.stage = ST_LP; }
     }
 }
 
@@ -183,13 +191,13 @@ __global__ __launch_bounds__(TPB) void k_sqp_lp_finish(DV d)
 {
     const int inst = blockIdx.x;
     SQP_PTRS
-    if (!S.lp_pending) return;
+    if (S.done || S.stage != ST_LP || !qp_final(d, inst)) return;
     const double *op = d.op + on, *ol = d.olam + om, *oU = d.omxU + on, *oL = d.omxL + on;
     auto dz = [](double v) { return fabs(v) < 1e-10 ? 0.0 : v; };   // utils.jl:16-22
     for (int j = threadIdx.x; j < d.n; j += TPB) { x[j] = dz(op[j]); mxU[j] = dz(oU[j]); mxL[j] = dz(oL[j]); }
     for (int i = threadIdx.x; i < d.m; i += TPB) lam[i] = dz(ol[i]);
     if (threadIdx.x == 0) {
-        S.sub_status = I.status; S.lp_pending = 0; S.n_qp++; S.it_ipm = I.ipm_iters;
+        S.sub_status = I.status; S.stage = ST_TOP; S.n_qp++; S.it_ipm = I.ipm_iters;
         S.tot_ipm += I.ipm_iters; S.tot_fac += I.n_factor;
     }
     __syncthreads();
@@ -202,8 +210,8 @@ __global__ __launch_bounds__(TPB) void k_sqp_top(DV d)
 {
     const int inst = blockIdx.x;
     SQP_PTRS
-    if (S.done) return;
-    if (threadIdx.x == 0) { S.stage = SQ_RUN; S.it_ipm = 0; }
+    if (S.done || !S.started || S.stage != ST_TOP || S.budget <= 0) return;
+    if (threadIdx.x == 0) { S.stage = ST_QP; S.it_ipm = 0; }
     __syncthreads();
     if (S.iter > d.max_iter) {                            // sqp.jl:215-224
         if (threadIdx.x == 0) S.ret = S.prim_infeas <= d.tol_infeas ? 6 : -1;
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(TPB) void k_sqp_mid(DV d)
 {
     const int inst = blockIdx.x;
     SQP_PTRS
-    if (S.done || S.stage != SQ_RUN) return;
+    if (S.done || S.stage != ST_QP || !qp_final(d, inst)) return;
     const double *op = d.op + on, *ol = d.olam + om, *oU = d.omxU + on, *oL = d.omxL + on;
     // compute_step! :373-378
     for (int j = threadIdx.x; j < d.n; j += TPB) { ps[j] = op[j]; pmxL[j] = oL[j] - mxL[j]; pmxU[j] = oU[j] - mxU[j]; }
@@ -299,7 +307,7 @@ __global__ __launch_bounds__(TPB) void k_sqp_mid(DV d)
             if (threadIdx.x == 0) S.fr = 1;
             __syncthreads();
             push_trace(d, inst, S, pn);
-            if (threadIdx.x == 0) { S.iter += 1; S.stage = SQ_SKIP; }
+            if (threadIdx.x == 0) { S.iter += 1; S.stage = ST_TOP; S.budget -= 1; }
         }
         return;
     } else {                                                           // :169-178 (quirk #1)
@@ -316,7 +324,7 @@ __global__ __launch_bounds__(TPB) void k_sqp_mid(DV d)
     push_trace(d, inst, S, pn);                                        // :184
     if (pn <= d.tol_direction) {                                       // :187-196
         if (S.fr) {
-            if (threadIdx.x == 0) { S.fr = 0; S.iter += 1; S.stage = SQ_SKIP; }
+            if (threadIdx.x == 0) { S.fr = 0; S.iter += 1; S.stage = ST_TOP; S.budget -= 1; }
         } else {
             if (threadIdx.x == 0) S.ret = 0;
             __syncthreads();
@@ -367,7 +375,7 @@ __global__ __launch_bounds__(TPB) void k_sqp_mid(DV d)
             }
             if (threadIdx.x == 0) {
                 qp_request(I, SQPHIP_MODE_SOC, S.Delta, S.mu);
-                S.soc_pending = 1; S.q0 = q0; S.pnorm = pn; S.stage = SQ_SOC;
+                S.q0 = q0; S.pnorm = pn; S.stage = ST_SOC;
             }
             return;
         }
@@ -380,6 +388,7 @@ __global__ __launch_bounds__(TPB) void k_sqp_mid(DV d)
     if (threadIdx.x == 0) {
         if (S.fr && S.step_acceptance) S.fr = 0;                       // :209-211
         S.iter += 1;                                                   // :213
+        S.stage = ST_TOP; S.budget -= 1;
     }
 }
 
@@ -388,7 +397,7 @@ __global__ __launch_bounds__(TPB) void k_sqp_soc_finish(DV d)
 {
     const int inst = blockIdx.x;
     SQP_PTRS
-    if (S.done || !S.soc_pending) return;
+    if (S.done || S.stage != ST_SOC || !qp_final(d, inst)) return;
     const double *op = d.op + on;
     for (int j = threadIdx.x; j < d.n; j += TPB) { psoc[j] = ps[j] + op[j]; tmpx[j] = x[j] + ps[j] + op[j]; }
     __syncthreads();
@@ -413,16 +422,26 @@ __global__ __launch_bounds__(TPB) void k_sqp_soc_finish(DV d)
     if (threadIdx.x == 0) {
         if (S.fr && S.step_acceptance) S.fr = 0;
         S.iter += 1;
-        S.soc_pending = 0; S.stage = SQ_RUN;
+        S.stage = ST_TOP; S.budget -= 1;
     }
+}
+
+__global__ void k_sqp_budget(DV d, int budget)
+{
+    for (int i = threadIdx.x; i < d.B; i += blockDim.x) d.sst[i].budget = budget;
 }
 
 __global__ void k_sqp_count(DV d)
 {
-    int nd = 0, ns = 0;
-    for (int i = threadIdx.x; i < d.B; i += blockDim.x) { if (!d.sst[i].done) ++nd; if (d.ist[i].start) ++ns; }
+    // counters[2] = instances that still have work in this run, [3] = pending sub-problem starts
+    int nb = 0, ns = 0;
+    for (int i = threadIdx.x; i < d.B; i += blockDim.x) {
+        const SqpState &S = d.sst[i];
+        if (!S.done && (S.budget > 0 || S.stage != ST_TOP)) ++nb;
+        if (d.ist[i].start) ++ns;
+    }
     __shared__ int a[64], b[64];
-    a[threadIdx.x] = nd; b[threadIdx.x] = ns;
+    a[threadIdx.x] = nb; b[threadIdx.x] = ns;
     __syncthreads();
     if (threadIdx.x == 0) {
         int s0 = 0, s1 = 0;
@@ -444,34 +463,35 @@ void sqp_reset(Ctx &C)
     SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
 }
 
+// Every instance performs up to `max_outer` more outer iterations of run! (0 = until it terminates).
+// Continuous batching: one fixed kernel sequence per sweep; every kernel is gated on the per-instance
+// stage / phase, so an instance whose sub-problem has converged goes through its merit step and into
+// its next sub-problem while the others are still iterating -- no instance waits for the slowest.
 void sqp_run(Ctx &C, int max_outer)
 {
     DV &d = C.d;
     hipStream_t s = C.stream;
     const dim3 gB(d.B), bT(TPB);
+    hipLaunchKernelGGL(k_sqp_budget, dim3(1), dim3(64), 0, s, d, max_outer > 0 ? max_outer : 0x3fffffff);
     hipLaunchKernelGGL(k_sqp_begin, gB, bT, 0, s, d);
-    read_sqp_counters(C);
-    if (C.h_counters[3] > 0) {
-        launch_qp_gather(C);
-        ipm_run_all(C);
-        hipLaunchKernelGGL(k_sqp_lp_finish, gB, bT, 0, s, d);
-    }
-    for (int outer = 0; max_outer <= 0 || outer < max_outer; ++outer) {
+    for (long sweep = 0; sweep < 100000000L; ++sweep) {
+        ipm_sweep(C, /*sqp_level=*/true);
         read_sqp_counters(C);
+        if (C.tm.pending_trailing.size() > 4096) C.tm.flush();
         if (C.h_counters[2] == 0) break;
-        hipLaunchKernelGGL(k_sqp_top, gB, bT, 0, s, d);
-        launch_qp_gather(C);
-        ipm_run_all(C);
-        hipLaunchKernelGGL(k_sqp_mid, gB, bT, 0, s, d);
-        if (d.use_soc) {
-            read_sqp_counters(C);
-            if (C.h_counters[3] > 0) {
-                ipm_run_all(C);
-                hipLaunchKernelGGL(k_sqp_soc_finish, gB, bT, 0, s, d);
-            }
-        }
     }
     SQPHIP_HIP_OK(hipStreamSynchronize(s));
+}
+
+// SQP-level kernels of a sweep, in dependency order (called from ipm_sweep)
+void sqp_stage_kernels(Ctx &C)
+{
+    DV &d = C.d;
+    const dim3 gB(d.B), bT(TPB);
+    hipLaunchKernelGGL(k_sqp_lp_finish, gB, bT, 0, C.stream, d);
+    hipLaunchKernelGGL(k_sqp_mid, gB, bT, 0, C.stream, d);
+    if (d.use_soc) hipLaunchKernelGGL(k_sqp_soc_finish, gB, bT, 0, C.stream, d);
+    hipLaunchKernelGGL(k_sqp_top, gB, bT, 0, C.stream, d);
 }
 
 // ---------------------------------------------------------------------------------------------
