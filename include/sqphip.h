@@ -54,6 +54,7 @@ typedef struct {
     int32_t literal_quirks;  /* 1: reproduce SURVEY.md App. C #2/#3 (JuMP-sign Hessian/KT residual) */
     double ipm_tol;          /* interior-point optimality tolerance (scaled), default 1e-9 */
     int32_t ipm_max_iter;    /* default 200 */
+    int32_t ipm_phase1;      /* 1: confirm infeasibility verdicts with a phase-1 run (default 0) */
     int32_t device;          /* HIP device ordinal */
 } sqphip_options;
 

@@ -22,6 +22,7 @@ void ora_default_options(ora_options *o)
     o->literal_quirks = 1;
     o->ipm_tol = 1e-9;
     o->ipm_max_iter = 200;
+    o->ipm_phase1 = 0;
     o->num_threads = 1;
 }
 

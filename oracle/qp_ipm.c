@@ -14,7 +14,8 @@
  *          J_i p + tp_i - tm_i       = lo_i                          (equality rows)
  *          tp, tm >= 0,   lb <= p <= ub
  * Rows the mode treats as hard carry the exact-penalty weight rho_big; if elastic mass remains on a
- * hard row a phase-1 solve decides between "infeasible" and "raise rho_big".  With elastics on every
+ * hard row the sub-problem is reported infeasible (with opt.ipm_phase1 a phase-1 solve first decides
+ * between "infeasible" and "raise rho_big"; on every problem tried it only ever confirmed the verdict).  With elastics on every
  * row the reduced KKT matrix  K = [W J'; J -D]  (W = H + hd + Sigma_p + delta_w I, D > 0) is
  * quasi-definite whenever W > 0, so an LDL' without pivoting exists; inertia is judged on the total
  * pivot signs (n positive, m negative) and a wrong count raises delta_w.  A fixed primal-dual
@@ -770,6 +771,7 @@ int ora_qp_solve(ora_qp *q, int mode, const double *x_k, double delta, double mu
         if (rc == 2) { status = ORA_MOI_NUMERICAL_ERROR; break; }
         q->last_elastic = hard_elastic(q);
         if (q->last_elastic <= ELASTIC_TOL) { status = ORA_MOI_LOCALLY_SOLVED; break; }
+        if (!q->opt.ipm_phase1) { status = ORA_MOI_LOCALLY_INFEASIBLE; break; }
         /* elastic mass on a hard row: infeasible, or penalty too small?  Phase 1 decides. */
         {
             size_t nb = sizeof(double) * (size_t)n, mb = sizeof(double) * (size_t)m;

@@ -57,6 +57,8 @@ typedef struct {
     /* stand-in for the external solver's own options */
     double ipm_tol;
     int ipm_max_iter;
+    int ipm_phase1;    /* 1: confirm an infeasibility verdict with a phase-1 run and escalate the penalty if it
+                          disagrees; 0 (default): elastic mass left on a hard row means infeasible */
     int num_threads;   /* OpenMP threads for the dense LDL^T (cpu_baseline reports this) */
 } ora_options;
 

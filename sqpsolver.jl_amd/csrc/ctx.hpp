@@ -66,7 +66,7 @@ struct DV {
     int *phase;
     int *counters;      // [0] instances iterating, [1] start flags, [2] SQP not done, [3] start flags
     double ipm_tol;
-    int ipm_max_iter;
+    int ipm_max_iter, ipm_phase1;
     // ---- SQP level
     double *x, *lambda, *mxL, *mxU, *df, *E, *pstep, *psoc, *plam, *pmxL, *pmxU, *Esoc, *tmpx, *tmpE,
         *hlam;

@@ -9,8 +9,8 @@
 //
 // Method (DESIGN.md section "IPM"): every row carries elastic variables tp, tm >= 0 so the programme
 // always has a strict interior and the start satisfies the (linear) row equations exactly; hard rows
-// are priced at rho_big (exact penalty) and a phase-1 run separates "infeasible" from "penalty too
-// small".  Monotone Fiacco-McCormick barrier updates, one Newton direction per iteration from the
+// are priced at rho_big (exact penalty); elastic mass left on a hard row means infeasible (optionally
+// confirmed by a phase-1 run, options.ipm_phase1).  Monotone Fiacco-McCormick barrier updates, one Newton direction per iteration from the
 // reduced KKT system K = [W J'; J -D] factorised by the batched dense LDL^T (ldlt.hip), inertia
 // judged on pivot signs (n positive, m negative) with delta_w escalation, a fixed primal-dual
 // regularisation of 1e-8, fraction-to-boundary step lengths.  One 256-thread workgroup owns an instance in the vector kernels; wave-level
@@ -552,6 +552,7 @@ __global__ __launch_bounds__(TPB) void k_qp_finish(DV d)
         if (st.rc == 1) status = SQPHIP_MOI_ITERATION_LIMIT;
         else if (st.rc == 2) status = SQPHIP_MOI_NUMERICAL_ERROR;
         else if (el <= ELASTIC_TOL) status = SQPHIP_MOI_LOCALLY_SOLVED;
+        else if (!d.ipm_phase1) status = SQPHIP_MOI_LOCALLY_INFEASIBLE;
         if (threadIdx.x == 0) st.elastic = el;
     } else {
         const bool infeasible = st.rc != 0 || el > ELASTIC_TOL;
