@@ -452,7 +452,7 @@ __global__ __launch_bounds__(TPB) void k_refine(DV d, int last)
         wN[d.n + i] = r; en = fmax(en, fabs(r));
     }
     en = block_reduce<OpMax>(en);
-    const bool stop = last || st.refine_it >= 2 || !(en > 1e-11 * st.rn);
+    const bool stop = last || st.refine_it >= 1 || !(en > 1e-11 * st.rn);
     if (!stop)
         for (int i = threadIdx.x; i < d.Npad; i += TPB) xv[i] = i < d.N ? wN[i] : 0.0;
     if (threadIdx.x == 0) {
@@ -627,7 +627,7 @@ static void read_counters(Ctx &C)
 //   k_qp_gather / k_ipm_start     -> instances with a start request
 //   k_ipm_prepare phase PREP      -> convergence test, barrier update, diagonals -> FACTOR
 //   assemble, LDL^T, inertia      -> FACTOR -> SOLVE (or delta_w bump, stays FACTOR)
-//   3 x (solve, refine)           -> SOLVE -> STEP
+//   2 x (solve, refine)           -> SOLVE -> STEP
 //   k_ipm_step    phase STEP      -> update -> PREP
 //   k_ipm_prepare again           -> so that a converged instance is recognised in this sweep
 void ipm_sweep(Ctx &C, bool sqp_level)
@@ -647,9 +647,9 @@ void ipm_sweep(Ctx &C, bool sqp_level)
     if (C.tm.enabled) { hipEventRecord(ev.second, s); C.tm.pending_factor.push_back(ev); }
     hipLaunchKernelGGL(k_inertia_rhs, gB, bT, 0, s, d);
     if (C.tm.enabled) { ev = C.tm.get(); hipEventRecord(ev.first, s); }
-    for (int r = 0; r < 3; ++r) {
+    for (int r = 0; r < 2; ++r) {      // plain solve + at most one refinement step
         ldlt_solve(C.plan, d.K, d.dinv, d.xv, d.vv, d.phase, PH_SOLVE);
-        hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, r == 2 ? 1 : 0);
+        hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, r == 1 ? 1 : 0);
     }
     if (C.tm.enabled) { hipEventRecord(ev.second, s); C.tm.pending_solve.push_back(ev); }
     hipLaunchKernelGGL(k_ipm_step, gB, bT, 0, s, d);
