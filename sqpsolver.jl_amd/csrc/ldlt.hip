@@ -161,10 +161,10 @@ __global__ __launch_bounds__(256) void k_panel_trsm(double *__restrict__ K, long
 // disjoint bank halves.
 __device__ __forceinline__ int swz(int k, int i) { return k * 64 + (i ^ ((k & 1) << 4)); }
 
-__global__ __launch_bounds__(256, 2) void k_trailing(double *__restrict__ K, long strideK, int ld,
-                                                    const double *__restrict__ Wbuf, long strideW, int Npad,
-                                                    int T, int kp, int nsub, int wslot, int jlo, int jhi,
-                                                    int ntl, int B, const int *__restrict__ phase, int want)
+__device__ __forceinline__ void schur_update_tile(double *__restrict__ K, long strideK, int ld,
+                                                  const double *__restrict__ Wbuf, long strideW, int Npad,
+                                                  int T, int kp, int nsub, int wslot, int jlo, int jhi,
+                                                  int ntl, int B, const int *__restrict__ phase, int want)
 {
     int inst, t;
     const int bid = blockIdx.x;
@@ -236,6 +236,24 @@ __global__ __launch_bounds__(256, 2) void k_trailing(double *__restrict__ K, lon
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr)
                 Cg[(long)(bj * 16 + l4 + 4 * rr) * ld + bi * 16 + l15] = acc[bj][bi][rr];
+}
+
+// the bulk updates (head + rest of ldlt_factor): the kernel the roofline is quoted on
+__global__ __launch_bounds__(256, 2) void k_trailing(double *__restrict__ K, long strideK, int ld,
+                                                    const double *__restrict__ Wbuf, long strideW, int Npad,
+                                                    int T, int kp, int nsub, int wslot, int jlo, int jhi,
+                                                    int ntl, int B, const int *__restrict__ phase, int want)
+{
+    schur_update_tile(K, strideK, ld, Wbuf, strideW, Npad, T, kp, nsub, wslot, jlo, jhi, ntl, B, phase, want);
+}
+
+// the rank-64 update of the second tile column of an outer panel (look-ahead stream, not timed)
+__global__ __launch_bounds__(256, 2) void k_colupdate(double *__restrict__ K, long strideK, int ld,
+                                                     const double *__restrict__ Wbuf, long strideW, int Npad,
+                                                     int T, int kp, int nsub, int wslot, int jlo, int jhi,
+                                                     int ntl, int B, const int *__restrict__ phase, int want)
+{
+    schur_update_tile(K, strideK, ld, Wbuf, strideW, Npad, T, kp, nsub, wslot, jlo, jhi, ntl, B, phase, want);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -336,8 +354,12 @@ static void launch_update(const LdltPlan &P, hipStream_t s, double *K, int kp, i
     std::pair<hipEvent_t, hipEvent_t> ev;
     const bool timed = tm && tm->enabled && count;
     if (timed) { ev = tm->get(); hipEventRecord(ev.first, s); }
-    hipLaunchKernelGGL(k_trailing, dim3(ntl * P.B), dim3(256), 0, s, K, strideK, P.ld, P.Wbuf, strideW, P.Npad,
-                       P.T, kp, nsub, wslot, jlo, jhi, ntl, P.B, phase, want);
+    if (count)
+        hipLaunchKernelGGL(k_trailing, dim3(ntl * P.B), dim3(256), 0, s, K, strideK, P.ld, P.Wbuf, strideW, P.Npad,
+                           P.T, kp, nsub, wslot, jlo, jhi, ntl, P.B, phase, want);
+    else
+        hipLaunchKernelGGL(k_colupdate, dim3(ntl * P.B), dim3(256), 0, s, K, strideK, P.ld, P.Wbuf, strideW, P.Npad,
+                           P.T, kp, nsub, wslot, jlo, jhi, ntl, P.B, phase, want);
     if (timed) { hipEventRecord(ev.second, s); tm->pending_trailing.push_back(ev); }
     if (tm && count) tm->trailing_launches++;
 }
