@@ -228,7 +228,7 @@ __global__ __launch_bounds__(TPB) void k_ipm_start(DV d)
     }
     if (threadIdx.x == 0) {
         st.sf = sf; st.soft_w = soft_w; st.hsc = (st.stage == 0 && use_obj) ? sf : 0.0;
-        st.mu = 1.0; st.iter = 0; st.rc = -1; st.dw_last = 0.0; st.dw = 0.0; st.dw_floor = 0.0;
+        st.mu = 1.0; st.iter = 0; st.rc = -1; st.dw_last = 0.0; st.dw = 0.0; st.dw_floor = 0.0; st.n_acc = 0;
         st.cn = 0.0;
         st.start = 0;
         d.phase[inst] = PH_PREP;
@@ -288,10 +288,13 @@ __global__ __launch_bounds__(TPB) void k_ipm_prepare(DV d)
     }
     const double sd = fmax(100.0, dl1 / (double)(d.n + d.m)) / 100.0;
     const double e0 = fmax(fmax(rdn / sd, rpn), cmax / sd);
-    if (e0 <= d.ipm_tol) {
+    // converged, or acceptable: 8 consecutive iterates within 100 x tol
+    const int n_acc = e0 <= 100.0 * d.ipm_tol ? st.n_acc + 1 : 0;
+    if (e0 <= d.ipm_tol || n_acc >= 8) {
         if (threadIdx.x == 0) { st.rc = 0; d.phase[inst] = PH_DONE; }
         return;
     }
+    if (threadIdx.x == 0) st.n_acc = n_acc;
     // barrier update: mu <- max(mu_min, min(0.2 mu, mu^1.5)) while the barrier problem is solved
     double mu = st.mu;
     const double mu_min = d.ipm_tol / 10.0;
