@@ -181,7 +181,7 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
         d.max_iter = opt->max_iter; d.use_soc = opt->use_soc; d.literal_quirks = opt->literal_quirks;
         C.plan.N = d.N; C.plan.Npad = d.Npad; C.plan.T = d.Npad / 64; C.plan.ld = d.ld; C.plan.B = B;
         C.plan.stream = C.stream;
-        C.plan.Wbuf = C.dalloc<double>((size_t)4 * B * d.Npad * 64);
+        C.plan.Wbuf = C.dalloc<double>((size_t)2 * LdltPlan::MAX_R * B * d.Npad * 64);
         C.plan.init_lookahead();
         SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
         return SQPHIP_OK;

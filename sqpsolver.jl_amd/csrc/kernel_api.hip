@@ -42,7 +42,7 @@ struct Scratch {
         P.N = (int)N; P.Npad = (int)((N + 63) / 64 * 64); P.T = P.Npad / 64; P.ld = P.Npad; P.B = B;
         SQPHIP_HIP_OK(hipStreamCreate(&P.stream));
         SQPHIP_HIP_OK(hipMalloc(&K, sizeof(double) * (size_t)B * P.ld * P.Npad));
-        SQPHIP_HIP_OK(hipMalloc(&P.Wbuf, sizeof(double) * (size_t)4 * B * P.Npad * 64));
+        SQPHIP_HIP_OK(hipMalloc(&P.Wbuf, sizeof(double) * (size_t)2 * LdltPlan::MAX_R * B * P.Npad * 64));
         P.init_lookahead();
         SQPHIP_HIP_OK(hipMalloc(&dinv, sizeof(double) * (size_t)B * P.Npad));
         SQPHIP_HIP_OK(hipMalloc(&x, sizeof(double) * (size_t)B * P.Npad));

@@ -150,110 +150,189 @@ __global__ __launch_bounds__(256) void k_panel_trsm(double *__restrict__ K, long
 }
 
 // ---------------------------------------------------------------------------------------------
-// Schur update on fp64 MFMA.  One workgroup (4 waves) per 64x64 tile (ti,tj), tj in [jlo,jhi), ti>=tj:
+// Schur update on fp64 MFMA.  A workgroup (4 waves) owns a run of `tpb` consecutive 64x64 tiles (ti,tj),
+// tj in [jlo,jhi), ti>=tj, in column-major tile order, and for each of them computes
 //   A[ti][tj] -= sum_{t<nsub} W_t[ti] * L[tj][kp+t]'      (nsub 64-wide sub-panels, inner depth 64*nsub)
 // The C tile is read and written ONCE per call whatever nsub is: with the two-level blocking of
-// ldlt_factor (nsub = 2) the bulk update does 16 flops per byte of C traffic instead of 8, which
-// lifts it off the HBM roof.  MFMA operands are arranged so that the accumulator's lane index runs
-// along i (the contiguous direction of the column-major tile): T[jj][ii] = sum_k L[j][k] W[i][k],
-// A-operand = L, B-operand = W.  LDS images are k-major (Ls[k][j], Ws[k][i]) exactly as the columns lie
-// in HBM; an XOR of 16 on the in-row index for odd k puts the two k-rows read by one 32-lane group on
-// disjoint bank halves.
+// ldlt_factor the bulk update does 8*nsub flops per byte of C traffic, which lifts it off the HBM roof.
+// MFMA operands are arranged so that the accumulator's lane index runs along i (the contiguous direction
+// of the column-major tile): T[jj][ii] = sum_k L[j][k] W[i][k], A-operand = L, B-operand = W.  LDS images
+// are k-major (Ls[k][j], Ws[k][i]) exactly as the columns lie in HBM; an XOR of 16 on the in-row index
+// for odd k puts the two k-rows read by one 32-lane group on disjoint bank halves.
+// Pipeline: the operand tiles of step s+1 (the next sub-panel, or sub-panel 0 of the NEXT tile of the run)
+// are fetched into registers while step s is multiplied, so the memory latency of a fetch -- several
+// thousand cycles when the whole chip streams -- is paid once per run, not once per tile (a cycle-stamp
+// trace of the one-tile-per-workgroup version showed 8 k cycles of prologue + 3.5 k of first-fetch wait
+// per 16 k cycles of MFMA work; scripts/probes/trailing_trace.hip).
 __device__ __forceinline__ int swz(int k, int i) { return k * 64 + (i ^ ((k & 1) << 4)); }
 
-__device__ __forceinline__ void schur_update_tile(double *__restrict__ K, long strideK, int ld,
-                                                  const double *__restrict__ Wbuf, long strideW, int Npad,
-                                                  int T, int kp, int nsub, int wslot, int jlo, int jhi,
-                                                  int ntl, int B, const int *__restrict__ phase, int want)
+// cycle stamps of one wave per sampled workgroup (scripts/probes/trailing_trace.hip only)
+#ifdef SQPHIP_TRACE_TRAILING
+__device__ long long g_trace[2048][16];
+__device__ long long g_span[1 << 17][3];    // per workgroup: first stamp, last stamp, (XCC_ID << 32 | HW_ID)
+#define SQPHIP_TR(i)                                                                                  \
+    if (threadIdx.x == 0) {                                                                           \
+        const long long now_ = (long long)__builtin_readcyclecounter();                               \
+        if ((blockIdx.x % 61) == 0 && blockIdx.x / 61 < 2048 && (i) < 16) g_trace[blockIdx.x / 61][i] = now_; \
+        if (blockIdx.x < (1 << 17)) {                                                                 \
+            if ((i) == 0) {                                                                           \
+                g_span[blockIdx.x][0] = now_;                                                         \
+                g_span[blockIdx.x][2] = (long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32 | \
+                                        (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); \
+            }                                                                                         \
+            if ((i) == 15) g_span[blockIdx.x][1] = now_;                                              \
+        }                                                                                             \
+    }
+#else
+#define SQPHIP_TR(i)
+#endif
+
+__device__ __forceinline__ void schur_update_run(double *__restrict__ K, long strideK, int ld,
+                                                 const double *__restrict__ Wbuf, long strideW, int Npad,
+                                                 int T, int kp, int nsub, int wslot, int jlo, int ntl, int tpb,
+                                                 int nrun, int B, const int *__restrict__ phase, int want)
 {
-    int inst, t;
+    int inst, run;
     const int bid = blockIdx.x;
     if ((B & 7) == 0) {             // keep one instance's tiles on one XCD (its panels stay in that L2)
         const int xcd = bid & 7, q = bid >> 3;
-        inst = (q / ntl) * 8 + xcd;
-        t = q % ntl;
+        inst = (q / nrun) * 8 + xcd;
+        run = q % nrun;
     } else {
-        inst = bid / ntl;
-        t = bid % ntl;
+        inst = bid / nrun;
+        run = bid % nrun;
     }
     if (phase && phase[inst] != want) return;
-    // column-major enumeration of the tiles (ti >= tj) of tile columns jlo .. jhi-1
-    int tj = jlo, cnt = T - jlo;
-    while (t >= cnt) { t -= cnt; ++tj; --cnt; }
-    const int ti = tj + t;
+    SQPHIP_TR(0)
+    // column-major enumeration of the tiles (ti >= tj) of tile columns jlo .. : first tile of the run
+    int t = run * tpb;
+    const int tend = t + tpb < ntl ? t + tpb : ntl;
+    int tj = jlo, ti;
+    {
+        int r = t, cnt = T - jlo;
+        while (r >= cnt) { r -= cnt; ++tj; --cnt; }
+        ti = tj + r;
+    }
 
-    __shared__ double Ls[64 * 64];
-    __shared__ double Ws[64 * 64];
+    // two stages of 32 k-columns each: [stage][Ls | Ws][32 x 64]
+    __shared__ double lds[2][2][32 * 64];
     double *Kb = K + (long)inst * strideK;
+    const double *Wb = Wbuf + (long)wslot * strideW + (long)inst * Npad * 64;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int jb = (wave >> 1) * 32, ib = (wave & 1) * 32;
     const int l15 = lane & 15, l4 = lane >> 4;
-    double *Cg = Kb + (long)(tj * 64 + jb) * ld + ti * 64 + ib;
-    // issue the C loads early: acc = C, then acc -= products (negated A operand)
-    d4 acc[2][2];
+    // operand staging: thread moves 2 doubles per column, 32 threads cover a column, 8 columns per pass,
+    // 4 passes per 32-column half of a sub-panel
+    const int ii = (tid & 31) * 2, kk0 = tid >> 5;
+    d2 lv[4], wv[4];
+    // step = 2 * sub + half
+    auto fetch = [&](int ftj, int fti, int step) {
+        const int col = (kp + (step >> 1)) * 64 + (step & 1) * 32;
+        const double *Lg = Kb + (long)col * ld + ftj * 64;                                           // L[tj][kp+sub]
+        const double *Wg = Wb + (long)(step >> 1) * strideW + (long)((step & 1) * 32) * Npad + fti * 64;   // W_sub[ti]
 #pragma unroll
-    for (int bj = 0; bj < 2; ++bj)
-#pragma unroll
-        for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
-                acc[bj][bi][rr] = Cg[(long)(bj * 16 + l4 + 4 * rr) * ld + bi * 16 + l15];
-    for (int sub = 0; sub < nsub; ++sub) {
-        const double *Lg = Kb + (long)((kp + sub) * 64) * ld + tj * 64;                        // L[tj][kp+sub]
-        const double *Wg = Wbuf + (long)(wslot + sub) * strideW + (long)inst * Npad * 64 + ti * 64;   // W_sub[ti]
-        if (sub) __syncthreads();
-        // stage both operand tiles: thread moves 2 doubles per (column) step; 32 threads cover a column
-        {
-            const int ii = (tid & 31) * 2, kk0 = tid >> 5;     // 8 columns per pass
-#pragma unroll
-            for (int pass = 0; pass < 8; ++pass) {
-                const int kk = pass * 8 + kk0;
-                const d2 lv = *reinterpret_cast<const d2 *>(Lg + (long)kk * ld + ii);
-                const d2 wv = *reinterpret_cast<const d2 *>(Wg + (long)kk * Npad + ii);
-                *reinterpret_cast<d2 *>(&Ls[swz(kk, ii)]) = lv;
-                *reinterpret_cast<d2 *>(&Ws[swz(kk, ii)]) = wv;
-            }
+        for (int pass = 0; pass < 4; ++pass) {
+            const int kk = pass * 8 + kk0;
+            lv[pass] = *reinterpret_cast<const d2 *>(Lg + (long)kk * ld + ii);
+            wv[pass] = *reinterpret_cast<const d2 *>(Wg + (long)kk * Npad + ii);
         }
-        __syncthreads();
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int kk = pass * 8 + kk0;
+            *reinterpret_cast<d2 *>(&lds[buf][0][swz(kk, ii)]) = lv[pass];
+            *reinterpret_cast<d2 *>(&lds[buf][1][swz(kk, ii)]) = wv[pass];
+        }
+    };
+    const int nstep = 2 * nsub;
+    fetch(tj, ti, 0);
+    stash(0);
+    if (nstep > 1) fetch(tj, ti, 1);
+    else if (t + 1 < tend) { int ntj = tj, nti = ti + 1; if (nti == T) { ++ntj; nti = ntj; } fetch(ntj, nti, 0); }
+    __syncthreads();
+    SQPHIP_TR(1)
+    int buf = 0;
+    for (; t < tend; ++t) {
+        // the tile after this one
+        int ntj = tj, nti = ti + 1;
+        if (nti == T) { ++ntj; nti = ntj; }
+        double *Cg = Kb + (long)(tj * 64 + jb) * ld + ti * 64 + ib;
+        // C loads are issued now and consumed after the last product (acc starts at zero and the A operand
+        // is negated, so the result is C + acc)
+        d4 cin[2][2], acc[2][2];
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    cin[bj][bi][rr] = Cg[(long)(bj * 16 + l4 + 4 * rr) * ld + bi * 16 + l15];
+                    acc[bj][bi][rr] = 0.0;
+                }
+        for (int step = 0; step < nstep; ++step) {
+            // registers hold (or are receiving) the operands of the step after this one
+            const double *Ls = lds[buf][0], *Ws = lds[buf][1];
 #pragma unroll 4
-        for (int ks = 0; ks < 16; ++ks) {
-            const int kk = ks * 4 + l4;
-            const double a0 = -Ls[swz(kk, jb + l15)];
-            const double a1 = -Ls[swz(kk, jb + 16 + l15)];
-            const double b0 = Ws[swz(kk, ib + l15)];
-            const double b1 = Ws[swz(kk, ib + 16 + l15)];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+            for (int ks = 0; ks < 8; ++ks) {
+                const int kk = ks * 4 + l4;
+                const double a0 = -Ls[swz(kk, jb + l15)];
+                const double a1 = -Ls[swz(kk, jb + 16 + l15)];
+                const double b0 = Ws[swz(kk, ib + l15)];
+                const double b1 = Ws[swz(kk, ib + 16 + l15)];
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            const bool more = step + 1 < nstep || t + 1 < tend;
+            if (more) {
+                stash(buf ^ 1);                 // the other stage: nobody reads it during this step
+                // operands two steps ahead
+                if (step + 2 < nstep) fetch(tj, ti, step + 2);
+                else if (t + 1 < tend) {
+                    const int s2 = step + 2 - nstep;          // 0 or 1 of the next tile
+                    if (s2 < nstep) fetch(ntj, nti, s2);
+                    else if (t + 2 < tend) {                  // nstep == 1: two tiles ahead
+                        int n2j = ntj, n2i = nti + 1;
+                        if (n2i == T) { ++n2j; n2i = n2j; }
+                        fetch(n2j, n2i, 0);
+                    }
+                }
+            }
+            __syncthreads();
+            buf ^= 1;
+            SQPHIP_TR(2 + step + (t + 1 == tend ? 0 : 100))
         }
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+                    Cg[(long)(bj * 16 + l4 + 4 * rr) * ld + bi * 16 + l15] = cin[bj][bi][rr] + acc[bj][bi][rr];
+        tj = ntj; ti = nti;
     }
-#pragma unroll
-    for (int bj = 0; bj < 2; ++bj)
-#pragma unroll
-        for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
-                Cg[(long)(bj * 16 + l4 + 4 * rr) * ld + bi * 16 + l15] = acc[bj][bi][rr];
+    SQPHIP_TR(15)
 }
 
 // the bulk updates (head + rest of ldlt_factor): the kernel the roofline is quoted on
-__global__ __launch_bounds__(256, 2) void k_trailing(double *__restrict__ K, long strideK, int ld,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_trailing(double *__restrict__ K, long strideK, int ld,
                                                     const double *__restrict__ Wbuf, long strideW, int Npad,
-                                                    int T, int kp, int nsub, int wslot, int jlo, int jhi,
-                                                    int ntl, int B, const int *__restrict__ phase, int want)
+                                                    int T, int kp, int nsub, int wslot, int jlo, int ntl, int tpb,
+                                                    int nrun, int B, const int *__restrict__ phase, int want)
 {
-    schur_update_tile(K, strideK, ld, Wbuf, strideW, Npad, T, kp, nsub, wslot, jlo, jhi, ntl, B, phase, want);
+    schur_update_run(K, strideK, ld, Wbuf, strideW, Npad, T, kp, nsub, wslot, jlo, ntl, tpb, nrun, B, phase, want);
 }
 
-// the rank-64 update of the second tile column of an outer panel (look-ahead stream, not timed)
+// the rank-64 updates inside an outer panel (look-ahead stream, not timed)
 __global__ __launch_bounds__(256, 2) void k_colupdate(double *__restrict__ K, long strideK, int ld,
                                                      const double *__restrict__ Wbuf, long strideW, int Npad,
-                                                     int T, int kp, int nsub, int wslot, int jlo, int jhi,
-                                                     int ntl, int B, const int *__restrict__ phase, int want)
+                                                     int T, int kp, int nsub, int wslot, int jlo, int ntl, int tpb,
+                                                     int nrun, int B, const int *__restrict__ phase, int want)
 {
-    schur_update_tile(K, strideK, ld, Wbuf, strideW, Npad, T, kp, nsub, wslot, jlo, jhi, ntl, B, phase, want);
+    schur_update_run(K, strideK, ld, Wbuf, strideW, Npad, T, kp, nsub, wslot, jlo, ntl, tpb, nrun, B, phase, want);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -350,16 +429,21 @@ static void launch_update(const LdltPlan &P, hipStream_t s, double *K, int kp, i
     if (jhi > P.T) jhi = P.T;
     if (jlo >= jhi) return;
     const int ntl = tiles_in_cols(P.T, jlo, jhi);
+    // tiles per workgroup: long runs amortise the pipeline fill, but keep >= ~4 workgroups per CU slot
+    int tpb = (int)((long)ntl * P.B / 2048);
+    if (tpb > P.tpb_max) tpb = P.tpb_max;
+    if (tpb < 1) tpb = 1;
+    const int nrun = (ntl + tpb - 1) / tpb;
     const long strideK = (long)P.ld * P.Npad, strideW = (long)P.B * P.Npad * 64;
     std::pair<hipEvent_t, hipEvent_t> ev;
     const bool timed = tm && tm->enabled && count;
     if (timed) { ev = tm->get(); hipEventRecord(ev.first, s); }
     if (count)
-        hipLaunchKernelGGL(k_trailing, dim3(ntl * P.B), dim3(256), 0, s, K, strideK, P.ld, P.Wbuf, strideW, P.Npad,
-                           P.T, kp, nsub, wslot, jlo, jhi, ntl, P.B, phase, want);
+        hipLaunchKernelGGL(k_trailing, dim3(nrun * P.B), dim3(256), 0, s, K, strideK, P.ld, P.Wbuf, strideW, P.Npad,
+                           P.T, kp, nsub, wslot, jlo, ntl, tpb, nrun, P.B, phase, want);
     else
-        hipLaunchKernelGGL(k_colupdate, dim3(ntl * P.B), dim3(256), 0, s, K, strideK, P.ld, P.Wbuf, strideW, P.Npad,
-                           P.T, kp, nsub, wslot, jlo, jhi, ntl, P.B, phase, want);
+        hipLaunchKernelGGL(k_colupdate, dim3(nrun * P.B), dim3(256), 0, s, K, strideK, P.ld, P.Wbuf, strideW, P.Npad,
+                           P.T, kp, nsub, wslot, jlo, ntl, tpb, nrun, P.B, phase, want);
     if (timed) { hipEventRecord(ev.second, s); tm->pending_trailing.push_back(ev); }
     if (tm && count) tm->trailing_launches++;
 }
@@ -375,34 +459,34 @@ static void launch_panel(const LdltPlan &P, hipStream_t s, double *K, double *di
                            P.Wbuf + (long)wslot * strideW, P.Npad, c, phase, want);
 }
 
-// Two-level right-looking LDL^T: outer panels of two 64-wide sub-panels, so every pass over the
-// trailing matrix applies a rank-128 update.  Look-ahead: the update is split into the "head" (the two
+// Two-level right-looking LDL^T: outer panels of R 64-wide sub-panels, so every pass over the
+// trailing matrix applies a rank-64R update.  Look-ahead: the update is split into the "head" (the R
 // tile columns of the next outer panel) and the "rest"; the latency-bound factorisation of the next
 // panel runs on the auxiliary stream while the main stream streams the rest through the MFMA kernel.
-// W = L D of the current outer panel lives in Wbuf slots {0,1} or {2,3} by panel parity.
+// W = L D of the current outer panel lives in Wbuf slots [0,R) or [MAX_R, MAX_R+R) by panel parity.
 void ldlt_factor(const LdltPlan &P, double *K, double *dinv, const int *phase, int want, Timers *tm)
 {
     hipStream_t sA = P.stream, sB = P.aux ? P.aux : P.stream;
-    const int T = P.T;
-    const int nq = (T + 1) / 2;
+    const int T = P.T, R = P.R;
+    const int nq = (T + R - 1) / R;
     hipEvent_t evStart = P.ev[0];
     if (sB != sA) { hipEventRecord(evStart, sA); hipStreamWaitEvent(sB, evStart, 0); }
     for (int q = 0; q < nq; ++q) {
-        const int c0 = 2 * q, c1 = c0 + 1, slot = (q & 1) * 2;
-        const int nsub = c1 < T ? 2 : 1;
+        const int c0 = R * q, slot = (q & 1) * LdltPlan::MAX_R;
+        const int nsub = c0 + R <= T ? R : T - c0;
         hipEvent_t evPanel = P.ev[1 + (q & 1)], evHead = P.ev[3 + (q & 1)];
-        // ---- stream B: factor the outer panel
-        launch_panel(P, sB, K, dinv, c0, slot, phase, want);
-        if (nsub == 2) {
-            launch_update(P, sB, K, c0, 1, slot, c1, c1 + 1, phase, want, tm, false);   // tile column c1 <- sub-panel c0
-            launch_panel(P, sB, K, dinv, c1, slot + 1, phase, want);
+        // ---- stream B: factor the outer panel, sub-panel by sub-panel; sub-panel j then updates the
+        //      remaining tile columns of the outer panel (rank 64)
+        for (int j = 0; j < nsub; ++j) {
+            launch_panel(P, sB, K, dinv, c0 + j, slot + j, phase, want);
+            launch_update(P, sB, K, c0 + j, 1, slot + j, c0 + j + 1, c0 + nsub, phase, want, tm, false);
         }
         if (c0 + nsub >= T) break;
         if (sB != sA) { hipEventRecord(evPanel, sB); hipStreamWaitEvent(sA, evPanel, 0); }
-        // ---- stream A: head (next panel's two tile columns), then the rest
-        launch_update(P, sA, K, c0, nsub, slot, c0 + 2, c0 + 4, phase, want, tm, true);
+        // ---- stream A: head (the next panel's tile columns), then the rest
+        launch_update(P, sA, K, c0, nsub, slot, c0 + R, c0 + 2 * R, phase, want, tm, true);
         if (sB != sA) { hipEventRecord(evHead, sA); hipStreamWaitEvent(sB, evHead, 0); }
-        launch_update(P, sA, K, c0, nsub, slot, c0 + 4, T, phase, want, tm, true);
+        launch_update(P, sA, K, c0, nsub, slot, c0 + 2 * R, T, phase, want, tm, true);
     }
     if (sB != sA) { hipEventRecord(P.ev[5], sB); hipStreamWaitEvent(sA, P.ev[5], 0); }
     if (tm) tm->n_factor++;

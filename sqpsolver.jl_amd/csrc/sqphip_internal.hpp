@@ -51,13 +51,27 @@ struct Timers {
 
 struct LdltPlan {
     int N = 0, Npad = 0, T = 0, ld = 0, B = 0;
-    double *Wbuf = nullptr;     // 4 slots of [B][64][Npad] : W = L D of the sub-panels of two outer panels
+    int R = 4;                  // 64-wide sub-panels per outer panel: the trailing update has rank 64 R
+    static constexpr int MAX_R = 4;
+    double *Wbuf = nullptr;     // 2 MAX_R slots of [B][64][Npad] : W = L D of the sub-panels of two outer panels
     hipStream_t stream = nullptr;   // main stream (everything but the panel look-ahead)
     hipStream_t aux = nullptr;      // panel factorisation of the next outer panel
     hipEvent_t ev[6] = {};          // start, panel[2], head[2], join
+    int tpb_max = 1;            // longest run of tiles one Schur-update workgroup takes (SQPHIP_TPB): runs of 8
+                                // speed the bulk kernel up by 10 % but starve the look-ahead panel chain of CU
+                                // slots; 1 gives the shortest whole factorisation (measured, N = 2813, B = 64)
     void init_lookahead()
     {
-        if (!getenv("SQPHIP_NO_LOOKAHEAD")) hipStreamCreateWithFlags(&aux, hipStreamNonBlocking);
+        // the panel chain is latency-critical and shares the chip with the bulk update: give its stream the
+        // highest queue priority so its workgroups take the first CU slots that free up
+        if (!getenv("SQPHIP_NO_LOOKAHEAD")) {
+            int least = 0, greatest = 0;
+            hipDeviceGetStreamPriorityRange(&least, &greatest);
+            if (getenv("SQPHIP_NO_PRIORITY")) greatest = least;
+            hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, greatest);
+        }
+        if (const char *e = getenv("SQPHIP_OUTER")) { R = atoi(e); if (R < 1) R = 1; if (R > MAX_R) R = MAX_R; }
+        if (const char *e = getenv("SQPHIP_TPB")) { tpb_max = atoi(e); if (tpb_max < 1) tpb_max = 1; }
         for (auto &e : ev) hipEventCreateWithFlags(&e, hipEventDisableTiming);
     }
     void destroy_lookahead()
