@@ -597,6 +597,7 @@ static int ipm_run(ora_qp *q, const double *p_start)
     const double mu_min = tol / 10.0;
     double mu = 1.0;
     int n_acc = 0;
+    double dw_prev = 0.0;
     int verbose = getenv("ORA_IPM_VERBOSE") != NULL;
     for (int it = 0; it < q->opt.ipm_max_iter; ++it) {
         ipm_meas ms;
@@ -638,7 +639,9 @@ static int ipm_run(ora_qp *q, const double *p_start)
          * inaccurate.  Steps are the fraction-to-boundary lengths (primal and dual separately). */
         double dw = 0.0, alpha = 0.0, a_d = 0.0, relres = 0.0;
         int ok = 0;
-        double dw_floor = 0.0;
+        /* if the previous iteration of this solve needed an inertia correction, the zero trial is skipped
+         * and a third of that correction is tried first (it decays geometrically while it keeps working) */
+        double dw_floor = dw_prev > 3e-10 ? fmax(1e-20, dw_prev / 3.0) : 0.0;
         for (int attempt = 0; attempt < 12 && !ok; ++attempt) {
             if (kkt_factor(q, dw_floor, &dw) != 0) break;
             relres = ipm_direction(q, dw, mu, rd, rp);
@@ -651,6 +654,7 @@ static int ipm_run(ora_qp *q, const double *p_start)
             if (dw_floor > 1e20) break;
         }
         if (!ok) { rc = 2; break; }
+        dw_prev = dw;
         for (int64_t j = 0; j < n; ++j) {
             q->p[j] = nudge_inside(q->p[j] + alpha * q->dp[j], q->lb[j], q->ub[j]);
             q->zl[j] += a_d * q->dzl[j];

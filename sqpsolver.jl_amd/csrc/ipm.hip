@@ -321,7 +321,10 @@ __global__ __launch_bounds__(TPB) void k_ipm_prepare(DV d)
     if (threadIdx.x == 0) {
         st.mu = mu; st.tau = fmax(0.99, 1.0 - mu); st.e0 = e0;
         st.ipm_iters++;
-        st.dw = 0.0; st.dw_floor = 0.0; st.fac_attempt = 0; st.dir_attempt = 0;
+        // st.dw still holds the correction the previous iteration of this solve ended with: if it needed one,
+        // skip the zero trial and start from a third of it
+        const double keep = st.dw > 3e-10 ? fmax(1e-20, st.dw / 3.0) : 0.0;
+        st.dw = keep; st.dw_floor = keep; st.fac_attempt = 0; st.dir_attempt = 0;
         d.phase[inst] = PH_FACTOR;
     }
 }

@@ -187,11 +187,15 @@ __device__ long long g_span[1 << 17][3];    // per workgroup: first stamp, last 
 #define SQPHIP_TR(i)
 #endif
 
+// KC = k-columns per LDS stage (two stages): 32 -> 64 KB of LDS, two workgroups per CU; 16 -> 32 KB, up to four.
+template <int KC>
 __device__ __forceinline__ void schur_update_run(double *__restrict__ K, long strideK, int ld,
                                                  const double *__restrict__ Wbuf, long strideW, int Npad,
                                                  int T, int kp, int nsub, int wslot, int jlo, int ntl, int tpb,
                                                  int nrun, int B, const int *__restrict__ phase, int want)
 {
+    constexpr int SPS = 64 / KC;            // stages per 64-wide sub-panel
+    constexpr int NP = KC / 8;              // staging passes: 8 columns per pass
     int inst, run;
     const int bid = blockIdx.x;
     if ((B & 7) == 0) {             // keep one instance's tiles on one XCD (its panels stay in that L2)
@@ -214,25 +218,23 @@ __device__ __forceinline__ void schur_update_run(double *__restrict__ K, long st
         ti = tj + r;
     }
 
-    // two stages of 32 k-columns each: [stage][Ls | Ws][32 x 64]
-    __shared__ double lds[2][2][32 * 64];
+    // two stages of KC k-columns each: [stage][Ls | Ws][KC x 64]
+    __shared__ double lds[2][2][KC * 64];
     double *Kb = K + (long)inst * strideK;
     const double *Wb = Wbuf + (long)wslot * strideW + (long)inst * Npad * 64;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int jb = (wave >> 1) * 32, ib = (wave & 1) * 32;
     const int l15 = lane & 15, l4 = lane >> 4;
-    // operand staging: thread moves 2 doubles per column, 32 threads cover a column, 8 columns per pass,
-    // 4 passes per 32-column half of a sub-panel
+    // operand staging: thread moves 2 doubles per column, 32 threads cover a column, 8 columns per pass
     const int ii = (tid & 31) * 2, kk0 = tid >> 5;
-    d2 lv[4], wv[4];
-    // step = 2 * sub + half
+    d2 lv[NP], wv[NP];
     auto fetch = [&](int ftj, int fti, int step) {
-        const int col = (kp + (step >> 1)) * 64 + (step & 1) * 32;
-        const double *Lg = Kb + (long)col * ld + ftj * 64;                                           // L[tj][kp+sub]
-        const double *Wg = Wb + (long)(step >> 1) * strideW + (long)((step & 1) * 32) * Npad + fti * 64;   // W_sub[ti]
+        const int sub = step / SPS, off = (step % SPS) * KC;
+        const double *Lg = Kb + (long)((kp + sub) * 64 + off) * ld + ftj * 64;              // L[tj][kp+sub]
+        const double *Wg = Wb + (long)sub * strideW + (long)off * Npad + fti * 64;          // W_sub[ti]
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
+        for (int pass = 0; pass < NP; ++pass) {
             const int kk = pass * 8 + kk0;
             lv[pass] = *reinterpret_cast<const d2 *>(Lg + (long)kk * ld + ii);
             wv[pass] = *reinterpret_cast<const d2 *>(Wg + (long)kk * Npad + ii);
@@ -240,17 +242,16 @@ __device__ __forceinline__ void schur_update_run(double *__restrict__ K, long st
     };
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
+        for (int pass = 0; pass < NP; ++pass) {
             const int kk = pass * 8 + kk0;
             *reinterpret_cast<d2 *>(&lds[buf][0][swz(kk, ii)]) = lv[pass];
             *reinterpret_cast<d2 *>(&lds[buf][1][swz(kk, ii)]) = wv[pass];
         }
     };
-    const int nstep = 2 * nsub;
+    const int nstep = SPS * nsub;           // >= 2
     fetch(tj, ti, 0);
     stash(0);
-    if (nstep > 1) fetch(tj, ti, 1);
-    else if (t + 1 < tend) { int ntj = tj, nti = ti + 1; if (nti == T) { ++ntj; nti = ntj; } fetch(ntj, nti, 0); }
+    fetch(tj, ti, 1);
     __syncthreads();
     SQPHIP_TR(1)
     int buf = 0;
@@ -259,23 +260,20 @@ __device__ __forceinline__ void schur_update_run(double *__restrict__ K, long st
         int ntj = tj, nti = ti + 1;
         if (nti == T) { ++ntj; nti = ntj; }
         double *Cg = Kb + (long)(tj * 64 + jb) * ld + ti * 64 + ib;
-        // C loads are issued now and consumed after the last product (acc starts at zero and the A operand
-        // is negated, so the result is C + acc)
-        d4 cin[2][2], acc[2][2];
+        // acc = C, then acc -= products (negated A operand)
+        d4 acc[2][2];
 #pragma unroll
         for (int bj = 0; bj < 2; ++bj)
 #pragma unroll
             for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    cin[bj][bi][rr] = Cg[(long)(bj * 16 + l4 + 4 * rr) * ld + bi * 16 + l15];
-                    acc[bj][bi][rr] = 0.0;
-                }
+                for (int rr = 0; rr < 4; ++rr)
+                    acc[bj][bi][rr] = Cg[(long)(bj * 16 + l4 + 4 * rr) * ld + bi * 16 + l15];
         for (int step = 0; step < nstep; ++step) {
             // registers hold (or are receiving) the operands of the step after this one
             const double *Ls = lds[buf][0], *Ws = lds[buf][1];
 #pragma unroll 4
-            for (int ks = 0; ks < 8; ++ks) {
+            for (int ks = 0; ks < KC / 4; ++ks) {
                 const int kk = ks * 4 + l4;
                 const double a0 = -Ls[swz(kk, jb + l15)];
                 const double a1 = -Ls[swz(kk, jb + 16 + l15)];
@@ -286,20 +284,11 @@ __device__ __forceinline__ void schur_update_run(double *__restrict__ K, long st
                 acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
             }
-            const bool more = step + 1 < nstep || t + 1 < tend;
-            if (more) {
+            if (step + 1 < nstep || t + 1 < tend) {
                 stash(buf ^ 1);                 // the other stage: nobody reads it during this step
                 // operands two steps ahead
                 if (step + 2 < nstep) fetch(tj, ti, step + 2);
-                else if (t + 1 < tend) {
-                    const int s2 = step + 2 - nstep;          // 0 or 1 of the next tile
-                    if (s2 < nstep) fetch(ntj, nti, s2);
-                    else if (t + 2 < tend) {                  // nstep == 1: two tiles ahead
-                        int n2j = ntj, n2i = nti + 1;
-                        if (n2i == T) { ++n2j; n2i = n2j; }
-                        fetch(n2j, n2i, 0);
-                    }
-                }
+                else if (t + 1 < tend) fetch(ntj, nti, step + 2 - nstep);
             }
             __syncthreads();
             buf ^= 1;
@@ -311,28 +300,30 @@ __device__ __forceinline__ void schur_update_run(double *__restrict__ K, long st
             for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr)
-                    Cg[(long)(bj * 16 + l4 + 4 * rr) * ld + bi * 16 + l15] = cin[bj][bi][rr] + acc[bj][bi][rr];
+                    Cg[(long)(bj * 16 + l4 + 4 * rr) * ld + bi * 16 + l15] = acc[bj][bi][rr];
         tj = ntj; ti = nti;
     }
     SQPHIP_TR(15)
 }
 
 // the bulk updates (head + rest of ldlt_factor): the kernel the roofline is quoted on
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_trailing(double *__restrict__ K, long strideK, int ld,
+template <int KC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_trailing(double *__restrict__ K, long strideK, int ld,
                                                     const double *__restrict__ Wbuf, long strideW, int Npad,
                                                     int T, int kp, int nsub, int wslot, int jlo, int ntl, int tpb,
                                                     int nrun, int B, const int *__restrict__ phase, int want)
 {
-    schur_update_run(K, strideK, ld, Wbuf, strideW, Npad, T, kp, nsub, wslot, jlo, ntl, tpb, nrun, B, phase, want);
+    schur_update_run<KC>(K, strideK, ld, Wbuf, strideW, Npad, T, kp, nsub, wslot, jlo, ntl, tpb, nrun, B, phase, want);
 }
 
-// the rank-64 updates inside an outer panel (look-ahead stream, not timed)
-__global__ __launch_bounds__(256, 2) void k_colupdate(double *__restrict__ K, long strideK, int ld,
+// the left-looking updates inside an outer panel (look-ahead stream, not timed)
+template <int KC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_colupdate(double *__restrict__ K, long strideK, int ld,
                                                      const double *__restrict__ Wbuf, long strideW, int Npad,
                                                      int T, int kp, int nsub, int wslot, int jlo, int ntl, int tpb,
                                                      int nrun, int B, const int *__restrict__ phase, int want)
 {
-    schur_update_run(K, strideK, ld, Wbuf, strideW, Npad, T, kp, nsub, wslot, jlo, ntl, tpb, nrun, B, phase, want);
+    schur_update_run<KC>(K, strideK, ld, Wbuf, strideW, Npad, T, kp, nsub, wslot, jlo, ntl, tpb, nrun, B, phase, want);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -438,11 +429,17 @@ static void launch_update(const LdltPlan &P, hipStream_t s, double *K, int kp, i
     std::pair<hipEvent_t, hipEvent_t> ev;
     const bool timed = tm && tm->enabled && count;
     if (timed) { ev = tm->get(); hipEventRecord(ev.first, s); }
-    if (count)
-        hipLaunchKernelGGL(k_trailing, dim3(nrun * P.B), dim3(256), 0, s, K, strideK, P.ld, P.Wbuf, strideW, P.Npad,
+    if (count && P.kc == 16)
+        hipLaunchKernelGGL(k_trailing<16>, dim3(nrun * P.B), dim3(256), 0, s, K, strideK, P.ld, P.Wbuf, strideW, P.Npad,
+                           P.T, kp, nsub, wslot, jlo, ntl, tpb, nrun, P.B, phase, want);
+    else if (count)
+        hipLaunchKernelGGL(k_trailing<32>, dim3(nrun * P.B), dim3(256), 0, s, K, strideK, P.ld, P.Wbuf, strideW, P.Npad,
+                           P.T, kp, nsub, wslot, jlo, ntl, tpb, nrun, P.B, phase, want);
+    else if (P.kc == 16)
+        hipLaunchKernelGGL(k_colupdate<16>, dim3(nrun * P.B), dim3(256), 0, s, K, strideK, P.ld, P.Wbuf, strideW, P.Npad,
                            P.T, kp, nsub, wslot, jlo, ntl, tpb, nrun, P.B, phase, want);
     else
-        hipLaunchKernelGGL(k_colupdate, dim3(nrun * P.B), dim3(256), 0, s, K, strideK, P.ld, P.Wbuf, strideW, P.Npad,
+        hipLaunchKernelGGL(k_colupdate<32>, dim3(nrun * P.B), dim3(256), 0, s, K, strideK, P.ld, P.Wbuf, strideW, P.Npad,
                            P.T, kp, nsub, wslot, jlo, ntl, tpb, nrun, P.B, phase, want);
     if (timed) { hipEventRecord(ev.second, s); tm->pending_trailing.push_back(ev); }
     if (tm && count) tm->trailing_launches++;
@@ -475,11 +472,12 @@ void ldlt_factor(const LdltPlan &P, double *K, double *dinv, const int *phase, i
         const int c0 = R * q, slot = (q & 1) * LdltPlan::MAX_R;
         const int nsub = c0 + R <= T ? R : T - c0;
         hipEvent_t evPanel = P.ev[1 + (q & 1)], evHead = P.ev[3 + (q & 1)];
-        // ---- stream B: factor the outer panel, sub-panel by sub-panel; sub-panel j then updates the
-        //      remaining tile columns of the outer panel (rank 64)
+        // ---- stream B: factor the outer panel, sub-panel by sub-panel, left-looking inside the panel: tile
+        //      column c0+j first receives the rank-64j update of sub-panels 0..j-1 in ONE pass (each in-panel
+        //      column is read and written once; right-looking rank-64 updates cost twice the HBM traffic)
         for (int j = 0; j < nsub; ++j) {
+            if (j) launch_update(P, sB, K, c0, j, slot, c0 + j, c0 + j + 1, phase, want, tm, false);
             launch_panel(P, sB, K, dinv, c0 + j, slot + j, phase, want);
-            launch_update(P, sB, K, c0 + j, 1, slot + j, c0 + j + 1, c0 + nsub, phase, want, tm, false);
         }
         if (c0 + nsub >= T) break;
         if (sB != sA) { hipEventRecord(evPanel, sB); hipStreamWaitEvent(sA, evPanel, 0); }
