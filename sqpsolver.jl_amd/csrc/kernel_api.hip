@@ -179,23 +179,23 @@ extern "C" int sqphip_ldlt_bench(int32_t device, int32_t batch, int64_t N, int32
 }
 
 // ---------------------------------------------------------------------------------------------
-// fp64 MFMA issue-rate probe: every wave runs `iters` x 8 independent v_mfma_f64_16x16x4_f64 from
+// fp64 MFMA issue-rate probe: every wave runs `iters` x 4 independent v_mfma_f64_16x16x4_f64 from
 // registers (no memory traffic).  Gives the on-box ceiling the LDL^T roofline is quoted against.
 namespace {
 typedef double d4v __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void k_mfma_f64_probe(double *out, int iters)
+__global__ __launch_bounds__(1024) void k_mfma_f64_probe(double *out, int iters)
 {
-    d4v acc[8];
-    const double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+    d4v acc[4];
+    const double a = 1e-3 * threadIdx.x, b = 1e-3;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = d4v{0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < 4; ++i) acc[i] = d4v{0.0, 0.0, 0.0, 0.0};
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
     }
     double s = 0.0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 }  // namespace
@@ -204,7 +204,7 @@ extern "C" int sqphip_mfma_f64_peak(int32_t device, double *tflops)
 {
     try {
         SQPHIP_HIP_OK(hipSetDevice(device));
-        const int blocks = 256 * 8, threads = 256, iters = 20000;
+        const int blocks = 256, threads = 1024, iters = 80000;   // 4 waves per SIMD, 4 chains per wave
         double *out;
         SQPHIP_HIP_OK(hipMalloc(&out, sizeof(double) * blocks * threads));
         hipEvent_t e0, e1;
@@ -216,7 +216,7 @@ extern "C" int sqphip_mfma_f64_peak(int32_t device, double *tflops)
         SQPHIP_HIP_OK(hipEventSynchronize(e1));
         float ms = 0.f;
         hipEventElapsedTime(&ms, e0, e1);
-        const double flops = (double)blocks * (threads / 64) * (double)iters * 8.0 * 2.0 * 16 * 16 * 4;
+        const double flops = (double)blocks * (threads / 64) * (double)iters * 4.0 * 2.0 * 16 * 16 * 4;
         *tflops = flops / (1e-3 * ms) / 1e12;
         hipEventDestroy(e0); hipEventDestroy(e1);
         hipFree(out);

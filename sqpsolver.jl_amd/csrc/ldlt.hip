@@ -364,45 +364,55 @@ __global__ __launch_bounds__(64) void k_fwd_step(const double *__restrict__ K, l
     xb[i * 64 + r] -= acc;
 }
 
-// backward substitution L' x = v, step k (descending).  Workgroup j<=k re-solves the 64x64
-// unit-upper system of tile (k,k)'; j==k publishes x_k, j<k updates v_j -= L_kj' x_k.
-__global__ __launch_bounds__(64) void k_bwd_step(const double *__restrict__ K, long strideK, int ld,
-                                                double *__restrict__ x, double *__restrict__ v,
-                                                int Npad, int k, const int *__restrict__ phase, int want)
+// backward substitution L' x = v, step k (descending).  Workgroup j<=k re-solves the 64x64 unit-upper
+// system of tile (k,k)' (wave 0; the tile is staged transposed-readable in LDS by all four waves);
+// j==k publishes x_k, j<k updates v_j -= L_kj' x_k: tile (k,j) is fetched into registers during the
+// diagonal solve, transposed through the same LDS buffer, and the row range of the product is split over
+// the waves.
+__global__ __launch_bounds__(256) void k_bwd_step(const double *__restrict__ K, long strideK, int ld,
+                                                 double *__restrict__ x, double *__restrict__ v,
+                                                 int Npad, int k, const int *__restrict__ phase, int want)
 {
     const int inst = blockIdx.y;
     if (phase && phase[inst] != want) return;
     const int j = blockIdx.x;
-    const int c = threadIdx.x;
+    const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
     const double *Kb = K + (long)inst * strideK;
     const double *Lkk = Kb + (long)(k * 64) * ld + k * 64;
     double *vb = v + (long)inst * Npad;
     __shared__ double tile[64 * 65];
     __shared__ double xs[64];
-    // stage tile (k,k) transposed-readable: tile[cc*65 + rr] = L[rr][cc]
-#pragma unroll 8
-    for (int cc = 0; cc < 64; ++cc) tile[cc * 65 + c] = Lkk[(long)cc * ld + c];
-    __syncthreads();
-    double xc = vb[k * 64 + c];
-    for (int rr = 63; rr > 0; --rr) {
-        const double xr = __shfl(xc, rr);
-        if (c < rr) xc -= tile[c * 65 + rr] * xr;
+    __shared__ double part[4][64];
+    // stage tile (k,k) transposed-readable: tile[cc*65 + rr] = L[rr][cc]; wave w moves columns 16w..16w+15
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) tile[(w * 16 + cc) * 65 + c] = Lkk[(long)(w * 16 + cc) * ld + c];
+    double lt[16];
+    if (j != k) {
+        const double *Lkj = Kb + (long)(j * 64 + w * 16) * ld + k * 64 + c;   // tile (k,j): rows k-block, cols j-block
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) lt[cc] = Lkj[(long)cc * ld];
     }
-    if (j == k) {
-        x[(long)inst * Npad + k * 64 + c] = xc;
-        return;
+    __syncthreads();
+    if (w == 0) {
+        double xc = vb[k * 64 + c];
+        for (int rr = 63; rr > 0; --rr) {
+            const double xr = __shfl(xc, rr);
+            if (c < rr) xc -= tile[c * 65 + rr] * xr;
+        }
+        if (j == k) x[(long)inst * Npad + k * 64 + c] = xc;
+        xs[c] = xc;
     }
-    xs[c] = xc;
+    if (j == k) return;
     __syncthreads();
-    const double *Lkj = Kb + (long)(j * 64) * ld + k * 64;   // tile (k,j): rows k-block, cols j-block
-    __syncthreads();
-#pragma unroll 8
-    for (int cc = 0; cc < 64; ++cc) tile[cc * 65 + c] = Lkj[(long)cc * ld + c];
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) tile[(w * 16 + cc) * 65 + c] = lt[cc];
     __syncthreads();
     double acc = 0.0;
-#pragma unroll 16
-    for (int rr = 0; rr < 64; ++rr) acc += tile[c * 65 + rr] * xs[rr];
-    vb[j * 64 + c] -= acc;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) acc += tile[c * 65 + w * 16 + rr] * xs[w * 16 + rr];
+    part[w][c] = acc;
+    __syncthreads();
+    if (w == 0) vb[j * 64 + c] -= (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -499,7 +509,7 @@ void ldlt_solve(const LdltPlan &P, const double *K, const double *dinv, double *
         hipLaunchKernelGGL(k_fwd_step, dim3(P.T - k, P.B), dim3(64), 0, s, K, strideK, P.ld, dinv, x, v,
                            P.Npad, k, phase, want);
     for (int k = P.T - 1; k >= 0; --k)
-        hipLaunchKernelGGL(k_bwd_step, dim3(k + 1, P.B), dim3(64), 0, s, K, strideK, P.ld, x, v, P.Npad, k,
+        hipLaunchKernelGGL(k_bwd_step, dim3(k + 1, P.B), dim3(256), 0, s, K, strideK, P.ld, x, v, P.Npad, k,
                            phase, want);
 }
 
