@@ -23,8 +23,8 @@ import time
 _ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, _ROOT)
 
-FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet fp64 matrix peak; MI355X_MICROARCH.md has no fp64 row.
-                               # bench prints the on-box register-resident MFMA probe next to it.
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet fp64 matrix peak; MI355X_MICROARCH.md has no fp64 row.  The on-box
+                               # register-resident MFMA probe (printed next to it) sustains 77.6 of it.
 
 
 def outer_width() -> int:
@@ -37,7 +37,7 @@ def trailing_alg_flops(N: int, R: int | None = None) -> float:
     outer panels of R 64-wide sub-panels (ldlt.hip, ldlt_factor); after an outer panel the lower
     triangle (incl. diagonal) of the matrix right of the panel receives a rank-64R update, 2 flops per
     multiply-add.  (The rank-64 updates inside an outer panel run on the look-ahead stream and are
-    neither timed nor counted.)  N = 2813, R = 2: 6.92 of the 7.42 GFLOP of N^3/3."""
+    neither timed nor counted.)  N = 2813: 6.46 (R = 4, the default) or 6.95 (R = 2) of the 7.42 GFLOP of N^3/3."""
     R = R or outer_width()
     T = (N + 63) // 64
     tot = 0.0
@@ -59,7 +59,7 @@ def main():
     ap.add_argument("--groups", type=int, default=1,
                     help="instance groups per GPU, each a context with its own HIP stream pair, driven "
                          "concurrently so that the latency-bound panel / solve phases of one group "
-                         "overlap the MFMA-bound updates of another (2 gives about +8 % QP/s on MI355X but the "
+                         "overlap the MFMA-bound updates of another (2 gives about +5 % QP/s on MI355X but the "
                          "HIP-event kernel timing then includes queueing behind the other group, so the "
                          "default keeps one group and a clean roofline measurement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

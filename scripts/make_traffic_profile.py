@@ -1,0 +1,37 @@
+"""Post-process scripts/gpu_profile_bench.sh output: per-kernel HBM traffic per launch (FETCH_SIZE doubled per the
+gfx950 correction of MI355X_MICROARCH.md, KiB -> bytes) and a copy of the kernel stats.  python make_traffic_profile.py DIR TAG"""
+import csv, glob, json, os, shutil, sys, collections
+root, tag = sys.argv[1], sys.argv[2]
+
+def per_kernel(sub, counter):
+    tot = collections.defaultdict(float); n = collections.defaultdict(set)
+    for f in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            tot[k] += float(r["Counter_Value"]); n[k].add(r["Dispatch_Id"])
+    return {k: (tot[k], len(n[k])) for k in tot}
+
+fe, wr = per_kernel("fetch", "FETCH_SIZE"), per_kernel("write", "WRITE_SIZE")
+out = {}
+for k in sorted(set(fe) | set(wr)):
+    if not k.startswith("sqphip::"):
+        continue
+    f, nf = fe.get(k, (0.0, 0)); w, nw = wr.get(k, (0.0, 0))
+    out[k] = {"dispatches": nf or nw,
+              "fetch_bytes_per_launch_corrected": 2.0 * 1024.0 * f / max(1, nf),
+              "write_bytes_per_launch": 1024.0 * w / max(1, nw)}
+json.dump(out, open(os.path.join(root, f"{tag}_pmc_traffic_batch64.json"), "w"), indent=1)
+tr = next((v for k, v in out.items() if "k_trailing" in k), None)
+if tr:
+    json.dump({"kernel": "k_trailing<16>", "hbm_bytes_per_launch": tr["fetch_bytes_per_launch_corrected"] + tr["write_bytes_per_launch"],
+               "fetch_bytes_per_launch": tr["fetch_bytes_per_launch_corrected"], "write_bytes_per_launch": tr["write_bytes_per_launch"],
+               "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, bench.py --steps 1 --warmup 0 (64 instances, one group); "
+                      "KiB -> bytes; FETCH_SIZE doubled (gfx950 wide-read correction, MI355X_MICROARCH.md HBM section); average over the "
+                      "k_trailing dispatches of the run (scripts/gpu_profile_bench.sh)"},
+              open(os.path.join(root, "trailing_traffic.json"), "w"), indent=1)
+for f in glob.glob(os.path.join(root, "stats", "**", "*kernel_stats.csv"), recursive=True):
+    shutil.copy(f, os.path.join(root, f"{tag}_bench_kernel_stats.csv"))
+shutil.copy(os.path.join(root, "bench_under_rocprof.json"), os.path.join(root, f"{tag}_bench_under_rocprof.json"))
+print(json.dumps({k: v for k, v in out.items() if "trailing" in k or "colupdate" in k}, indent=1))

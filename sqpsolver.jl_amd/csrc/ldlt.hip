@@ -187,12 +187,45 @@ __device__ long long g_span[1 << 17][3];    // per workgroup: first stamp, last 
 #define SQPHIP_TR(i)
 #endif
 
+// Tile schedule of a Schur-update launch over tile columns [jlo, jhi), rows ti >= tj: index t -> (tj, ti).
+// Consecutive workgroups of one instance run on one XCD at about the same time (32 CUs x 4 resident
+// workgroups), so the order walks the region in super-tiles -- groups of S tile columns, inside a group first
+// the triangular diagonal block, then S-wide x h-high blocks below it, column-major inside a block -- so that
+// the ~128 tiles in flight share ~2 x 11 operand panels (2.8 MB at rank 256) through that XCD's 4 MB L2
+// instead of streaming one W panel per tile from the fabric.  S = 1 is the plain column-major order.
+__device__ __forceinline__ void tile_decode(int t, int jlo, int jhi, int T, int S, int &tj, int &ti)
+{
+    int c0 = jlo;
+    for (;;) {
+        const int w = jhi - c0 < S ? jhi - c0 : S;                  // columns of this group
+        const int cnt = w * (T - c0) - w * (w - 1) / 2;             // its tiles
+        if (t < cnt || c0 + w >= jhi) {
+            const int tri = w * (w + 1) / 2;
+            if (t < tri) {                                          // diagonal block, column-major
+                int c = 0, len = w;
+                while (t >= len) { t -= len; ++c; --len; }
+                tj = c0 + c; ti = tj + t;
+                return;
+            }
+            t -= tri;
+            const int h = w >= 8 ? w : 64 / w;                      // block height: ~64 tiles per block
+            const int rb = t / (w * h), rem = t - rb * (w * h);
+            const int r0 = c0 + w + rb * h;
+            const int hb = T - r0 < h ? T - r0 : h;
+            const int cj = rem / hb;
+            tj = c0 + cj; ti = r0 + rem - cj * hb;
+            return;
+        }
+        t -= cnt; c0 += w;
+    }
+}
+
 // KC = k-columns per LDS stage (two stages): 32 -> 64 KB of LDS, two workgroups per CU; 16 -> 32 KB, up to four.
 template <int KC>
 __device__ __forceinline__ void schur_update_run(double *__restrict__ K, long strideK, int ld,
                                                  const double *__restrict__ Wbuf, long strideW, int Npad,
-                                                 int T, int kp, int nsub, int wslot, int jlo, int ntl, int tpb,
-                                                 int nrun, int B, const int *__restrict__ phase, int want)
+                                                 int T, int kp, int nsub, int wslot, int jlo, int jhi, int S, int ntl,
+                                                 int tpb, int nrun, int B, const int *__restrict__ phase, int want)
 {
     constexpr int SPS = 64 / KC;            // stages per 64-wide sub-panel
     constexpr int NP = KC / 8;              // staging passes: 8 columns per pass
@@ -208,15 +241,11 @@ __device__ __forceinline__ void schur_update_run(double *__restrict__ K, long st
     }
     if (phase && phase[inst] != want) return;
     SQPHIP_TR(0)
-    // column-major enumeration of the tiles (ti >= tj) of tile columns jlo .. : first tile of the run
+    // first tile of the run
     int t = run * tpb;
     const int tend = t + tpb < ntl ? t + tpb : ntl;
-    int tj = jlo, ti;
-    {
-        int r = t, cnt = T - jlo;
-        while (r >= cnt) { r -= cnt; ++tj; --cnt; }
-        ti = tj + r;
-    }
+    int tj, ti;
+    tile_decode(t, jlo, jhi, T, S, tj, ti);
 
     // two stages of KC k-columns each: [stage][Ls | Ws][KC x 64]
     __shared__ double lds[2][2][KC * 64];
@@ -257,8 +286,8 @@ __device__ __forceinline__ void schur_update_run(double *__restrict__ K, long st
     int buf = 0;
     for (; t < tend; ++t) {
         // the tile after this one
-        int ntj = tj, nti = ti + 1;
-        if (nti == T) { ++ntj; nti = ntj; }
+        int ntj = tj, nti = ti;
+        if (t + 1 < tend) tile_decode(t + 1, jlo, jhi, T, S, ntj, nti);
         double *Cg = Kb + (long)(tj * 64 + jb) * ld + ti * 64 + ib;
         // acc = C, then acc -= products (negated A operand)
         d4 acc[2][2];
@@ -310,20 +339,20 @@ __device__ __forceinline__ void schur_update_run(double *__restrict__ K, long st
 template <int KC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_trailing(double *__restrict__ K, long strideK, int ld,
                                                     const double *__restrict__ Wbuf, long strideW, int Npad,
-                                                    int T, int kp, int nsub, int wslot, int jlo, int ntl, int tpb,
-                                                    int nrun, int B, const int *__restrict__ phase, int want)
+                                                    int T, int kp, int nsub, int wslot, int jlo, int jhi, int S, int ntl,
+                                                    int tpb, int nrun, int B, const int *__restrict__ phase, int want)
 {
-    schur_update_run<KC>(K, strideK, ld, Wbuf, strideW, Npad, T, kp, nsub, wslot, jlo, ntl, tpb, nrun, B, phase, want);
+    schur_update_run<KC>(K, strideK, ld, Wbuf, strideW, Npad, T, kp, nsub, wslot, jlo, jhi, S, ntl, tpb, nrun, B, phase, want);
 }
 
 // the left-looking updates inside an outer panel (look-ahead stream, not timed)
 template <int KC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_colupdate(double *__restrict__ K, long strideK, int ld,
                                                      const double *__restrict__ Wbuf, long strideW, int Npad,
-                                                     int T, int kp, int nsub, int wslot, int jlo, int ntl, int tpb,
-                                                     int nrun, int B, const int *__restrict__ phase, int want)
+                                                     int T, int kp, int nsub, int wslot, int jlo, int jhi, int S, int ntl,
+                                                     int tpb, int nrun, int B, const int *__restrict__ phase, int want)
 {
-    schur_update_run<KC>(K, strideK, ld, Wbuf, strideW, Npad, T, kp, nsub, wslot, jlo, ntl, tpb, nrun, B, phase, want);
+    schur_update_run<KC>(K, strideK, ld, Wbuf, strideW, Npad, T, kp, nsub, wslot, jlo, jhi, S, ntl, tpb, nrun, B, phase, want);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -441,16 +470,16 @@ static void launch_update(const LdltPlan &P, hipStream_t s, double *K, int kp, i
     if (timed) { ev = tm->get(); hipEventRecord(ev.first, s); }
     if (count && P.kc == 16)
         hipLaunchKernelGGL(k_trailing<16>, dim3(nrun * P.B), dim3(256), 0, s, K, strideK, P.ld, P.Wbuf, strideW, P.Npad,
-                           P.T, kp, nsub, wslot, jlo, ntl, tpb, nrun, P.B, phase, want);
+                           P.T, kp, nsub, wslot, jlo, jhi, P.supertile, ntl, tpb, nrun, P.B, phase, want);
     else if (count)
         hipLaunchKernelGGL(k_trailing<32>, dim3(nrun * P.B), dim3(256), 0, s, K, strideK, P.ld, P.Wbuf, strideW, P.Npad,
-                           P.T, kp, nsub, wslot, jlo, ntl, tpb, nrun, P.B, phase, want);
+                           P.T, kp, nsub, wslot, jlo, jhi, P.supertile, ntl, tpb, nrun, P.B, phase, want);
     else if (P.kc == 16)
         hipLaunchKernelGGL(k_colupdate<16>, dim3(nrun * P.B), dim3(256), 0, s, K, strideK, P.ld, P.Wbuf, strideW, P.Npad,
-                           P.T, kp, nsub, wslot, jlo, ntl, tpb, nrun, P.B, phase, want);
+                           P.T, kp, nsub, wslot, jlo, jhi, P.supertile, ntl, tpb, nrun, P.B, phase, want);
     else
         hipLaunchKernelGGL(k_colupdate<32>, dim3(nrun * P.B), dim3(256), 0, s, K, strideK, P.ld, P.Wbuf, strideW, P.Npad,
-                           P.T, kp, nsub, wslot, jlo, ntl, tpb, nrun, P.B, phase, want);
+                           P.T, kp, nsub, wslot, jlo, jhi, P.supertile, ntl, tpb, nrun, P.B, phase, want);
     if (timed) { hipEventRecord(ev.second, s); tm->pending_trailing.push_back(ev); }
     if (tm && count) tm->trailing_launches++;
 }
