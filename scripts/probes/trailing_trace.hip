@@ -6,6 +6,19 @@
 #include <vector>
 using namespace sqphip;
 
+// pseudo-random doubles in (-1, 1): real mantissa activity (an all-zero matrix keeps the MFMA datapath quiet,
+// draws 900 W and holds 2.4 GHz; random data is what the product multiplies)
+__global__ void k_fill_random(double *p, size_t n, unsigned seed)
+{
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        unsigned long long z = (i + 1) * 0x9E3779B97F4A7C15ull + seed;
+        z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;
+        p[i] = ((double)(z >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0) * 1e-3;
+    }
+}
+
 int main(int argc, char **argv)
 {
     const int N = 2813, B = 64, R = argc > 1 ? atoi(argv[1]) : 4;
@@ -16,11 +29,20 @@ int main(int argc, char **argv)
     const size_t nk = (size_t)B * P.Npad * P.Npad, nw = (size_t)2 * LdltPlan::MAX_R * B * P.Npad * 64;
     hipMalloc(&K, nk * 8); hipMalloc(&P.Wbuf, nw * 8);
     hipMemset(K, 0, nk * 8); hipMemset(P.Wbuf, 0, nw * 8);
+    if (argc > 4 && atoi(argv[4])) {
+        k_fill_random<<<4096, 256>>>(K, nk, 1u);
+        k_fill_random<<<4096, 256>>>(P.Wbuf, nw, 2u);
+        hipDeviceSynchronize();
+    }
     P.init_lookahead();
     P.R = R;
     if (argc > 2) P.tpb_max = atoi(argv[2]);
     Timers tm; tm.enabled = true;
-    for (int rep = 0; rep < 3; ++rep) launch_update(P, P.stream, K, 0, R, 0, 2 * R, P.T, nullptr, 0, &tm, true);
+    const int reps = argc > 3 ? atoi(argv[3]) : 3;   // many reps: hold the kernel on the chip while rocm-smi samples clocks
+    for (int rep = 0; rep < reps; ++rep) {
+        launch_update(P, P.stream, K, 0, R, 0, 2 * R, P.T, nullptr, 0, &tm, true);
+        if (tm.pending_trailing.size() > 256) tm.flush();
+    }
     hipStreamSynchronize(P.stream);
     tm.flush();
     static long long h[2048][16];
@@ -39,8 +61,8 @@ int main(int argc, char **argv)
         }
         seg[15] += h[i][15] - h[i][1 + 2 * R];
     }
-    printf("(stamps of the LAST tile of each sampled run) R=%d tiles/instance %d, launch %.3f ms (avg of 3), span of sampled stamps %lld ticks\n", R, ntl,
-           tm.trailing_seconds * 1e3 / 3, tmax - tmin);
+    printf("(stamps of the LAST tile of each sampled run) R=%d tiles/instance %d, launch %.3f ms (avg), span of sampled stamps %lld ticks\n", R, ntl,
+           tm.trailing_seconds * 1e3 / reps, tmax - tmin);
     printf("prologue (index, C loads, fetch issue): %.0f\n", seg[0] / nsamp);
     for (int s = 0; s < R; ++s)
         printf("sub %d: stage %.0f   multiply %.0f   (ideal multiply 64 MFMA x 64 = 4096)\n", s, seg[1 + 2 * s] / nsamp,
