@@ -69,6 +69,11 @@ def main():
                         sum_pd=float(net.pd.sum()), sum_rate=float(net.rate_a.sum()),
                         f_bus_head=net.f_bus[:8].tolist(), t_bus_head=net.t_bus[:8].tolist())
     json.dump({"synthetic_networks": fp}, open(os.path.join(HERE, "networks.json"), "w"), indent=1)
+    # the 14-bus synthetic case in the reference's on-disk format (MATPOWER v2), read back by tests/test_matpower.py
+    from sqpsolver_jl_amd.matpower import write_matpower
+    with open(os.path.join(HERE, "case14_synth.m"), "w") as fh:
+        fh.write("% synthetic IEEE-14-shaped case written by tests/golden/make_golden.py (acopf_synth(14,5,20,seed=14))\n")
+        fh.write(write_matpower(base, "case14_synth"))
     print("wrote", os.listdir(HERE))
 
 

@@ -331,3 +331,32 @@ def test_dropin_seat_reproduces_reference_answers(name):
     assert [(t["iter"], t["accepted"], t["fr"], t["sub_status"]) for t in sqp.trace] == \
            [(t["iter"], t["accepted"], t["fr"], t["sub_status"]) for t in ro["trace"]]
     assert rel(model.mult_g, ro["mult_g"]) < 1e-6
+
+
+# ------------------------------------------------------------------ input side: MATPOWER file -> device evaluator
+def test_matpower_case_file_runs_through_the_device_path():
+    """tests/golden/case14_synth.m (the reference's on-disk format) -> Network -> batched device
+    SQP-TR; the open-branch contingency is expressed in the file's status column."""
+    from sqpsolver_jl_amd import matpower as MP
+    txt = open(os.path.join(GOLD, "case14_synth.m")).read()
+    base = MP.load_case(txt)
+    mpc = MP.read_matpower(txt)
+    mpc["branch"][17, 10] = 0.0                      # take branch 18 out of service in the file data
+    out = MP.network_from_matpower(mpc)
+    assert out.status[17] == 0.0 and out.status.sum() == base.nl - 1
+    nets = [base, out]
+    lays = [acopf_layout(nt) for nt in nets]
+    kw = dict(max_iter=45, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=0)
+    ctx = pkg.Context(lays[0].n, lays[0].m, lays[0].num_linear, lays[0].jrow, lays[0].jcol, lays[0].hrow, lays[0].hcol,
+                      lays[0].xL, lays[0].xU, lays[0].gL, lays[0].gU, pkg.default_options(**kw), batch=2)
+    ctx.acopf_attach(base, lays[0])
+    for b in range(2):
+        ctx.acopf_set_instance(b, nets[b], lays[b])
+    ctx.sqp_reset(); ctx.sqp_run(0)
+    for b in range(2):
+        ro = O.sqp_solve(O.problem_acopf(nets[b], lays[b]), O.default_options(**kw))
+        rg = ctx.sqp_get(b)
+        assert (rg["status"], rg["iter"]) == (ro["status"], ro["iter"])
+        tol = TOL if ro["status"] == 0 else TOL_TRAJ
+        assert rel(rg["x"], ro["x"]) < tol and abs(rg["obj_val"] - ro["obj_val"]) <= tol * abs(ro["obj_val"])
+    ctx.close()
