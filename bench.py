@@ -65,6 +65,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--literal-quirks", type=int, default=1)
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event timing of k_trailing")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank flow "
+                         "on a box with fewer GPUs than ranks, together with --one-device)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
     import numpy as np
@@ -76,9 +80,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
 
     import sqpsolver_jl_amd as pkg
     from sqpsolver_jl_amd.acopf_synth import acopf_synth, acopf_layout, contingency, CASES
@@ -123,7 +132,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")   # collective buffers
 
     def run_steps(k):
         """k outer SQP-TR iterations of every instance of the shard (continuous batching inside the
