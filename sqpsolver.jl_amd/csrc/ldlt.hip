@@ -56,6 +56,9 @@ __device__ __forceinline__ void diag_factor_wave(double *__restrict__ A, int ld,
 #pragma unroll
         for (int q = 0; q < 16; ++q)
             if (4 * q + W > j) a[q] -= lm * colbuf[j & 1][4 * q + W];
+        // pin this step's updates (see panel_trsm_wave): keeps the scheduler from sinking them across barriers
+#pragma unroll
+        for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(a[q]));
     }
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -85,67 +88,125 @@ __global__ __launch_bounds__(256) void k_diag_factor(double *__restrict__ K, lon
 }
 
 // ---------------------------------------------------------------------------------------------
-// tiles (i,k), i>k: X L_kk' = A_ik, W = X, L = X D^-1.  One 256-thread workgroup per tile; thread
-// (r, W) owns row r restricted to the columns c = W (mod 4).  Right-looking substitution: at step j the
-// owner wave publishes the final x_j through LDS, every wave applies x_c -= x_j L_kk[c][j] to its own
-// columns c > j (same subtraction order per entry as the textbook loop).  Specialised on the
-// compile-time wave index like k_diag_factor.
-template <int W>
+// tiles (i,k), i>k: X L_kk' = A_ik, W = X, L = X D^-1.  One 256-thread workgroup per tile.  Lane l of wave W
+// owns rows r2 = l & 31 and r2 + 32 restricted to the columns c = cg (mod 8), cg = 2 W + (l >> 5): 2 x 8
+// entries in registers.  Right-looking substitution: at step j the owner lanes publish the final x_j through
+// LDS, every lane applies x_c -= x_j L_kk[c][j] to its own columns c > j (same subtraction order per entry as
+// the textbook loop).  The kernel is bound by the CU's LDS pipe (the reads of L_kk: one per (j, c) pair and
+// wave); with two rows per lane each read feeds two multiply-adds -- the one-row-per-lane layout issued 17
+// LDS reads per wave and step, this one 10.  The per-wave program is specialised on the compile-time wave
+// index like k_diag_factor; the half-wave index enters only through predication and LDS addresses.
+template <int W, int TB>
 __device__ __forceinline__ void panel_trsm_wave(const double *__restrict__ Lkk, double *__restrict__ A, int ld,
-                                                double *__restrict__ Wout, int Npad,
-                                                const double *__restrict__ di, double *Ls, double (*xs)[64], int r)
+                                                double *__restrict__ Wout, int Npad, int ntile,
+                                                const double *__restrict__ di, double *Ls, double (*xs)[TB][64], int lane)
 {
+    const int half = lane >> 5, r2 = lane & 31, cg = 2 * W + half;
     // packed strict lower triangle: column j holds rows c > j at Ls[tri(j) + c - j - 1]
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        constexpr int dummy = 0; (void)dummy;
-        const int c = 4 * q + W;
-        const double v = Lkk[(long)c * ld + r];
-        if (r > c) Ls[c * 63 - c * (c - 1) / 2 + r - c - 1] = v;
-    }
-    double x[16];
+    for (int q = 0; q < 8; ++q) {
+        const int c = 8 * q + cg;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) x[q] = A[(long)(4 * q + W) * ld + r];
+        for (int h = 0; h < 2; ++h) {
+            const int r = r2 + 32 * h;
+            const double v = Lkk[(long)c * ld + r];
+            if (r > c) Ls[c * 63 - c * (c - 1) / 2 + r - c - 1] = v;
+        }
+    }
+    // row tiles t >= ntile (below the last one) are loaded from whatever follows in the buffer -- the reads
+    // stay inside this instance's matrix because k < T-1 -- computed on, and never stored
+    double x[TB][2][8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const double *Aq = A + (long)(8 * q + cg) * ld + r2;
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+            x[t][0][q] = Aq[64 * t];
+            x[t][1][q] = Aq[64 * t + 32];
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 63; ++j) {
-        if ((j & 3) == W) xs[j & 1][r] = x[j >> 2];
-        __syncthreads();             // also orders the Ls stores of the prologue before their first use
-        const double xj = xs[j & 1][r];
+        if (((j & 7) >> 1) == W) {                  // the wave that owns column j; its half (j & 1) publishes
+            if (half == (j & 1)) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q)
-            if (4 * q + W > j) x[q] -= xj * Ls[j * 63 - j * (j - 1) / 2 + (4 * q + W) - j - 1];
+                for (int t = 0; t < TB; ++t) {
+                    xs[j & 1][t][r2] = x[t][0][j >> 3];
+                    xs[j & 1][t][r2 + 32] = x[t][1][j >> 3];
+                }
+            }
+        }
+        __syncthreads();             // also orders the Ls stores of the prologue before their first use
+        double xj[TB][2];
+#pragma unroll
+        for (int t = 0; t < TB; ++t) { xj[t][0] = xs[j & 1][t][r2]; xj[t][1] = xs[j & 1][t][r2 + 32]; }
+        // an opaque zero added to this step's L_kk addresses: without it the scheduler hoists the (read-only
+        // after the prologue) L_kk reads of many later steps above the barriers and spills
+        int z = 0;
+        asm volatile("" : "+v"(z));
+        const int tri = j * 63 - j * (j - 1) / 2 - j - 1 + z;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (8 * q + 7 <= j) continue;                       // every column of this group is <= j
+            double l;
+            if (8 * q > j) {                                    // every column of this group is > j
+                l = Ls[tri + 8 * q + cg];
+            } else {                                            // the group that contains j: lanes with c > j only
+                const bool act = 8 * q + cg > j;
+                const double lv = Ls[act ? tri + 8 * q + cg : 0];   // index clamped for the idle lanes
+                l = act ? lv : 0.0;
+            }
+#pragma unroll
+            for (int t = 0; t < TB; ++t) {
+                x[t][0][q] -= xj[t][0] * l;
+                x[t][1][q] -= xj[t][1] * l;
+            }
+        }
+        // pin this step's updates here: the scheduler otherwise sinks multiply-adds of far columns across
+        // later barriers and keeps their x_j / L operands alive in scratch
+#pragma unroll
+        for (int t = 0; t < TB; ++t)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(x[t][0][q]), "+v"(x[t][1][q]));
     }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int c = 4 * q + W;
-        Wout[(long)c * Npad + r] = x[q];
-        A[(long)c * ld + r] = x[q] * di[c];
+    for (int q = 0; q < 8; ++q) {
+        const int c = 8 * q + cg;
+        double *Wq = Wout + (long)c * Npad + r2, *Aq = A + (long)c * ld + r2;
+        const double dc = di[c];
+#pragma unroll
+        for (int t = 0; t < TB; ++t)
+            if (TB == 1 || t < ntile) {
+                Wq[64 * t] = x[t][0][q]; Wq[64 * t + 32] = x[t][1][q];
+                Aq[64 * t] = x[t][0][q] * dc; Aq[64 * t + 32] = x[t][1][q] * dc;
+            }
     }
 }
 
+template <int TB>
 __global__ __launch_bounds__(256) void k_panel_trsm(double *__restrict__ K, long strideK, int ld,
                                                    const double *__restrict__ dinv,
-                                                   double *__restrict__ Wbuf, int Npad, int k,
+                                                   double *__restrict__ Wbuf, int Npad, int k, int T,
                                                    const int *__restrict__ phase, int want)
 {
     const int inst = blockIdx.y;
     if (phase && phase[inst] != want) return;
-    const int i = k + 1 + blockIdx.x;
-    const int r = threadIdx.x & 63;
+    const int i = k + 1 + blockIdx.x * TB;          // first row tile of this workgroup
+    const int ntile = T - i < TB ? T - i : TB;
+    const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double *Kb = K + (long)inst * strideK;
     const double *Lkk = Kb + (long)(k * 64) * ld + k * 64;
     double *A = Kb + (long)(k * 64) * ld + i * 64;
-    __shared__ double Ls[2016];      // strict lower triangle of L_kk, packed by columns (15.75 KB: the
-                                     // kernel fits beside two resident k_trailing workgroups)
-    __shared__ double xs[2][64];
+    __shared__ double Ls[2016];      // strict lower triangle of L_kk, packed by columns (15.75 KB)
+    __shared__ double xs[2][TB][64];
     double *Wout = Wbuf + (long)inst * Npad * 64 + i * 64;   // Wbuf already points at this sub-panel's slot
     const double *di = dinv + (long)inst * Npad + k * 64;
     switch (w) {
-    case 0: panel_trsm_wave<0>(Lkk, A, ld, Wout, Npad, di, Ls, xs, r); break;
-    case 1: panel_trsm_wave<1>(Lkk, A, ld, Wout, Npad, di, Ls, xs, r); break;
-    case 2: panel_trsm_wave<2>(Lkk, A, ld, Wout, Npad, di, Ls, xs, r); break;
-    default: panel_trsm_wave<3>(Lkk, A, ld, Wout, Npad, di, Ls, xs, r); break;
+    case 0: panel_trsm_wave<0, TB>(Lkk, A, ld, Wout, Npad, ntile, di, Ls, xs, lane); break;
+    case 1: panel_trsm_wave<1, TB>(Lkk, A, ld, Wout, Npad, ntile, di, Ls, xs, lane); break;
+    case 2: panel_trsm_wave<2, TB>(Lkk, A, ld, Wout, Npad, ntile, di, Ls, xs, lane); break;
+    default: panel_trsm_wave<3, TB>(Lkk, A, ld, Wout, Npad, ntile, di, Ls, xs, lane); break;
     }
 }
 
@@ -490,9 +551,11 @@ static void launch_panel(const LdltPlan &P, hipStream_t s, double *K, double *di
     const long strideK = (long)P.ld * P.Npad, strideW = (long)P.B * P.Npad * 64;
     hipLaunchKernelGGL(k_diag_factor, dim3(P.B), dim3(256), 0, s, K, strideK, P.ld, dinv, P.Npad, c, phase, want);
     const int rem = P.T - c - 1;
-    if (rem > 0)
-        hipLaunchKernelGGL(k_panel_trsm, dim3(rem, P.B), dim3(256), 0, s, K, strideK, P.ld, dinv,
-                           P.Wbuf + (long)wslot * strideW, P.Npad, c, phase, want);
+    if (rem <= 0) return;
+    // one row tile per workgroup: the TB = 2 / 4 instantiations of the template halve the LDS traffic again but
+    // the fully unrolled substitution then spills inside the step loop (30 ms instead of 12 per factorisation)
+    hipLaunchKernelGGL(k_panel_trsm<1>, dim3(rem, P.B), dim3(256), 0, s, K, strideK, P.ld, dinv,
+                       P.Wbuf + (long)wslot * strideW, P.Npad, c, P.T, phase, want);
 }
 
 // Two-level right-looking LDL^T: outer panels of R 64-wide sub-panels, so every pass over the
