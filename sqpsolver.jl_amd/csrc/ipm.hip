@@ -365,33 +365,15 @@ __global__ __launch_bounds__(128) void k_kkt_assemble(DV d)
 }
 
 // ---------------------------------------------------------------------------------------------
-// after the factorisation: inertia from pivot signs; on success build the Newton right-hand side
-__global__ __launch_bounds__(TPB) void k_inertia_rhs(DV d)
+// before the factorisation: the Newton right-hand side (it does not depend on delta_w) and its working copy
+// xv, which the panel kernels of the factorisation turn into L^-1 rhs on the fly (fused forward elimination).
+// Runs for every instance in PH_FACTOR, i.e. again before each re-factorisation.
+__global__ __launch_bounds__(TPB) void k_build_rhs(DV d)
 {
     const int inst = blockIdx.x;
     if (d.phase[inst] != PH_FACTOR) return;
     IpmState &st = d.ist[inst];
     INST_PTRS
-    const double *dinv = d.dinv + (long)inst * d.Npad;
-    double np = 0, bad = 0;
-    for (int i = threadIdx.x; i < d.N; i += TPB) {
-        const double v = dinv[i];
-        if (!fin(v) || v == 0.0) bad += 1; else if (v > 0) np += 1;
-    }
-    np = block_reduce<OpSum>(np); bad = block_reduce<OpSum>(bad);
-    const bool ok = (np == (double)d.n) && bad == 0;
-    if (!ok) {
-        if (threadIdx.x == 0) {
-            st.n_factor++;
-            st.fac_attempt++;
-            double dw = st.dw;
-            if (dw == 0.0) dw = st.dw_last == 0.0 ? 1e-4 : fmax(1e-20, st.dw_last / 3.0);
-            else dw *= (st.dw_last == 0.0 ? 100.0 : 8.0);
-            st.dw = dw;
-            if (dw > 1e40 || st.fac_attempt >= 60) { st.rc = 2; d.phase[inst] = PH_DONE; }
-        }
-        return;
-    }
     const double tgt = st.mu;
     double rn = 0.0;
     for (int j = threadIdx.x; j < d.n; j += TPB) {
@@ -422,13 +404,37 @@ __global__ __launch_bounds__(TPB) void k_inertia_rhs(DV d)
         xv[i] = v;
         sol[i] = 0.0;
     }
-    if (threadIdx.x == 0) {
-        st.n_factor++;
-        if (st.dw > 0.0) st.dw_last = st.dw;
-        st.rn = fmax(1.0, rn);
-        st.refine_it = 0;
-        d.phase[inst] = PH_SOLVE;
+    if (threadIdx.x == 0) st.rn = fmax(1.0, rn);
+}
+
+// after the factorisation: inertia from pivot signs -> PH_SOLVE, or a larger delta_w (stays PH_FACTOR)
+__global__ __launch_bounds__(TPB) void k_inertia(DV d)
+{
+    const int inst = blockIdx.x;
+    if (d.phase[inst] != PH_FACTOR) return;
+    IpmState &st = d.ist[inst];
+    const double *dinv = d.dinv + (long)inst * d.Npad;
+    double np = 0, bad = 0;
+    for (int i = threadIdx.x; i < d.N; i += TPB) {
+        const double v = dinv[i];
+        if (!fin(v) || v == 0.0) bad += 1; else if (v > 0) np += 1;
     }
+    np = block_reduce<OpSum>(np); bad = block_reduce<OpSum>(bad);
+    const bool ok = (np == (double)d.n) && bad == 0;
+    if (threadIdx.x != 0) return;
+    st.n_factor++;
+    if (!ok) {
+        st.fac_attempt++;
+        double dw = st.dw;
+        if (dw == 0.0) dw = st.dw_last == 0.0 ? 1e-4 : fmax(1e-20, st.dw_last / 3.0);
+        else dw *= (st.dw_last == 0.0 ? 100.0 : 8.0);
+        st.dw = dw;
+        if (dw > 1e40 || st.fac_attempt >= 60) { st.rc = 2; d.phase[inst] = PH_DONE; }
+        return;
+    }
+    if (st.dw > 0.0) st.dw_last = st.dw;
+    st.refine_it = 0;
+    d.phase[inst] = PH_SOLVE;
 }
 
 // after a triangular solve: accumulate, form the residual against the sparse operator, decide
@@ -632,8 +638,9 @@ static void read_counters(Ctx &C)
 //   [SQP level]   stage gating    -> merit step of finished sub-problems, next sub-problem request
 //   k_qp_gather / k_ipm_start     -> instances with a start request
 //   k_ipm_prepare phase PREP      -> convergence test, barrier update, diagonals -> FACTOR
-//   assemble, LDL^T, inertia      -> FACTOR -> SOLVE (or delta_w bump, stays FACTOR)
-//   2 x (solve, refine)           -> SOLVE -> STEP
+//   assemble, rhs, LDL^T (with the forward elimination of the rhs fused in), inertia
+//                                 -> FACTOR -> SOLVE (or delta_w bump, stays FACTOR)
+//   backward solve, refine, full solve, refine      -> SOLVE -> STEP
 //   k_ipm_step    phase STEP      -> update -> PREP
 //   k_ipm_prepare again           -> so that a converged instance is recognised in this sweep
 void ipm_sweep(Ctx &C, bool sqp_level)
@@ -647,14 +654,15 @@ void ipm_sweep(Ctx &C, bool sqp_level)
     hipLaunchKernelGGL(k_ipm_start, gB, bT, 0, s, d);
     hipLaunchKernelGGL(k_ipm_prepare, gB, bT, 0, s, d);
     hipLaunchKernelGGL(k_kkt_assemble, dim3(d.Npad, d.B), dim3(128), 0, s, d);
+    hipLaunchKernelGGL(k_build_rhs, gB, bT, 0, s, d);
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (C.tm.enabled) { ev = C.tm.get(); hipEventRecord(ev.first, s); }
-    ldlt_factor(C.plan, d.K, d.dinv, d.phase, PH_FACTOR, &C.tm);
+    ldlt_factor(C.plan, d.K, d.dinv, d.phase, PH_FACTOR, &C.tm, d.xv, d.vv);   // + fused forward elimination of xv
     if (C.tm.enabled) { hipEventRecord(ev.second, s); C.tm.pending_factor.push_back(ev); }
-    hipLaunchKernelGGL(k_inertia_rhs, gB, bT, 0, s, d);
+    hipLaunchKernelGGL(k_inertia, gB, bT, 0, s, d);
     if (C.tm.enabled) { ev = C.tm.get(); hipEventRecord(ev.first, s); }
-    for (int r = 0; r < 2; ++r) {      // plain solve + at most one refinement step
-        ldlt_solve(C.plan, d.K, d.dinv, d.xv, d.vv, d.phase, PH_SOLVE);
+    for (int r = 0; r < 2; ++r) {      // plain solve (backward half only) + at most one refinement step
+        ldlt_solve(C.plan, d.K, d.dinv, d.xv, d.vv, d.phase, PH_SOLVE, r == 0);
         hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, r == 1 ? 1 : 0);
     }
     if (C.tm.enabled) { hipEventRecord(ev.second, s); C.tm.pending_solve.push_back(ev); }

@@ -107,8 +107,16 @@ extern "C" int sqphip_ldlt_solve_host(int32_t device, int32_t batch, int64_t N, 
         for (int b = 0; b < batch; ++b)
             SQPHIP_HIP_OK(hipMemcpyAsync(S.x + (long)b * S.P.Npad, rhs + (long)b * N, sizeof(double) * N,
                                          hipMemcpyHostToDevice, S.P.stream));
-        ldlt_factor(S.P, S.K, S.dinv, nullptr, 0, nullptr);
-        ldlt_solve(S.P, S.K, S.dinv, S.x, S.v, nullptr, 0);
+        // default: forward elimination fused into the factorisation (the product path); SQPHIP_FUSED_FWD=0
+        // exercises the stand-alone forward steps (the refinement path)
+        const char *ff = getenv("SQPHIP_FUSED_FWD");
+        if (ff && ff[0] == '0') {
+            ldlt_factor(S.P, S.K, S.dinv, nullptr, 0, nullptr);
+            ldlt_solve(S.P, S.K, S.dinv, S.x, S.v, nullptr, 0);
+        } else {
+            ldlt_factor(S.P, S.K, S.dinv, nullptr, 0, nullptr, S.x, S.v);
+            ldlt_solve(S.P, S.K, S.dinv, S.x, S.v, nullptr, 0, true);
+        }
         for (int b = 0; b < batch; ++b)
             SQPHIP_HIP_OK(hipMemcpyAsync(rhs + (long)b * N, S.x + (long)b * S.P.Npad, sizeof(double) * N,
                                          hipMemcpyDeviceToHost, S.P.stream));

@@ -29,12 +29,15 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 // order.
 template <int W>
 __device__ __forceinline__ void diag_factor_wave(double *__restrict__ A, int ld, double *__restrict__ dinv_out,
-                                                 double (*colbuf)[64], int r)
+                                                 double (*colbuf)[64], int r, double *__restrict__ bk)
 {
     double a[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) a[q] = A[(long)(4 * q + W) * ld + r];
     double my_dinv = 0.0;
+    // fused forward elimination (wave 0 only): bb = entry r of the right-hand side block; after step j it has
+    // received -L_rj y_j, so at the end it is y = L_kk^-1 b
+    double bb = (W == 0 && bk) ? bk[r] : 0.0;
 #pragma unroll
     for (int j = 0; j < 64; ++j) {
         constexpr int dummy = 0; (void)dummy;
@@ -53,6 +56,7 @@ __device__ __forceinline__ void diag_factor_wave(double *__restrict__ A, int ld,
             my_dinv = (r == j) ? dji : my_dinv;
             a[jq] = below ? l : a[jq];
         }
+        if (W == 0) bb -= lm * __shfl(bb, j);
 #pragma unroll
         for (int q = 0; q < 16; ++q)
             if (4 * q + W > j) a[q] -= lm * colbuf[j & 1][4 * q + W];
@@ -66,11 +70,15 @@ __device__ __forceinline__ void diag_factor_wave(double *__restrict__ A, int ld,
         if (c < r) A[(long)c * ld + r] = a[q];
     }
     if ((r & 3) == W) dinv_out[r] = my_dinv;          // set by lane r == j of the owner wave of column j
+    if (W == 0 && bk) bk[r] = bb;
 }
 
+// bvec / vvec (both or neither): right-hand sides [B][Npad] for the fused forward elimination -- b_k is replaced
+// by y_k = L_kk^-1 b_k and v_k = D_k^-1 y_k is stored, exactly what k_fwd_step(k) does for its diagonal tile.
 __global__ __launch_bounds__(256) void k_diag_factor(double *__restrict__ K, long strideK, int ld,
                                                     double *__restrict__ dinv, int Npad, int k,
-                                                    const int *__restrict__ phase, int want)
+                                                    const int *__restrict__ phase, int want,
+                                                    double *__restrict__ bvec, double *__restrict__ vvec)
 {
     const int inst = blockIdx.x;
     if (phase && phase[inst] != want) return;
@@ -79,11 +87,16 @@ __global__ __launch_bounds__(256) void k_diag_factor(double *__restrict__ K, lon
     double *A = K + (long)inst * strideK + (long)(k * 64) * ld + k * 64;   // tile origin
     double *dout = dinv + (long)inst * Npad + k * 64;
     __shared__ double colbuf[2][64];
+    double *bk = bvec ? bvec + (long)inst * Npad + k * 64 : nullptr;
     switch (w) {
-    case 0: diag_factor_wave<0>(A, ld, dout, colbuf, r); break;
-    case 1: diag_factor_wave<1>(A, ld, dout, colbuf, r); break;
-    case 2: diag_factor_wave<2>(A, ld, dout, colbuf, r); break;
-    default: diag_factor_wave<3>(A, ld, dout, colbuf, r); break;
+    case 0: diag_factor_wave<0>(A, ld, dout, colbuf, r, bk); break;
+    case 1: diag_factor_wave<1>(A, ld, dout, colbuf, r, bk); break;
+    case 2: diag_factor_wave<2>(A, ld, dout, colbuf, r, bk); break;
+    default: diag_factor_wave<3>(A, ld, dout, colbuf, r, bk); break;
+    }
+    if (bvec) {
+        __syncthreads();             // dout[] of all four waves and bk[] of wave 0 are visible
+        if (w == 0) vvec[(long)inst * Npad + k * 64 + r] = bk[r] * dout[r];
     }
 }
 
@@ -99,7 +112,8 @@ __global__ __launch_bounds__(256) void k_diag_factor(double *__restrict__ K, lon
 template <int W, int TB>
 __device__ __forceinline__ void panel_trsm_wave(const double *__restrict__ Lkk, double *__restrict__ A, int ld,
                                                 double *__restrict__ Wout, int Npad, int ntile,
-                                                const double *__restrict__ di, double *Ls, double (*xs)[TB][64], int lane)
+                                                const double *__restrict__ di, double *Ls, double (*xs)[TB][64], int lane,
+                                                const double *__restrict__ yk, double (*red)[TB][64])
 {
     const int half = lane >> 5, r2 = lane & 31, cg = 2 * W + half;
     // packed strict lower triangle: column j holds rows c > j at Ls[tri(j) + c - j - 1]
@@ -169,17 +183,30 @@ __device__ __forceinline__ void panel_trsm_wave(const double *__restrict__ Lkk, 
 #pragma unroll
             for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(x[t][0][q]), "+v"(x[t][1][q]));
     }
+    double part[TB][2];
+#pragma unroll
+    for (int t = 0; t < TB; ++t) part[t][0] = part[t][1] = 0.0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int c = 8 * q + cg;
         double *Wq = Wout + (long)c * Npad + r2, *Aq = A + (long)c * ld + r2;
         const double dc = di[c];
+        const double yc = yk ? yk[c] : 0.0;
 #pragma unroll
-        for (int t = 0; t < TB; ++t)
+        for (int t = 0; t < TB; ++t) {
+            const double l0 = x[t][0][q] * dc, l1 = x[t][1][q] * dc;
             if (TB == 1 || t < ntile) {
                 Wq[64 * t] = x[t][0][q]; Wq[64 * t + 32] = x[t][1][q];
-                Aq[64 * t] = x[t][0][q] * dc; Aq[64 * t + 32] = x[t][1][q] * dc;
+                Aq[64 * t] = l0; Aq[64 * t + 32] = l1;
             }
+            part[t][0] += l0 * yc; part[t][1] += l1 * yc;
+        }
+    }
+    // fused forward elimination: this lane's share of (L_ik y_k)[row], combined over the 8 column groups by
+    // the kernel body
+    if (yk) {
+#pragma unroll
+        for (int t = 0; t < TB; ++t) { red[cg][t][r2] = part[t][0]; red[cg][t][r2 + 32] = part[t][1]; }
     }
 }
 
@@ -187,7 +214,8 @@ template <int TB>
 __global__ __launch_bounds__(256) void k_panel_trsm(double *__restrict__ K, long strideK, int ld,
                                                    const double *__restrict__ dinv,
                                                    double *__restrict__ Wbuf, int Npad, int k, int T,
-                                                   const int *__restrict__ phase, int want)
+                                                   const int *__restrict__ phase, int want,
+                                                   double *__restrict__ bvec)
 {
     const int inst = blockIdx.y;
     if (phase && phase[inst] != want) return;
@@ -200,13 +228,31 @@ __global__ __launch_bounds__(256) void k_panel_trsm(double *__restrict__ K, long
     double *A = Kb + (long)(k * 64) * ld + i * 64;
     __shared__ double Ls[2016];      // strict lower triangle of L_kk, packed by columns (15.75 KB)
     __shared__ double xs[2][TB][64];
+    __shared__ double red[8][TB][64];   // fused forward elimination: partial products per column group
     double *Wout = Wbuf + (long)inst * Npad * 64 + i * 64;   // Wbuf already points at this sub-panel's slot
     const double *di = dinv + (long)inst * Npad + k * 64;
+    // bvec (optional): right-hand sides [B][Npad]; y_k = bvec[k-block] was finalised by k_diag_factor, this
+    // workgroup subtracts L_ik y_k from its own block(s) -- what k_fwd_step(k) does for tile row i
+    const double *yk = bvec ? bvec + (long)inst * Npad + k * 64 : nullptr;
     switch (w) {
-    case 0: panel_trsm_wave<0, TB>(Lkk, A, ld, Wout, Npad, ntile, di, Ls, xs, lane); break;
-    case 1: panel_trsm_wave<1, TB>(Lkk, A, ld, Wout, Npad, ntile, di, Ls, xs, lane); break;
-    case 2: panel_trsm_wave<2, TB>(Lkk, A, ld, Wout, Npad, ntile, di, Ls, xs, lane); break;
-    default: panel_trsm_wave<3, TB>(Lkk, A, ld, Wout, Npad, ntile, di, Ls, xs, lane); break;
+    case 0: panel_trsm_wave<0, TB>(Lkk, A, ld, Wout, Npad, ntile, di, Ls, xs, lane, yk, red); break;
+    case 1: panel_trsm_wave<1, TB>(Lkk, A, ld, Wout, Npad, ntile, di, Ls, xs, lane, yk, red); break;
+    case 2: panel_trsm_wave<2, TB>(Lkk, A, ld, Wout, Npad, ntile, di, Ls, xs, lane, yk, red); break;
+    default: panel_trsm_wave<3, TB>(Lkk, A, ld, Wout, Npad, ntile, di, Ls, xs, lane, yk, red); break;
+    }
+    if (bvec) {
+        __syncthreads();
+        if (w == 0) {
+            double *bi = bvec + (long)inst * Npad + i * 64;
+#pragma unroll
+            for (int t = 0; t < TB; ++t)
+                if (TB == 1 || t < ntile) {
+                    double sum = 0.0;
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) sum += red[g][t][lane];
+                    bi[64 * t + lane] -= sum;
+                }
+        }
     }
 }
 
@@ -546,16 +592,16 @@ static void launch_update(const LdltPlan &P, hipStream_t s, double *K, int kp, i
 }
 
 static void launch_panel(const LdltPlan &P, hipStream_t s, double *K, double *dinv, int c, int wslot,
-                         const int *phase, int want)
+                         const int *phase, int want, double *b, double *v)
 {
     const long strideK = (long)P.ld * P.Npad, strideW = (long)P.B * P.Npad * 64;
-    hipLaunchKernelGGL(k_diag_factor, dim3(P.B), dim3(256), 0, s, K, strideK, P.ld, dinv, P.Npad, c, phase, want);
+    hipLaunchKernelGGL(k_diag_factor, dim3(P.B), dim3(256), 0, s, K, strideK, P.ld, dinv, P.Npad, c, phase, want, b, v);
     const int rem = P.T - c - 1;
     if (rem <= 0) return;
     // one row tile per workgroup: the TB = 2 / 4 instantiations of the template halve the LDS traffic again but
     // the fully unrolled substitution then spills inside the step loop (30 ms instead of 12 per factorisation)
     hipLaunchKernelGGL(k_panel_trsm<1>, dim3(rem, P.B), dim3(256), 0, s, K, strideK, P.ld, dinv,
-                       P.Wbuf + (long)wslot * strideW, P.Npad, c, P.T, phase, want);
+                       P.Wbuf + (long)wslot * strideW, P.Npad, c, P.T, phase, want, b);
 }
 
 // Two-level right-looking LDL^T: outer panels of R 64-wide sub-panels, so every pass over the
@@ -563,7 +609,9 @@ static void launch_panel(const LdltPlan &P, hipStream_t s, double *K, double *di
 // tile columns of the next outer panel) and the "rest"; the latency-bound factorisation of the next
 // panel runs on the auxiliary stream while the main stream streams the rest through the MFMA kernel.
 // W = L D of the current outer panel lives in Wbuf slots [0,R) or [MAX_R, MAX_R+R) by panel parity.
-void ldlt_factor(const LdltPlan &P, double *K, double *dinv, const int *phase, int want, Timers *tm)
+// b, v (optional, [B][Npad]): the forward elimination L y = b is fused into the panel kernels (b <- y, v <- D^-1 y),
+// so that the first solve after a factorisation is ldlt_solve(..., skip_fwd = true).
+void ldlt_factor(const LdltPlan &P, double *K, double *dinv, const int *phase, int want, Timers *tm, double *b, double *v)
 {
     hipStream_t sA = P.stream, sB = P.aux ? P.aux : P.stream;
     const int T = P.T, R = P.R;
@@ -579,7 +627,7 @@ void ldlt_factor(const LdltPlan &P, double *K, double *dinv, const int *phase, i
         //      column is read and written once; right-looking rank-64 updates cost twice the HBM traffic)
         for (int j = 0; j < nsub; ++j) {
             if (j) launch_update(P, sB, K, c0, j, slot, c0 + j, c0 + j + 1, phase, want, tm, false);
-            launch_panel(P, sB, K, dinv, c0 + j, slot + j, phase, want);
+            launch_panel(P, sB, K, dinv, c0 + j, slot + j, phase, want, b, v);
         }
         if (c0 + nsub >= T) break;
         if (sB != sA) { hipEventRecord(evPanel, sB); hipStreamWaitEvent(sA, evPanel, 0); }
@@ -593,11 +641,11 @@ void ldlt_factor(const LdltPlan &P, double *K, double *dinv, const int *phase, i
 }
 
 void ldlt_solve(const LdltPlan &P, const double *K, const double *dinv, double *x, double *v,
-                const int *phase, int want)
+                const int *phase, int want, bool skip_fwd)
 {
     const long strideK = (long)P.ld * P.Npad;
     hipStream_t s = P.stream;
-    for (int k = 0; k < P.T; ++k)
+    for (int k = 0; k < P.T && !skip_fwd; ++k)
         hipLaunchKernelGGL(k_fwd_step, dim3(P.T - k, P.B), dim3(64), 0, s, K, strideK, P.ld, dinv, x, v,
                            P.Npad, k, phase, want);
     for (int k = P.T - 1; k >= 0; --k)

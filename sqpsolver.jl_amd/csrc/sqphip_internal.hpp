@@ -87,9 +87,10 @@ struct LdltPlan {
 };
 
 // phase-filtered launches: kernels skip instances whose phase[inst] != want (phase may be null)
-void ldlt_factor(const LdltPlan &P, double *K, double *dinv, const int *phase, int want, Timers *tm);
+void ldlt_factor(const LdltPlan &P, double *K, double *dinv, const int *phase, int want, Timers *tm,
+                 double *b = nullptr, double *v = nullptr);
 void ldlt_solve(const LdltPlan &P, const double *K, const double *dinv, double *x, double *v,
-                const int *phase, int want);
+                const int *phase, int want, bool skip_fwd = false);
 
 #define SQPHIP_HIP_OK(expr)                                                                    \
     do {                                                                                       \
