@@ -177,6 +177,9 @@ int sqphip_ldlt_bench(int32_t device, int32_t batch, int64_t N, int32_t reps,
                       double *sec_per_factor, double *sec_trailing, int64_t *trailing_launches);
 
 /* on-box fp64 MFMA issue-rate probe (register-resident v_mfma_f64_16x16x4_f64 loop), TFLOP/s */
+/* test hook: factorise random batches with and without the look-ahead schedule and count repetitions whose
+ * factors differ in any bit (must be 0) */
+int sqphip_ldlt_stress(int32_t device, int32_t batch, int64_t N, int32_t reps, int32_t *mismatches);
 int sqphip_mfma_f64_peak(int32_t device, double *tflops);
 
 #ifdef __cplusplus

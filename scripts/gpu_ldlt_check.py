@@ -19,7 +19,7 @@ def qd(N, n1, seed):
     return A
 
 out = {}
-for N, B in ((6, 2), (64, 2), (100, 3), (307, 4), (600, 2)):
+for N, B in ((6, 2), (64, 2), (100, 3), (307, 4), (600, 2), (307, 8), (700, 16)):
     As = np.stack([qd(N, N * 2 // 5, 10 + b) for b in range(B)])
     rhs = np.random.default_rng(5).standard_normal((B, N))
     Af = np.ascontiguousarray(np.stack([np.asfortranarray(a).ravel(order="F") for a in As]))

@@ -187,6 +187,77 @@ extern "C" int sqphip_ldlt_bench(int32_t device, int32_t batch, int64_t N, int32
 }
 
 // ---------------------------------------------------------------------------------------------
+// Stress test of the look-ahead schedule: the same random quasi-definite batch is factorised with the two-stream
+// schedule and with everything on one stream (phase mask: a random subset of the instances is active); the
+// factors must agree bit for bit.  Returns the number of repetitions with a mismatch.
+namespace {
+// counts entries that differ; ld > 0: the buffers are [.][ld x ld] column-major matrices and only the lower
+// triangle (row >= column) is compared -- the strict upper triangle is never initialised nor read
+__global__ void k_maxdiff(const double *a, const double *b, size_t n, int ld, unsigned long long *out)
+{
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    unsigned long long bad = 0;
+    for (; i < n; i += stride) {
+        if (ld > 0) {
+            const size_t e = i % ((size_t)ld * ld);
+            if (e % ld < e / ld) continue;
+        }
+        const double x = a[i], y = b[i];
+        if (!(x == y) && !(x != x && y != y)) ++bad;
+    }
+    if (bad) atomicAdd(out, bad);
+}
+}  // namespace
+
+extern "C" int sqphip_ldlt_stress(int32_t device, int32_t batch, int64_t N, int32_t reps, int32_t *mismatches)
+{
+    try {
+        SQPHIP_HIP_OK(hipSetDevice(device));
+        Scratch S;
+        S.alloc(batch, N);
+        const long strideK = (long)S.P.ld * S.P.Npad;
+        const size_t nk = (size_t)batch * strideK;
+        double *K2, *dinv2; int *phase; unsigned long long *cnt;
+        SQPHIP_HIP_OK(hipMalloc(&K2, sizeof(double) * nk));
+        SQPHIP_HIP_OK(hipMalloc(&dinv2, sizeof(double) * (size_t)batch * S.P.Npad));
+        SQPHIP_HIP_OK(hipMalloc(&phase, sizeof(int) * batch));
+        SQPHIP_HIP_OK(hipMalloc(&cnt, sizeof(unsigned long long)));
+        std::vector<int> hp(batch);
+        int bad_reps = 0;
+        hipStream_t aux = S.P.aux;
+        for (int rep = 0; rep < reps; ++rep) {
+            unsigned r = 12345u + 7919u * rep;
+            for (int b = 0; b < batch; ++b) { r = r * 1664525u + 1013904223u; hp[b] = ((r >> 16) % 4) ? 1 : 0; }
+            SQPHIP_HIP_OK(hipMemcpyAsync(phase, hp.data(), sizeof(int) * batch, hipMemcpyHostToDevice, S.P.stream));
+            hipLaunchKernelGGL(k_fill_qd, dim3(S.P.Npad, batch), dim3(128), 0, S.P.stream, S.K, strideK, S.P.ld, S.P.N, S.P.Npad, 99u + rep);
+            hipLaunchKernelGGL(k_fill_qd, dim3(S.P.Npad, batch), dim3(128), 0, S.P.stream, K2, strideK, S.P.ld, S.P.N, S.P.Npad, 99u + rep);
+            // pivots of the instances the mask leaves out are never written: give both copies the same content
+            SQPHIP_HIP_OK(hipMemsetAsync(S.dinv, 0, sizeof(double) * (size_t)batch * S.P.Npad, S.P.stream));
+            SQPHIP_HIP_OK(hipMemsetAsync(dinv2, 0, sizeof(double) * (size_t)batch * S.P.Npad, S.P.stream));
+            S.P.aux = aux;
+            ldlt_factor(S.P, S.K, S.dinv, phase, 1, nullptr);
+            S.P.aux = nullptr;
+            ldlt_factor(S.P, K2, dinv2, phase, 1, nullptr);
+            S.P.aux = aux;
+            SQPHIP_HIP_OK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long), S.P.stream));
+            hipLaunchKernelGGL(k_maxdiff, dim3(2048), dim3(256), 0, S.P.stream, S.K, K2, nk, S.P.ld, cnt);
+            hipLaunchKernelGGL(k_maxdiff, dim3(64), dim3(256), 0, S.P.stream, S.dinv, dinv2, (size_t)batch * S.P.Npad, 0, cnt);
+            unsigned long long h = 0;
+            SQPHIP_HIP_OK(hipMemcpyAsync(&h, cnt, sizeof h, hipMemcpyDeviceToHost, S.P.stream));
+            SQPHIP_HIP_OK(hipStreamSynchronize(S.P.stream));
+            if (h) { ++bad_reps; fprintf(stderr, "sqphip_ldlt_stress: rep %d: %llu entries differ\n", rep, h); }
+        }
+        *mismatches = bad_reps;
+        hipFree(K2); hipFree(dinv2); hipFree(phase); hipFree(cnt);
+        return SQPHIP_OK;
+    } catch (const std::string &e) {
+        fprintf(stderr, "sqphip: %s\n", e.c_str());
+        return SQPHIP_EHIP;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // fp64 MFMA issue-rate probe: every wave runs `iters` x 4 independent v_mfma_f64_16x16x4_f64 from
 // registers (no memory traffic).  Gives the on-box ceiling the LDL^T roofline is quoted against.
 namespace {

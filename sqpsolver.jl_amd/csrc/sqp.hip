@@ -165,7 +165,9 @@ __global__ __launch_bounds__(TPB) void k_sqp_begin(DV d)
 {
     const int inst = blockIdx.x;
     SQP_PTRS
-    if (S.started || S.done) return;
+    const bool go = !(S.started || S.done);
+    __syncthreads();                 // every thread has read the gate before any thread changes the state
+    if (!go) return;
     __shared__ double fsh;
     acopf_eval(d, inst, x, 1.0, nullptr, &fsh, nullptr, E, nullptr, nullptr);
     __syncthreads();
@@ -191,7 +193,9 @@ __global__ __launch_bounds__(TPB) void k_sqp_lp_finish(DV d)
 {
     const int inst = blockIdx.x;
     SQP_PTRS
-    if (S.done || S.stage != ST_LP || !qp_final(d, inst)) return;
+    const bool go = !(S.done || S.stage != ST_LP || !qp_final(d, inst));
+    __syncthreads();                 // gate read by every thread before thread 0 moves the stage on
+    if (!go) return;
     const double *op = d.op + on, *ol = d.olam + om, *oU = d.omxU + on, *oL = d.omxL + on;
     auto dz = [](double v) { return fabs(v) < 1e-10 ? 0.0 : v; };   // utils.jl:16-22
     for (int j = threadIdx.x; j < d.n; j += TPB) { x[j] = dz(op[j]); mxU[j] = dz(oU[j]); mxL[j] = dz(oL[j]); }
@@ -210,7 +214,10 @@ __global__ __launch_bounds__(TPB) void k_sqp_top(DV d)
 {
     const int inst = blockIdx.x;
     SQP_PTRS
-    if (S.done || !S.started || S.stage != ST_TOP || S.budget <= 0) return;
+    const bool go = !(S.done || !S.started || S.stage != ST_TOP || S.budget <= 0);
+    const int step_acceptance = S.step_acceptance, fr = S.fr;
+    __syncthreads();                 // gate (and the flags used below) read by every thread before any write
+    if (!go) return;
     if (threadIdx.x == 0) { S.stage = ST_QP; S.it_ipm = 0; }
     __syncthreads();
     if (S.iter > d.max_iter) {                            // sqp.jl:215-224
@@ -219,7 +226,7 @@ __global__ __launch_bounds__(TPB) void k_sqp_top(DV d)
         finalize(d, inst, S, x);
         return;
     }
-    if (S.step_acceptance) {                              // :134-138, sqp.jl:86-104
+    if (step_acceptance) {                                // :134-138, sqp.jl:86-104
         const double hs = d.literal_quirks ? 1.0 : -1.0;
         for (int i = threadIdx.x; i < d.m; i += TPB) hlam[i] = hs * lam[i];
         __syncthreads();
@@ -236,7 +243,7 @@ __global__ __launch_bounds__(TPB) void k_sqp_top(DV d)
     double *xk = d.xk + on, *cin = d.cin + on, *bE = d.bE + om;
     for (int j = threadIdx.x; j < d.n; j += TPB) { xk[j] = x[j]; cin[j] = df[j]; }
     for (int i = threadIdx.x; i < d.m; i += TPB) bE[i] = E[i];
-    if (threadIdx.x == 0) qp_request(I, S.fr ? SQPHIP_MODE_FR : SQPHIP_MODE_QP, S.Delta, S.mu);
+    if (threadIdx.x == 0) qp_request(I, fr ? SQPHIP_MODE_FR : SQPHIP_MODE_QP, S.Delta, S.mu);
 }
 
 // q(p) of sqp_trust_region.jl:487-508 (with_step = true); tmpx/tmpE are scratch
@@ -276,7 +283,12 @@ __global__ __launch_bounds__(TPB) void k_sqp_mid(DV d)
 {
     const int inst = blockIdx.x;
     SQP_PTRS
-    if (S.done || S.stage != ST_QP || !qp_final(d, inst)) return;
+    const bool go = !(S.done || S.stage != ST_QP || !qp_final(d, inst));
+    // snapshot of the flags the branches below test: thread 0 changes S.fr / S.step_acceptance inside those
+    // branches, and a wave that reads them late must not take a different path from the one that wrote them
+    const int fr = S.fr, step_acceptance = S.step_acceptance;
+    __syncthreads();
+    if (!go) return;
     const double *op = d.op + on, *ol = d.olam + om, *oU = d.omxU + on, *oL = d.omxL + on;
     // compute_step! :373-378
     for (int j = threadIdx.x; j < d.n; j += TPB) { ps[j] = op[j]; pmxL[j] = oL[j] - mxL[j]; pmxU[j] = oU[j] - mxU[j]; }
@@ -299,7 +311,7 @@ __global__ __launch_bounds__(TPB) void k_sqp_mid(DV d)
             return;
         }
     } else if (st == SQPHIP_MOI_LOCALLY_INFEASIBLE) {
-        if (S.fr) {                                                    // :152-159
+        if (fr) {                                                      // :152-159
             if (threadIdx.x == 0) S.ret = S.prim_infeas <= d.tol_infeas ? 6 : 2;
             __syncthreads();
             finalize(d, inst, S, x);
@@ -316,14 +328,14 @@ __global__ __launch_bounds__(TPB) void k_sqp_mid(DV d)
         finalize(d, inst, S, x);
         return;
     }
-    if (S.step_acceptance) {                                           // :180-182, sqp.jl:170-183 alpha = 0
+    if (step_acceptance) {                                             // :180-182, sqp.jl:170-183 alpha = 0
         const double v = viol1(d, E, gL, gU, x, xL, xU);
-        if (threadIdx.x == 0) S.phi = S.fr ? v : S.f + S.mu * v;
+        if (threadIdx.x == 0) S.phi = fr ? v : S.f + S.mu * v;
     }
     __syncthreads();
     push_trace(d, inst, S, pn);                                        // :184
     if (pn <= d.tol_direction) {                                       // :187-196
-        if (S.fr) {
+        if (fr) {
             if (threadIdx.x == 0) { S.fr = 0; S.iter += 1; S.stage = ST_TOP; S.budget -= 1; }
         } else {
             if (threadIdx.x == 0) S.ret = 0;
@@ -333,7 +345,7 @@ __global__ __launch_bounds__(TPB) void k_sqp_mid(DV d)
         return;
     }
     if (S.prim_infeas <= d.tol_infeas && S.dual_infeas <= d.tol_residual && !isapprox_d(S.Delta, pn) &&
-        !S.fr) {                                                       // :198-204
+        !fr) {                                                       // :198-204
         if (threadIdx.x == 0) S.ret = 0;
         __syncthreads();
         finalize(d, inst, S, x);
@@ -346,9 +358,9 @@ __global__ __launch_bounds__(TPB) void k_sqp_mid(DV d)
     acopf_eval(d, inst, tmpx, 1.0, nullptr, &fsh, nullptr, tmpE, nullptr, nullptr);
     __syncthreads();
     const double c_k = viol1(d, tmpE, gL, gU, tmpx, xL, xU);
-    const double phi_k = S.fr ? c_k : fsh + S.mu * c_k;
+    const double phi_k = fr ? c_k : fsh + S.mu * c_k;
     double ared = S.phi - phi_k, pred = 1.0, q0 = 0.0;
-    if (!S.fr) {
+    if (!fr) {
         q0 = S.mu * viol1(d, E, gL, gU, x, xL, xU);                    // compute_qmodel(sqp, false)
         const double qk = qmodel_step(d, inst, S, ps, x, df, E, jv, hv, gL, gU, xL, xU, tmpx, tmpE);
         pred = q0 - qk;
@@ -361,7 +373,7 @@ __global__ __launch_bounds__(TPB) void k_sqp_mid(DV d)
             S.step_acceptance = 1;
         }
     } else {
-        if (d.use_soc && c_k > 0 && !S.fr) {                           // :544-549 -> sub_optimize_soc! :341-360
+        if (d.use_soc && c_k > 0 && !fr) {                           // :544-549 -> sub_optimize_soc! :341-360
             for (int j = threadIdx.x; j < d.n; j += TPB) tmpx[j] = x[j] + ps[j];
             __syncthreads();
             acopf_eval(d, inst, tmpx, 1.0, nullptr, nullptr, nullptr, Esoc, nullptr, nullptr);
@@ -397,7 +409,10 @@ __global__ __launch_bounds__(TPB) void k_sqp_soc_finish(DV d)
 {
     const int inst = blockIdx.x;
     SQP_PTRS
-    if (S.done || S.stage != ST_SOC || !qp_final(d, inst)) return;
+    const bool go = !(S.done || S.stage != ST_SOC || !qp_final(d, inst));
+    const int fr = S.fr;
+    __syncthreads();
+    if (!go) return;
     const double *op = d.op + on;
     for (int j = threadIdx.x; j < d.n; j += TPB) { psoc[j] = ps[j] + op[j]; tmpx[j] = x[j] + ps[j] + op[j]; }
     __syncthreads();
@@ -405,7 +420,7 @@ __global__ __launch_bounds__(TPB) void k_sqp_soc_finish(DV d)
     acopf_eval(d, inst, tmpx, 1.0, nullptr, &fsh, nullptr, tmpE, nullptr, nullptr);
     __syncthreads();
     const double c_s = viol1(d, tmpE, gL, gU, tmpx, xL, xU);
-    const double phi_soc = S.fr ? c_s : fsh + S.mu * c_s;
+    const double phi_soc = fr ? c_s : fsh + S.mu * c_s;
     const double ared = S.phi - phi_soc;
     const double qs = qmodel_step(d, inst, S, psoc, x, df, E, jv, hv, gL, gU, xL, xU, tmpx, tmpE);
     const double pred = S.q0 - qs;

@@ -360,3 +360,46 @@ def test_matpower_case_file_runs_through_the_device_path():
         tol = TOL if ro["status"] == 0 else TOL_TRAJ
         assert rel(rg["x"], ro["x"]) < tol and abs(rg["obj_val"] - ro["obj_val"]) <= tol * abs(ro["obj_val"])
     ctx.close()
+
+
+# ------------------------------------------------------------------ scheduling must not change the numbers
+def test_lookahead_schedule_is_bitwise_equal_to_single_stream():
+    """Two-stream look-ahead vs everything on one stream, random phase masks, batch multiple of 8 (XCD-aware tile
+    map): the factors must agree in every bit."""
+    import ctypes as C
+    from sqpsolver_jl_amd import _lib
+    L = _lib.lib()
+    L.sqphip_ldlt_stress.argtypes = [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_int32)]
+    for N, B, reps in ((700, 16, 6), (1500, 8, 3)):
+        m = C.c_int32(-1)
+        assert L.sqphip_ldlt_stress(0, B, N, reps, C.byref(m)) == 0
+        assert m.value == 0
+
+
+def test_batched_run_is_reproducible_bit_for_bit():
+    """The same batch (8 instances: the size that takes the XCD-aware map and fills the stage kernels with
+    concurrent workgroups) solved twice gives identical iterates, traces and work counters.  Guards the per-instance
+    state machine against gate races (a wave reading S.stage after thread 0 moved it on)."""
+    nb, ng, nl, seed = CASES["case14"]
+    base = acopf_synth(nb, ng, nl, seed)
+    nets = [base] + [contingency(base, s, seed) for s in range(1, 8)]
+    lays = [acopf_layout(nt) for nt in nets]
+    opts = pkg.default_options(max_iter=12, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=1)
+
+    def run():
+        ctx = pkg.Context(lays[0].n, lays[0].m, lays[0].num_linear, lays[0].jrow, lays[0].jcol, lays[0].hrow, lays[0].hcol,
+                          lays[0].xL, lays[0].xU, lays[0].gL, lays[0].gU, opts, batch=len(nets))
+        ctx.acopf_attach(base, lays[0])
+        for b in range(len(nets)):
+            ctx.acopf_set_instance(b, nets[b], lays[b])
+        ctx.sqp_reset(); ctx.sqp_run(0)
+        xs = [ctx.sqp_get(b)["x"].copy() for b in range(len(nets))]
+        tr = [[(r["iter"], r["accepted"], r["fr"], r["sub_status"], r["ipm_iters"]) for r in ctx.sqp_trace(b)]
+              for b in range(len(nets))]
+        c = ctx.counters(); ctx.close()
+        return xs, tr, (c["n_qp"], c["n_ipm_iter"], c["n_factor"])
+
+    a, b = run(), run()
+    assert a[2] == b[2] and a[1] == b[1]
+    for x, y in zip(a[0], b[0]):
+        assert np.array_equal(x, y)
