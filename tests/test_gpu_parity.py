@@ -403,3 +403,27 @@ def test_batched_run_is_reproducible_bit_for_bit():
     assert a[2] == b[2] and a[1] == b[1]
     for x, y in zip(a[0], b[0]):
         assert np.array_equal(x, y)
+
+
+def test_batch_of_eight_matches_oracle_instance_by_instance():
+    """Batch 8 (XCD-aware tile map, eight concurrent stage workgroups): every instance against the oracle."""
+    nb, ng, nl, seed = CASES["case14"]
+    base = acopf_synth(nb, ng, nl, seed)
+    nets = [base] + [contingency(base, s, seed) for s in range(1, 8)]
+    lays = [acopf_layout(nt) for nt in nets]
+    kw = dict(max_iter=40, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=0)
+    ctx = pkg.Context(lays[0].n, lays[0].m, lays[0].num_linear, lays[0].jrow, lays[0].jcol, lays[0].hrow, lays[0].hcol,
+                      lays[0].xL, lays[0].xU, lays[0].gL, lays[0].gU, pkg.default_options(**kw), batch=8)
+    ctx.acopf_attach(base, lays[0])
+    for b in range(8):
+        ctx.acopf_set_instance(b, nets[b], lays[b])
+    ctx.sqp_reset(); ctx.sqp_run(0)
+    for b in range(8):
+        ro = O.sqp_solve(O.problem_acopf(nets[b], lays[b]), O.default_options(**kw))
+        rg = ctx.sqp_get(b); tr = ctx.sqp_trace(b)
+        assert (rg["status"], rg["iter"]) == (ro["status"], ro["iter"]), b
+        assert [(a["iter"], a["accepted"], a["fr"], a["sub_status"]) for a in ro["trace"]] == \
+               [(c["iter"], c["accepted"], c["fr"], c["sub_status"]) for c in tr], b
+        tol = TOL if ro["status"] == 0 else TOL_TRAJ
+        assert rel(rg["x"], ro["x"]) < tol and abs(rg["obj_val"] - ro["obj_val"]) <= tol * abs(ro["obj_val"]), b
+    ctx.close()
