@@ -248,6 +248,7 @@ __global__ __launch_bounds__(TPB) void k_ipm_prepare(DV d)
         return;
     }
     const double hsc = st.hsc;
+    const int n_acc_prev = st.n_acc;     // read here: thread 0 updates it below, after the reductions' barriers
     hess_mul(d, inst, hsc, p, rd);
     jac_mul(d, inst, p, rp);
     __syncthreads();
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(TPB) void k_ipm_prepare(DV d)
     const double sd = fmax(100.0, dl1 / (double)(d.n + d.m)) / 100.0;
     const double e0 = fmax(fmax(rdn / sd, rpn), cmax / sd);
     // converged, or acceptable: 8 consecutive iterates within 100 x tol
-    const int n_acc = e0 <= 100.0 * d.ipm_tol ? st.n_acc + 1 : 0;
+    const int n_acc = e0 <= 100.0 * d.ipm_tol ? n_acc_prev + 1 : 0;
     if (e0 <= d.ipm_tol || n_acc >= 8) {
         if (threadIdx.x == 0) { st.rc = 0; d.phase[inst] = PH_DONE; }
         return;
@@ -463,8 +464,9 @@ __global__ __launch_bounds__(TPB) void k_refine(DV d, int last)
         const double r = rhs[d.n + i] - (wN[d.n + i] - dd * sol[d.n + i]);
         wN[d.n + i] = r; en = fmax(en, fabs(r));
     }
+    const int refine_it = st.refine_it;      // read before the reduction's barriers, written by thread 0 below
     en = block_reduce<OpMax>(en);
-    const bool stop = last || st.refine_it >= 1 || !(en > 1e-11 * st.rn);
+    const bool stop = last || refine_it >= 1 || !(en > 1e-11 * st.rn);
     if (!stop)
         for (int i = threadIdx.x; i < d.Npad; i += TPB) xv[i] = i < d.N ? wN[i] : 0.0;
     if (threadIdx.x == 0) {
