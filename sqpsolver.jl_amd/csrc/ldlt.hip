@@ -115,6 +115,7 @@ __device__ __forceinline__ void panel_trsm_wave(const double *__restrict__ Lkk, 
                                                 const double *__restrict__ di, double *Ls, double (*xs)[TB][64], int lane,
                                                 const double *__restrict__ yk, double (*red)[TB][64])
 {
+    static_assert(TB == 1 || TB == 2, "one or two row tiles per workgroup");
     const int half = lane >> 5, r2 = lane & 31, cg = 2 * W + half;
     // packed strict lower triangle: column j holds rows c > j at Ls[tri(j) + c - j - 1]
 #pragma unroll
@@ -127,33 +128,29 @@ __device__ __forceinline__ void panel_trsm_wave(const double *__restrict__ Lkk, 
             if (r > c) Ls[c * 63 - c * (c - 1) / 2 + r - c - 1] = v;
         }
     }
-    // row tiles t >= ntile (below the last one) are loaded from whatever follows in the buffer -- the reads
-    // stay inside this instance's matrix because k < T-1 -- computed on, and never stored
-    double x[TB][2][8];
+    // Row tile 0 in xa, row tile 1 (TB == 2) in xb: [h * 8 + q] = row r2 + 32 h, column 8 q + cg.  Two separate
+    // 16-entry arrays with explicit code per tile: a [TB][2][8] array indexed by a tile loop stays in scratch.
+    // A second tile below the last row tile (ntile == 1) is loaded from whatever follows in the buffer -- the
+    // reads stay inside this instance's matrix because k < T-1 -- computed on, and never stored.
+    double xa[16], xb[16];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const double *Aq = A + (long)(8 * q + cg) * ld + r2;
-#pragma unroll
-        for (int t = 0; t < TB; ++t) {
-            x[t][0][q] = Aq[64 * t];
-            x[t][1][q] = Aq[64 * t + 32];
-        }
+        xa[q] = Aq[0]; xa[8 + q] = Aq[32];
+        if (TB == 2) { xb[q] = Aq[64]; xb[8 + q] = Aq[96]; }
     }
 #pragma unroll
     for (int j = 0; j < 63; ++j) {
         if (((j & 7) >> 1) == W) {                  // the wave that owns column j; its half (j & 1) publishes
             if (half == (j & 1)) {
-#pragma unroll
-                for (int t = 0; t < TB; ++t) {
-                    xs[j & 1][t][r2] = x[t][0][j >> 3];
-                    xs[j & 1][t][r2 + 32] = x[t][1][j >> 3];
-                }
+                xs[j & 1][0][r2] = xa[j >> 3]; xs[j & 1][0][r2 + 32] = xa[8 + (j >> 3)];
+                if (TB == 2) { xs[j & 1][1][r2] = xb[j >> 3]; xs[j & 1][1][r2 + 32] = xb[8 + (j >> 3)]; }
             }
         }
         __syncthreads();             // also orders the Ls stores of the prologue before their first use
-        double xj[TB][2];
-#pragma unroll
-        for (int t = 0; t < TB; ++t) { xj[t][0] = xs[j & 1][t][r2]; xj[t][1] = xs[j & 1][t][r2 + 32]; }
+        const double a0 = xs[j & 1][0][r2], a1 = xs[j & 1][0][r2 + 32];
+        double b0 = 0.0, b1 = 0.0;
+        if (TB == 2) { b0 = xs[j & 1][1][r2]; b1 = xs[j & 1][1][r2 + 32]; }
         // an opaque zero added to this step's L_kk addresses: without it the scheduler hoists the (read-only
         // after the prologue) L_kk reads of many later steps above the barriers and spills
         int z = 0;
@@ -170,48 +167,49 @@ __device__ __forceinline__ void panel_trsm_wave(const double *__restrict__ Lkk, 
                 const double lv = Ls[act ? tri + 8 * q + cg : 0];   // index clamped for the idle lanes
                 l = act ? lv : 0.0;
             }
-#pragma unroll
-            for (int t = 0; t < TB; ++t) {
-                x[t][0][q] -= xj[t][0] * l;
-                x[t][1][q] -= xj[t][1] * l;
-            }
+            xa[q] -= a0 * l; xa[8 + q] -= a1 * l;
+            if (TB == 2) { xb[q] -= b0 * l; xb[8 + q] -= b1 * l; }
         }
         // pin this step's updates here: the scheduler otherwise sinks multiply-adds of far columns across
         // later barriers and keeps their x_j / L operands alive in scratch
 #pragma unroll
-        for (int t = 0; t < TB; ++t)
-#pragma unroll
-            for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(x[t][0][q]), "+v"(x[t][1][q]));
+        for (int q = 0; q < 16; ++q) {
+            asm volatile("" : "+v"(xa[q]));
+            if (TB == 2) asm volatile("" : "+v"(xb[q]));
+        }
     }
-    double part[TB][2];
-#pragma unroll
-    for (int t = 0; t < TB; ++t) part[t][0] = part[t][1] = 0.0;
+    double pa0 = 0.0, pa1 = 0.0, pb0 = 0.0, pb1 = 0.0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int c = 8 * q + cg;
         double *Wq = Wout + (long)c * Npad + r2, *Aq = A + (long)c * ld + r2;
         const double dc = di[c];
         const double yc = yk ? yk[c] : 0.0;
-#pragma unroll
-        for (int t = 0; t < TB; ++t) {
-            const double l0 = x[t][0][q] * dc, l1 = x[t][1][q] * dc;
-            if (TB == 1 || t < ntile) {
-                Wq[64 * t] = x[t][0][q]; Wq[64 * t + 32] = x[t][1][q];
-                Aq[64 * t] = l0; Aq[64 * t + 32] = l1;
+        {
+            const double l0 = xa[q] * dc, l1 = xa[8 + q] * dc;
+            Wq[0] = xa[q]; Wq[32] = xa[8 + q];
+            Aq[0] = l0; Aq[32] = l1;
+            pa0 += l0 * yc; pa1 += l1 * yc;
+        }
+        if (TB == 2) {
+            const double l0 = xb[q] * dc, l1 = xb[8 + q] * dc;
+            if (ntile > 1) {
+                Wq[64] = xb[q]; Wq[96] = xb[8 + q];
+                Aq[64] = l0; Aq[96] = l1;
             }
-            part[t][0] += l0 * yc; part[t][1] += l1 * yc;
+            pb0 += l0 * yc; pb1 += l1 * yc;
         }
     }
     // fused forward elimination: this lane's share of (L_ik y_k)[row], combined over the 8 column groups by
     // the kernel body
     if (yk) {
-#pragma unroll
-        for (int t = 0; t < TB; ++t) { red[cg][t][r2] = part[t][0]; red[cg][t][r2 + 32] = part[t][1]; }
+        red[cg][0][r2] = pa0; red[cg][0][r2 + 32] = pa1;
+        if (TB == 2) { red[cg][1][r2] = pb0; red[cg][1][r2 + 32] = pb1; }
     }
 }
 
 template <int TB>
-__global__ __launch_bounds__(256) void k_panel_trsm(double *__restrict__ K, long strideK, int ld,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TB == 1 ? 4 : 2, TB == 1 ? 4 : 2))) void k_panel_trsm(double *__restrict__ K, long strideK, int ld,
                                                    const double *__restrict__ dinv,
                                                    double *__restrict__ Wbuf, int Npad, int k, int T,
                                                    const int *__restrict__ phase, int want,
@@ -598,8 +596,9 @@ static void launch_panel(const LdltPlan &P, hipStream_t s, double *K, double *di
     hipLaunchKernelGGL(k_diag_factor, dim3(P.B), dim3(256), 0, s, K, strideK, P.ld, dinv, P.Npad, c, phase, want, b, v);
     const int rem = P.T - c - 1;
     if (rem <= 0) return;
-    // one row tile per workgroup: the TB = 2 / 4 instantiations of the template halve the LDS traffic again but
-    // the fully unrolled substitution then spills inside the step loop (30 ms instead of 12 per factorisation)
+    // one row tile per workgroup.  The TB = 2 instantiation (two row tiles share every L_kk read and every
+    // barrier) is correct and spill-free but measured slower: 15.4 instead of 12.0 ms per factorisation, the
+    // longer steps of half as many workgroups hide less latency.
     hipLaunchKernelGGL(k_panel_trsm<1>, dim3(rem, P.B), dim3(256), 0, s, K, strideK, P.ld, dinv,
                        P.Wbuf + (long)wslot * strideW, P.Npad, c, P.T, phase, want, b);
 }
