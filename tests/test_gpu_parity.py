@@ -427,3 +427,21 @@ def test_batch_of_eight_matches_oracle_instance_by_instance():
         tol = TOL if ro["status"] == 0 else TOL_TRAJ
         assert rel(rg["x"], ro["x"]) < tol and abs(rg["obj_val"] - ro["obj_val"]) <= tol * abs(ro["obj_val"]), b
     ctx.close()
+
+
+# ------------------------------------------------------------------ edge: a problem without constraint rows
+def test_bound_constrained_problem_without_rows():
+    """m = 0 (empty Jacobian, no multipliers): min (x0-3)^2 + (x1+1)^2 + x0 x1 on [0,2]^2 -> x* = (2, 0), f* = 2,
+    through the drop-in seat (host `SqpTR` + `sqphip_qp_solve`)."""
+    from sqpsolver_jl_amd import host as H
+    f = lambda x: (x[0] - 3) ** 2 + (x[1] + 1) ** 2 + x[0] * x[1]
+    gr = lambda x: np.array([2 * (x[0] - 3) + x[1], 2 * (x[1] + 1) + x[0]])
+    hs = lambda x, s, lam: np.array([2.0 * s, 1.0 * s, 2.0 * s])
+    m = H.Model(2, 0, [0, 0], [2, 2], [], [], [], [(1, 1), (2, 1), (2, 2)], f, lambda x: np.zeros(0), gr,
+                lambda x: np.zeros(0), hs, 0)
+    m.x = np.array([1.0, 1.0])
+    H.optimize(m)
+    assert m.status == 0
+    assert np.allclose(m.x, [2.0, 0.0], atol=1e-7) and abs(m.obj_val - 2.0) < 1e-7
+    # grad f(x*) = (-2, 4) = mult_x_L - mult_x_U in the Model's output convention (both >= 0, MOI_wrapper.jl:1395-1453)
+    assert np.allclose(m.mult_x_U, [2.0, 0.0], atol=1e-6) and np.allclose(m.mult_x_L, [0.0, 4.0], atol=1e-6)
