@@ -642,7 +642,7 @@ static void read_counters(Ctx &C)
 //   k_ipm_prepare phase PREP      -> convergence test, barrier update, diagonals -> FACTOR
 //   assemble, rhs, LDL^T (with the forward elimination of the rhs fused in), inertia
 //                                 -> FACTOR -> SOLVE (or delta_w bump, stays FACTOR)
-//   backward solve, refine, full solve, refine      -> SOLVE -> STEP
+//   backward solve, residual check                  -> SOLVE -> STEP
 //   k_ipm_step    phase STEP      -> update -> PREP
 //   k_ipm_prepare again           -> so that a converged instance is recognised in this sweep
 void ipm_sweep(Ctx &C, bool sqp_level)
@@ -663,10 +663,11 @@ void ipm_sweep(Ctx &C, bool sqp_level)
     if (C.tm.enabled) { hipEventRecord(ev.second, s); C.tm.pending_factor.push_back(ev); }
     hipLaunchKernelGGL(k_inertia, gB, bT, 0, s, d);
     if (C.tm.enabled) { ev = C.tm.get(); hipEventRecord(ev.first, s); }
-    for (int r = 0; r < 2; ++r) {      // plain solve (backward half only) + at most one refinement step
-        ldlt_solve(C.plan, d.K, d.dinv, d.xv, d.vv, d.phase, PH_SOLVE, r == 0);
-        hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, r == 1 ? 1 : 0);
-    }
+    // backward half of the solve (the forward half happened inside the factorisation), then the residual against
+    // the sparse operator.  No iterative refinement: one step of it (the policy until late in round 1, two more
+    // launch chains per sweep) changed no iteration count on any test problem -- see oracle/qp_ipm.c, kkt_solve.
+    ldlt_solve(C.plan, d.K, d.dinv, d.xv, d.vv, d.phase, PH_SOLVE, true);
+    hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, 1);
     if (C.tm.enabled) { hipEventRecord(ev.second, s); C.tm.pending_solve.push_back(ev); }
     hipLaunchKernelGGL(k_ipm_step, gB, bT, 0, s, d);
     hipLaunchKernelGGL(k_ipm_prepare, gB, bT, 0, s, d);
