@@ -19,6 +19,10 @@ namespace sqphip {
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
+// k-major 64-wide LDS image: an XOR of 16 on the in-row index for odd k puts the two k-rows read by one 32-lane
+// group on disjoint bank halves
+__device__ __forceinline__ int swz(int k, int i) { return k * 64 + (i ^ ((k & 1) << 4)); }
+
 // ---------------------------------------------------------------------------------------------
 // tile (k,k): unblocked right-looking LDL^T by one 256-thread workgroup.  Thread (r, W) = (tid & 63,
 // tid >> 6) owns row r of the tile restricted to the columns c = W (mod 4): 16 entries in registers.
@@ -255,6 +259,123 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TB == 1 ? 4
 }
 
 // ---------------------------------------------------------------------------------------------
+// MFMA panel solve (the variant ldlt_factor launches).  One WAVE per 32 x 64 half tile of (i,k), two tiles per
+// workgroup sharing a k-major LDS image of L_kk.  The wave keeps its half tile in the MFMA accumulator layout
+//     X[cb][tr][rr]  <->  row 32 h + 16 tr + l15,  column 16 cb + l4 + 4 rr   (l15 = lane & 15, l4 = lane >> 4)
+// (a whole tile per wave needs 234 VGPRs and then finds no room beside the resident bulk-update workgroups:
+// 153 us per call instead of 32; half a tile fits in 128)
+// and works through the four 16-column blocks cb = 0..3:
+//   1. substitution inside the block (15 dependent steps): x_j lives in the lanes with l4 == (j & 3); it is
+//      broadcast to the other three lane groups of the same rows by a wave shuffle (no LDS round trip, no
+//      barrier -- the whole tile belongs to one wave), every lane then updates its columns > j of the block;
+//   2. the finished block updates the blocks to its right on the MFMA pipe: D[c][row] -= sum_k L[c][k] X[row][k]
+//      with A = L (from the LDS image) and B = X -- and the accumulator layout of X *is* the B-operand layout
+//      (column 4 ks + l4 of block cb is accumulator element rr = ks), so no data moves between the two phases.
+// 3/4 of the multiply-adds run on the MFMA pipe, the dependent chain is 60 shuffle steps instead of 63
+// barrier + LDS steps.  Arithmetic: the same substitution; the contributions of earlier blocks are summed in MFMA
+// order (4 at a time) instead of one by one.  Also performs the fused forward elimination (b_i -= L_ik y_k).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_panel_trsm_mfma(double *__restrict__ K, long strideK, int ld, const double *__restrict__ dinv,
+                       double *__restrict__ Wbuf, int Npad, int k, int T, const int *__restrict__ phase, int want,
+                       double *__restrict__ bvec)
+{
+    const int inst = blockIdx.y;
+    if (phase && phase[inst] != want) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int i = k + 1 + blockIdx.x * 2 + (wave >> 1);   // this wave's row tile ...
+    const int rh = (wave & 1) * 32;                       // ... and its half of the rows (2 x 16)
+    double *Kb = K + (long)inst * strideK;
+    const double *Lkk = Kb + (long)(k * 64) * ld + k * 64;
+    __shared__ double Ls[64 * 64];                        // Ls[swz(kcol, c)] = L_kk[c][kcol]  (k-major image)
+    {
+        const int ii = (tid & 31) * 2, kk0 = tid >> 5;    // 8 columns per pass, 8 passes
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int kk = pass * 8 + kk0;
+            *reinterpret_cast<d2 *>(&Ls[swz(kk, ii)]) = *reinterpret_cast<const d2 *>(Lkk + (long)kk * ld + ii);
+        }
+    }
+    __syncthreads();
+    if (i >= T) return;                                   // no further barriers below
+    double *A = Kb + (long)(k * 64) * ld + i * 64 + rh;
+    double *Wout = Wbuf + (long)inst * Npad * 64 + i * 64 + rh;   // Wbuf already points at this sub-panel's slot
+    const double *di = dinv + (long)inst * Npad + k * 64;
+    d4 X[4][2];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const double *Ac = A + (long)(16 * cb + l4 + 4 * rr) * ld + l15;
+#pragma unroll
+            for (int tr = 0; tr < 2; ++tr) X[cb][tr][rr] = Ac[16 * tr];
+        }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        // 1. substitution inside block cb
+#pragma unroll
+        for (int j = 0; j < 15; ++j) {
+            const int J = 16 * cb + j;
+            double xj[2];
+#pragma unroll
+            for (int tr = 0; tr < 2; ++tr) xj[tr] = __shfl(X[cb][tr][j >> 2], l15 | ((j & 3) << 4));
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                if (4 * rr + 3 <= j) continue;                       // columns l4 + 4 rr <= j for every lane
+                const bool act = l4 + 4 * rr > j;
+                const double lv = Ls[swz(J, 16 * cb + l4 + 4 * rr)];  // L[c][J]
+                const double l = act ? lv : 0.0;
+#pragma unroll
+                for (int tr = 0; tr < 2; ++tr) X[cb][tr][rr] -= xj[tr] * l;
+            }
+            // pin the step (see panel_trsm_wave)
+#pragma unroll
+            for (int tr = 0; tr < 2; ++tr) asm volatile("" : "+v"(X[cb][tr]));
+        }
+        // 2. blocks to the right: X[cb2] -= X[cb] * L[cb2-block][cb-block]'
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int cb2 = cb + 1; cb2 < 4; ++cb2) {
+                const double a = -Ls[swz(16 * cb + 4 * ks + l4, 16 * cb2 + l15)];
+#pragma unroll
+                for (int tr = 0; tr < 2; ++tr)
+                    X[cb2][tr] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[cb][tr][ks], X[cb2][tr], 0, 0, 0);
+            }
+        }
+    }
+    // results: W = X, L = X D^-1; fused forward elimination: part[tr] = (L_ik y_k)[row 16 tr + l15]
+    const double *yk = bvec ? bvec + (long)inst * Npad + k * 64 : nullptr;
+    double part[2] = {0.0, 0.0};
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int c = 16 * cb + l4 + 4 * rr;
+            double *Wc = Wout + (long)c * Npad + l15, *Ac = A + (long)c * ld + l15;
+            const double dc = di[c];
+            const double yc = yk ? yk[c] : 0.0;
+#pragma unroll
+            for (int tr = 0; tr < 2; ++tr) {
+                const double x = X[cb][tr][rr], lx = x * dc;
+                Wc[16 * tr] = x;
+                Ac[16 * tr] = lx;
+                part[tr] += lx * yc;
+            }
+        }
+    if (bvec) {
+        double *bi = bvec + (long)inst * Npad + i * 64 + rh;
+#pragma unroll
+        for (int tr = 0; tr < 2; ++tr) {
+            double p = part[tr];
+            p += __shfl_xor(p, 16);
+            p += __shfl_xor(p, 32);
+            if (l4 == 0) bi[16 * tr + l15] -= p;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Schur update on fp64 MFMA.  A workgroup (4 waves) owns a run of `tpb` consecutive 64x64 tiles (ti,tj),
 // tj in [jlo,jhi), ti>=tj, in column-major tile order, and for each of them computes
 //   A[ti][tj] -= sum_{t<nsub} W_t[ti] * L[tj][kp+t]'      (nsub 64-wide sub-panels, inner depth 64*nsub)
@@ -269,7 +390,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TB == 1 ? 4
 // thousand cycles when the whole chip streams -- is paid once per run, not once per tile (a cycle-stamp
 // trace of the one-tile-per-workgroup version showed 8 k cycles of prologue + 3.5 k of first-fetch wait
 // per 16 k cycles of MFMA work; scripts/probes/trailing_trace.hip).
-__device__ __forceinline__ int swz(int k, int i) { return k * 64 + (i ^ ((k & 1) << 4)); }
 
 // cycle stamps of one wave per sampled workgroup (scripts/probes/trailing_trace.hip only)
 #ifdef SQPHIP_TRACE_TRAILING
@@ -599,8 +719,12 @@ static void launch_panel(const LdltPlan &P, hipStream_t s, double *K, double *di
     // one row tile per workgroup.  The TB = 2 instantiation (two row tiles share every L_kk read and every
     // barrier) is correct and spill-free but measured slower: 15.4 instead of 12.0 ms per factorisation, the
     // longer steps of half as many workgroups hide less latency.
-    hipLaunchKernelGGL(k_panel_trsm<1>, dim3(rem, P.B), dim3(256), 0, s, K, strideK, P.ld, dinv,
-                       P.Wbuf + (long)wslot * strideW, P.Npad, c, P.T, phase, want, b);
+    if (P.trsm_mfma)
+        hipLaunchKernelGGL(k_panel_trsm_mfma, dim3((rem + 1) / 2, P.B), dim3(256), 0, s, K, strideK, P.ld, dinv,
+                           P.Wbuf + (long)wslot * strideW, P.Npad, c, P.T, phase, want, b);
+    else
+        hipLaunchKernelGGL(k_panel_trsm<1>, dim3(rem, P.B), dim3(256), 0, s, K, strideK, P.ld, dinv,
+                           P.Wbuf + (long)wslot * strideW, P.Npad, c, P.T, phase, want, b);
 }
 
 // Two-level right-looking LDL^T: outer panels of R 64-wide sub-panels, so every pass over the

@@ -57,6 +57,7 @@ struct LdltPlan {
     hipStream_t stream = nullptr;   // main stream (everything but the panel look-ahead)
     hipStream_t aux = nullptr;      // panel factorisation of the next outer panel
     hipEvent_t ev[6] = {};          // start, panel[2], head[2], join
+    int trsm_mfma = 1;          // panel solve on the MFMA pipe, one wave per tile (SQPHIP_TRSM_MFMA=0: LDS substitution)
     int supertile = 8;          // tile columns per super-tile of the Schur-update schedule (SQPHIP_SUPERTILE; 1 = column-major)
     int kc = 16;                // k-columns per LDS stage of the Schur-update kernel (SQPHIP_KC = 16 | 32)
     int tpb_max = 1;            // longest run of tiles one Schur-update workgroup takes (SQPHIP_TPB): runs of 8
@@ -73,6 +74,7 @@ struct LdltPlan {
             hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, greatest);
         }
         if (const char *e = getenv("SQPHIP_OUTER")) { R = atoi(e); if (R < 1) R = 1; if (R > MAX_R) R = MAX_R; }
+        if (const char *e = getenv("SQPHIP_TRSM_MFMA")) trsm_mfma = atoi(e);
         if (const char *e = getenv("SQPHIP_SUPERTILE")) { supertile = atoi(e); if (supertile < 1) supertile = 1; }
         if (const char *e = getenv("SQPHIP_KC")) kc = atoi(e) == 32 ? 32 : 16;
         if (const char *e = getenv("SQPHIP_TPB")) { tpb_max = atoi(e); if (tpb_max < 1) tpb_max = 1; }
