@@ -594,7 +594,7 @@ static int ipm_run(ora_qp *q, const double *p_start)
     const double tol = q->opt.ipm_tol;
     const double mu_min = tol / 10.0;
     double mu = 1.0;
-    int n_acc = 0;
+    int n_acc = 0, n_acc2 = 0;
     double dw_prev = 0.0;
     int verbose = getenv("ORA_IPM_VERBOSE") != NULL;
     for (int it = 0; it < q->opt.ipm_max_iter; ++it) {
@@ -607,7 +607,11 @@ static int ipm_run(ora_qp *q, const double *p_start)
         /* acceptable termination: 8 consecutive iterates within 100 x tol (the monotone rule can crawl
          * just above the tolerance when round-off keeps triggering tiny inertia corrections) */
         n_acc = e0 <= 100.0 * tol ? n_acc + 1 : 0;
-        if (n_acc >= 8) { rc = 0; break; }
+        /* ... or 15 within 1000 x tol (Ipopt's acceptable_tol / acceptable_iter ratio): the fixed 1e-8 dual
+         * regularisation leaves a row residual of 1e-8 |dy| that full Newton steps cannot remove when the multiplier
+         * steps stay large (seen at trust-region radii ~1e-5: rp stalls at 1.9e-7) */
+        n_acc2 = e0 <= 1000.0 * tol ? n_acc2 + 1 : 0;
+        if (n_acc >= 8 || n_acc2 >= 15) { rc = 0; break; }
         /* barrier update */
         for (int k = 0; k < 20; ++k) {
             double emu = fmax(fmax(ms.rd / sd, ms.rp), ipm_compl_err(q, mu) / sd);

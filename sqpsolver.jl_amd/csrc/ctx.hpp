@@ -19,7 +19,7 @@ struct IpmState {
     double sf, rho_big, soft_w, hsc;
     // iteration
     double mu, tau, dw, dw_last, dw_floor, cn, relres, rn, e0;
-    int iter, rc, fac_attempt, dir_attempt, refine_it, n_acc;
+    int iter, rc, fac_attempt, dir_attempt, refine_it, n_acc, n_acc2;
     // outcome
     int status, ipm_iters, n_factor;
     double elastic;

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(TPB) void k_ipm_start(DV d)
     }
     if (threadIdx.x == 0) {
         st.sf = sf; st.soft_w = soft_w; st.hsc = (st.stage == 0 && use_obj) ? sf : 0.0;
-        st.mu = 1.0; st.iter = 0; st.rc = -1; st.dw_last = 0.0; st.dw = 0.0; st.dw_floor = 0.0; st.n_acc = 0;
+        st.mu = 1.0; st.iter = 0; st.rc = -1; st.dw_last = 0.0; st.dw = 0.0; st.dw_floor = 0.0; st.n_acc = 0; st.n_acc2 = 0;
         st.cn = 0.0;
         st.start = 0;
         d.phase[inst] = PH_PREP;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(TPB) void k_ipm_prepare(DV d)
         return;
     }
     const double hsc = st.hsc;
-    const int n_acc_prev = st.n_acc;     // read here: thread 0 updates it below, after the reductions' barriers
+    const int n_acc_prev = st.n_acc, n_acc2_prev = st.n_acc2;   // read here: thread 0 updates them below, after the reductions' barriers
     hess_mul(d, inst, hsc, p, rd);
     jac_mul(d, inst, p, rp);
     __syncthreads();
@@ -291,11 +291,12 @@ __global__ __launch_bounds__(TPB) void k_ipm_prepare(DV d)
     const double e0 = fmax(fmax(rdn / sd, rpn), cmax / sd);
     // converged, or acceptable: 8 consecutive iterates within 100 x tol
     const int n_acc = e0 <= 100.0 * d.ipm_tol ? n_acc_prev + 1 : 0;
-    if (e0 <= d.ipm_tol || n_acc >= 8) {
+    const int n_acc2 = e0 <= 1000.0 * d.ipm_tol ? n_acc2_prev + 1 : 0;     // ... or 15 within 1000 x tol
+    if (e0 <= d.ipm_tol || n_acc >= 8 || n_acc2 >= 15) {
         if (threadIdx.x == 0) { st.rc = 0; d.phase[inst] = PH_DONE; }
         return;
     }
-    if (threadIdx.x == 0) st.n_acc = n_acc;
+    if (threadIdx.x == 0) { st.n_acc = n_acc; st.n_acc2 = n_acc2; }
     // barrier update: mu <- max(mu_min, min(0.2 mu, mu^1.5)) while the barrier problem is solved
     double mu = st.mu;
     const double mu_min = d.ipm_tol / 10.0;
