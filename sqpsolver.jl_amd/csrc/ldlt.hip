@@ -6,12 +6,15 @@
 //
 // Layout: each instance owns a column-major Npad x Npad buffer (ld = Npad, Npad = 64*T); only the
 // lower triangle is meaningful, rows/cols >= N are identity padding so every kernel works on whole
-// 64x64 tiles.  Right-looking blocked algorithm, one panel of 64 columns per step k:
-//   k_diag_factor : tile (k,k) -> L_kk, 1/D_k            one wave per instance (VALU, registers)
-//   k_panel_trsm  : tiles (i,k), i>k -> L_ik, W_ik=L_ik D  one wave per tile  (VALU, registers)
-//   k_trailing    : tiles (i,j), i>=j>k: A_ij -= W_ik L_jk'  v_mfma_f64_16x16x4_f64, LDS-staged
-// The trailing update carries ~(1 - 3/(2T)) of the N^3/3 flops and is the kernel the roofline in
-// bench.py is quoted on.
+// 64x64 tiles.  Two-level right-looking blocked algorithm (ldlt_factor): outer panels of R = 4 sub-panels of 64
+// columns; per sub-panel k
+//   k_diag_factor     : tile (k,k) -> L_kk, 1/D_k                 4 waves, columns split over waves, LDS broadcast
+//   k_panel_trsm_mfma : tiles (i,k), i>k -> L_ik, W_ik = L_ik D   one wave per half tile in MFMA accumulator layout
+//   k_colupdate       : tile column k+1 of the same outer panel -= W L'  (left-looking, rank 64 j, MFMA)
+// and per outer panel
+//   k_trailing        : tiles (i,j), i>=j right of the panel: A_ij -= sum_t W_it L_jt'   rank 256, MFMA, LDS-staged
+// k_diag_factor / k_panel_trsm_mfma also carry a right-hand side through the elimination (fused forward solve).
+// The bulk update carries 87 % of the N^3/3 flops at N = 2813 and is the kernel the roofline in bench.py is quoted on.
 #include "sqphip_internal.hpp"
 
 namespace sqphip {
