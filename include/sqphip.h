@@ -118,6 +118,21 @@ int sqphip_tr_update(double ared, double pred, double delta, double pnorm_inf,
                      double delta_max, double tol_direction, int32_t *accept_out,
                      double *delta_out);
 
+/* sqp_line_search.jl:303-334 (compute_alpha; the line-search algorithm is unreachable upstream, kept for
+ * completeness of the merit path): backtracking Armijo search alpha <- tau * alpha while
+ * phi(alpha) > phi0 + eta * alpha * D, starting from 1; stops with is_valid = 0 once alpha < min_alpha.
+ * phi(alpha) is the caller's merit at x + alpha p (compute_phi needs eval_f / eval_g: host callbacks), so it
+ * comes in as a C callback.  Returns at once with alpha = 1, is_valid = 1 when pnorm_inf <= tol_direction. */
+typedef double (*sqphip_phi_fn)(double alpha, void *user);
+int sqphip_armijo_alpha(double phi0, double D, double eta, double tau, double min_alpha, double pnorm_inf,
+                        double tol_direction, sqphip_phi_fn phi, void *user, double *alpha, int32_t *is_valid);
+/* sqp_line_search.jl:270-294 (compute_mu_rule1! / rule2! / rule3!), vector penalty mu[m]:
+ *   t = (df'p + max(p'Hp/2, 0)) / max((1 - rho) * viol1, 1e-8)
+ *   rule 1: mu_i = max(mu_i, t, |lambda_i|);  rule 2: iter == 1 ? mu_i = t : mu_i = max(mu_i, |lambda_i|);
+ *   rule 3: mu_i = max(mu_i, |lambda_i|) */
+int sqphip_compute_mu_rule(int32_t rule, int64_t iter, double rho, double viol1, double dfp, double half_pHp,
+                           int64_t m, const double *lambda, double *mu);
+
 /* ---- device-resident batched SQP-TR over the built-in ACOPF evaluator --------------------------
  * (sqp_trust_region.jl:98-223 for every instance of the batch; callbacks of
  * MOI_wrapper.jl:1115-1146 replaced by HIP kernels over PowerModels-ACP-shaped data,

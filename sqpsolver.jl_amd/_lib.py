@@ -108,5 +108,5 @@ EXPORTS = [
     "sqphip_acopf_attach", "sqphip_acopf_set_instance", "sqphip_acopf_eval", "sqphip_sqp_reset",
     "sqphip_sqp_run", "sqphip_sqp_get", "sqphip_sqp_status", "sqphip_sqp_trace",
     "sqphip_get_counters", "sqphip_reset_counters", "sqphip_set_timing", "sqphip_ldlt_factor_host",
-    "sqphip_ldlt_solve_host", "sqphip_ldlt_bench", "sqphip_ldlt_stress", "sqphip_mfma_f64_peak",
+    "sqphip_ldlt_solve_host", "sqphip_ldlt_bench", "sqphip_ldlt_stress", "sqphip_mfma_f64_peak", "sqphip_armijo_alpha", "sqphip_compute_mu_rule",
 ]

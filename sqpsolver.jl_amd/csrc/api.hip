@@ -357,6 +357,42 @@ extern "C" int sqphip_tr_update(double ared, double pred, double delta, double p
     return SQPHIP_OK;
 }
 
+// sqp_line_search.jl:303-334
+extern "C" int sqphip_armijo_alpha(double phi0, double D, double eta, double tau, double min_alpha, double pnorm_inf,
+                                   double tol_direction, sqphip_phi_fn phi, void *user, double *alpha,
+                                   int32_t *is_valid)
+{
+    if (!phi || !alpha || !is_valid) return SQPHIP_EINVAL;
+    double a = 1.0;
+    int ok = 1;
+    if (!(pnorm_inf <= tol_direction)) {
+        double phi_x_p = phi(a, user);
+        while (phi_x_p > phi0 + eta * a * D) {
+            if (a < min_alpha) { ok = 0; break; }        // the step size can become too small
+            a *= tau;
+            phi_x_p = phi(a, user);
+        }
+    }
+    *alpha = a;
+    *is_valid = ok;
+    return SQPHIP_OK;
+}
+
+// sqp_line_search.jl:270-294
+extern "C" int sqphip_compute_mu_rule(int32_t rule, int64_t iter, double rho, double viol1, double dfp,
+                                      double half_pHp, int64_t m, const double *lambda, double *mu)
+{
+    if (rule < 1 || rule > 3 || m < 0 || (m > 0 && (!lambda || !mu))) return SQPHIP_EINVAL;
+    const double denom = std::fmax((1.0 - rho) * viol1, 1.0e-8);
+    const double t = (dfp + std::fmax(half_pHp, 0.0)) / denom;
+    for (int64_t i = 0; i < m; ++i) {
+        if (rule == 1) { mu[i] = std::fmax(mu[i], t); mu[i] = std::fmax(mu[i], std::fabs(lambda[i])); }
+        else if (rule == 2) mu[i] = iter == 1 ? t : std::fmax(mu[i], std::fabs(lambda[i]));
+        else mu[i] = std::fmax(mu[i], std::fabs(lambda[i]));
+    }
+    return SQPHIP_OK;
+}
+
 // ---- ACOPF evaluator + batched SQP -----------------------------------------------------------------
 extern "C" int sqphip_acopf_attach(sqphip_ctx *h, int32_t nb, int32_t ng, int32_t nl, const int32_t *f_bus,
                                    const int32_t *t_bus, const int32_t *gen_bus, const int32_t *bal_ptr,

@@ -5,6 +5,8 @@ import ctypes as C
 import os
 import re
 
+import numpy as np
+
 import pytest
 
 import sqpsolver_jl_amd as pkg
@@ -96,3 +98,36 @@ def test_product_never_imports_the_oracle():
                                  if not ln.strip().startswith(("#", "//", "*", '"""', "The oracle")))
                 assert "from oracle" not in code and "import oracle" not in code, fn
                 assert "liboracle" not in code and "sqp_oracle.h" not in code, fn
+
+
+def test_armijo_and_mu_rules_host_logic():
+    """sqp_line_search.jl:270-334 -- scalar/host logic of the (upstream unreachable) line-search merit path."""
+    import ctypes as C
+    L = _lib.lib()
+    PHI = C.CFUNCTYPE(C.c_double, C.c_double, C.c_void_p)
+    L.sqphip_armijo_alpha.argtypes = [C.c_double] * 7 + [PHI, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    calls = []
+    # phi(alpha) = (alpha - 0.3)^2 along the step: phi0 = 0.09, D = -0.6; Armijo with eta = 0.4, tau = 0.5
+    phi = PHI(lambda a, u: (calls.append(a), (a - 0.3) ** 2)[1])
+    al, ok = C.c_double(), C.c_int32()
+    assert L.sqphip_armijo_alpha(0.09, -0.6, 0.4, 0.5, 1e-4, 1.0, 1e-8, phi, None, C.byref(al), C.byref(ok)) == 0
+    assert calls == [1.0, 0.5, 0.25] and al.value == 0.25 and ok.value == 1      # 0.0025 <= 0.09 - 0.06
+    # tiny direction: no evaluation, alpha = 1
+    calls.clear()
+    assert L.sqphip_armijo_alpha(0.09, -0.6, 0.4, 0.5, 1e-4, 1e-9, 1e-8, phi, None, C.byref(al), C.byref(ok)) == 0
+    assert calls == [] and al.value == 1.0 and ok.value == 1
+    # never sufficient decrease: alpha falls below min_alpha -> invalid
+    up = PHI(lambda a, u: 1.0 + a)
+    assert L.sqphip_armijo_alpha(1.0, -1.0, 0.4, 0.5, 0.2, 1.0, 1e-8, up, None, C.byref(al), C.byref(ok)) == 0
+    assert ok.value == 0 and al.value == 0.125                                  # 1, .5, .25, .125 (< 0.2: stop)
+    dp = C.POINTER(C.c_double)
+    L.sqphip_compute_mu_rule.argtypes = [C.c_int32, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, dp, dp]
+    lam = np.array([0.5, -3.0, 0.0]); t = (2.0 + 1.0) / max((1 - 0.5) * 4.0, 1e-8)     # = 1.5
+    for rule, it, want in ((1, 5, [1.5, 3.0, 1.5]), (2, 1, [1.5, 1.5, 1.5]), (2, 2, [1.0, 3.0, 1.0]), (3, 7, [1.0, 3.0, 1.0])):
+        mu = np.ones(3)
+        assert L.sqphip_compute_mu_rule(rule, it, 0.5, 4.0, 2.0, 1.0, 3, lam.ctypes.data_as(dp), mu.ctypes.data_as(dp)) == 0
+        assert mu.tolist() == want, (rule, it, mu)
+    mu = np.ones(3)
+    assert L.sqphip_compute_mu_rule(1, 1, 0.5, 0.0, 2.0, -9.0, 3, lam.ctypes.data_as(dp), mu.ctypes.data_as(dp)) == 0
+    assert mu[0] == 2.0 / 1e-8                                                   # denominator floor, negative curvature dropped
+    assert L.sqphip_compute_mu_rule(4, 1, 0.5, 1.0, 1.0, 1.0, 3, lam.ctypes.data_as(dp), mu.ctypes.data_as(dp)) != 0
