@@ -278,3 +278,22 @@ def test_quirk_flag_switches_hessian_sign():
     b = O.sqp_solve(P, O.default_options(max_iter=40, tol_infeas=1e-6, tol_residual=1e-4, literal_quirks=1))
     assert a["status"] == 0 and a["iter"] < b["iter"]       # textbook sign converges quadratically
     assert a["trace"][-1]["dual_infeas"] < 1e-6
+
+
+# ---------------------------------------------------------------- independent cross-check
+def test_acopf_optimum_agrees_with_scipy_trust_constr():
+    """The reference cannot run here, so the NLP answer of the restatement is pinned against an unrelated solver:
+    scipy's trust-constr (Byrd-Omojokun / interior point) on the same callbacks must reach the same local optimum
+    of the 14-bus case as the restated SqpTR.run! (textbook Hessian sign)."""
+    from scipy.optimize import Bounds, NonlinearConstraint, minimize
+    nb, ng, nl, seed = CASES["case14"]
+    net = acopf_synth(nb, ng, nl, seed); lay = acopf_layout(net); P = O.problem_acopf(net, lay)
+    r = O.sqp_solve(P, O.default_options(max_iter=60, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=0))
+    assert r["status"] == 0
+    jac = lambda x: sp.coo_matrix((P.eval_jac_g(x), (lay.jrow - 1, lay.jcol - 1)), shape=(lay.m, lay.n)).tocsr()
+    res = minimize(P.eval_f, lay.x0, jac=P.eval_grad_f, method="trust-constr",
+                   constraints=[NonlinearConstraint(P.eval_g, lay.gL, lay.gU, jac=jac)], bounds=Bounds(lay.xL, lay.xU),
+                   options=dict(gtol=1e-8, xtol=1e-10, maxiter=2000))
+    assert res.constr_violation < 1e-8
+    assert abs(res.fun - r["obj_val"]) <= 1e-8 * abs(r["obj_val"])
+    assert np.abs(res.x - r["x"]).max() < 1e-5
