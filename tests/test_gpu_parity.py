@@ -445,3 +445,37 @@ def test_bound_constrained_problem_without_rows():
     assert np.allclose(m.x, [2.0, 0.0], atol=1e-7) and abs(m.obj_val - 2.0) < 1e-7
     # grad f(x*) = (-2, 4) = mult_x_L - mult_x_U in the Model's output convention (both >= 0, MOI_wrapper.jl:1395-1453)
     assert np.allclose(m.mult_x_U, [2.0, 0.0], atol=1e-6) and np.allclose(m.mult_x_L, [0.0, 4.0], atol=1e-6)
+
+
+def test_batch_of_forty_matches_oracle_to_convergence():
+    """A batch that fills the chip's stage-kernel slots (40 instances: five per XCD) run to convergence: status,
+    iteration count, every accept / reject / restoration decision and the final point of every instance against the
+    oracle.  (Small batches hid a gate race in the stage kernels for most of round 1.)"""
+    nb, ng, nl, seed = CASES["case14"]
+    base = acopf_synth(nb, ng, nl, seed)
+    B = 40
+    nets = [base] + [contingency(base, s, seed) for s in range(1, B)]
+    lays = [acopf_layout(nt) for nt in nets]
+    kw = dict(max_iter=60, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=0)
+    ctx = pkg.Context(lays[0].n, lays[0].m, lays[0].num_linear, lays[0].jrow, lays[0].jcol, lays[0].hrow, lays[0].hcol,
+                      lays[0].xL, lays[0].xU, lays[0].gL, lays[0].gU, pkg.default_options(**kw), batch=B)
+    ctx.acopf_attach(base, lays[0])
+    for b in range(B):
+        ctx.acopf_set_instance(b, nets[b], lays[b])
+    ctx.sqp_reset(); ctx.sqp_run(0)
+    oo = O.default_options(num_threads=1, **kw)
+    nconv = 0
+    for b in range(B):
+        ro = O.sqp_solve(O.problem_acopf(nets[b], lays[b]), oo)
+        rg = ctx.sqp_get(b); tr = ctx.sqp_trace(b)
+        assert (rg["status"], rg["iter"]) == (ro["status"], ro["iter"]), b
+        assert [(a["iter"], a["accepted"], a["fr"], a["sub_status"]) for a in ro["trace"]] == \
+               [(c["iter"], c["accepted"], c["fr"], c["sub_status"]) for c in tr], b
+        tol = TOL if ro["status"] == 0 else TOL_TRAJ
+        assert abs(rg["obj_val"] - ro["obj_val"]) <= tol * abs(ro["obj_val"]), b
+        # the point itself to 1e-6: reactive dispatch has nearly flat directions (the cost sees active power only),
+        # so two runs that stop inside tol_direction of each other can sit 1e-7 apart along them
+        assert rel(rg["x"], ro["x"]) < max(tol, 1e-6), b
+        nconv += ro["status"] == 0
+    assert nconv >= B - 4            # almost every scenario of the 14-bus set is feasible
+    ctx.close()
