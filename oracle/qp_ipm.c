@@ -451,25 +451,29 @@ static double ipm_compl_err(const ora_qp *q, double mu)
 /* Build the rhs of the reduced Newton system for centring target `tgt`, solve, and expand to
  * all directions.  rd_vec / rp_vec are the current residuals.  Returns the relative residual
  * of the linear solve after refinement. */
+/* soc (may be NULL): per-pair second-order terms dz_aff * dx_aff of the predictor, laid out
+ * [zl n | zu n | zp m | zm m | vl m | vu m]; the complementarity targets become tgt - soc */
 static double ipm_direction(ora_qp *q, double delta_w, double tgt,
-                            const double *rd_vec, const double *rp_vec)
+                            const double *rd_vec, const double *rp_vec, const double *soc)
 {
     int64_t n = q->n, m = q->m;
+    const int64_t oZL = 0, oZU = n, oZP = 2 * n, oZM = 2 * n + m, oVL = 2 * n + 2 * m, oVU = 2 * n + 3 * m;
+#define SOC(k, idx) (soc ? soc[(k) + (idx)] : 0.0)
     for (int64_t j = 0; j < n; ++j) {
         double g = -rd_vec[j];
-        if (isfinite(q->lb[j])) { double gl = q->p[j] - q->lb[j]; g += (tgt - q->zl[j] * gl) / gl; }
-        if (isfinite(q->ub[j])) { double gu = q->ub[j] - q->p[j]; g -= (tgt - q->zu[j] * gu) / gu; }
+        if (isfinite(q->lb[j])) { double gl = q->p[j] - q->lb[j]; g += (tgt - SOC(oZL, j) - q->zl[j] * gl) / gl; }
+        if (isfinite(q->ub[j])) { double gu = q->ub[j] - q->p[j]; g -= (tgt - SOC(oZU, j) - q->zu[j] * gu) / gu; }
         q->rhs[j] = g;
     }
     for (int64_t i = 0; i < m; ++i) {
         if (q->rtype[i] == ROW_FREE) { q->rhs[n + i] = 0.0; continue; }
         double zp = q->zp[i], zm = q->zm[i];
-        double cp = tgt - zp * q->tp[i], cm = tgt - zm * q->tm[i];
+        double cp = tgt - SOC(oZP, i) - zp * q->tp[i], cm = tgt - SOC(oZM, i) - zm * q->tm[i];
         double b = -rp_vec[i] - cp / zp + cm / zm;
         if (q->rtype[i] == ROW_INEQ) {
             double sig = 0.0, t = 0.0;
-            if (isfinite(q->lo[i])) { double al = q->s[i] - q->lo[i]; sig += q->vl[i] / al; t += (tgt - q->vl[i] * al) / al; }
-            if (isfinite(q->hi[i])) { double au = q->hi[i] - q->s[i]; sig += q->vu[i] / au; t -= (tgt - q->vu[i] * au) / au; }
+            if (isfinite(q->lo[i])) { double al = q->s[i] - q->lo[i]; sig += q->vl[i] / al; t += (tgt - SOC(oVL, i) - q->vl[i] * al) / al; }
+            if (isfinite(q->hi[i])) { double au = q->hi[i] - q->s[i]; sig += q->vu[i] / au; t -= (tgt - SOC(oVU, i) - q->vu[i] * au) / au; }
             b += t / sig;
         }
         q->rhs[n + i] = b;
@@ -479,8 +483,8 @@ static double ipm_direction(ora_qp *q, double delta_w, double tgt,
         double dp = q->sol[j];
         q->dp[j] = dp;
         q->dzl[j] = 0.0; q->dzu[j] = 0.0;
-        if (isfinite(q->lb[j])) { double gl = q->p[j] - q->lb[j]; q->dzl[j] = (tgt - q->zl[j] * gl - q->zl[j] * dp) / gl; }
-        if (isfinite(q->ub[j])) { double gu = q->ub[j] - q->p[j]; q->dzu[j] = (tgt - q->zu[j] * gu + q->zu[j] * dp) / gu; }
+        if (isfinite(q->lb[j])) { double gl = q->p[j] - q->lb[j]; q->dzl[j] = (tgt - SOC(oZL, j) - q->zl[j] * gl - q->zl[j] * dp) / gl; }
+        if (isfinite(q->ub[j])) { double gu = q->ub[j] - q->p[j]; q->dzu[j] = (tgt - SOC(oZU, j) - q->zu[j] * gu + q->zu[j] * dp) / gu; }
     }
     for (int64_t i = 0; i < m; ++i) {
         q->dy[i] = q->ds[i] = q->dtp[i] = q->dtm[i] = q->dvl[i] = q->dvu[i] = 0.0;
@@ -488,13 +492,13 @@ static double ipm_direction(ora_qp *q, double delta_w, double tgt,
         double dy = -q->sol[n + i];
         double zp = q->zp[i], zm = q->zm[i];
         q->dy[i] = dy;
-        q->dtp[i] = (tgt - zp * q->tp[i] + q->tp[i] * dy) / zp;
-        q->dtm[i] = (tgt - zm * q->tm[i] - q->tm[i] * dy) / zm;
+        q->dtp[i] = (tgt - SOC(oZP, i) - zp * q->tp[i] + q->tp[i] * dy) / zp;
+        q->dtm[i] = (tgt - SOC(oZM, i) - zm * q->tm[i] - q->tm[i] * dy) / zm;
         if (q->rtype[i] == ROW_INEQ) {
             double sig = 0.0, t = 0.0, al = 0.0, au = 0.0, cl = 0.0, cu = 0.0;
             int hl = isfinite(q->lo[i]), hu = isfinite(q->hi[i]);
-            if (hl) { al = q->s[i] - q->lo[i]; cl = tgt - q->vl[i] * al; sig += q->vl[i] / al; t += cl / al; }
-            if (hu) { au = q->hi[i] - q->s[i]; cu = tgt - q->vu[i] * au; sig += q->vu[i] / au; t -= cu / au; }
+            if (hl) { al = q->s[i] - q->lo[i]; cl = tgt - SOC(oVL, i) - q->vl[i] * al; sig += q->vl[i] / al; t += cl / al; }
+            if (hu) { au = q->hi[i] - q->s[i]; cu = tgt - SOC(oVU, i) - q->vu[i] * au; sig += q->vu[i] / au; t -= cu / au; }
             double ds = (t - dy) / sig;
             q->ds[i] = ds;
             if (hl) q->dvl[i] = (cl - q->vl[i] * ds) / al;
@@ -503,6 +507,7 @@ static double ipm_direction(ora_qp *q, double delta_w, double tgt,
     }
     return relres;
 }
+#undef SOC
 
 static inline double ratio(double x, double dx, double a)
 {
@@ -596,6 +601,9 @@ static int ipm_run(ora_qp *q, const double *p_start)
     double mu = 1.0;
     int n_acc = 0, n_acc2 = 0;
     double dw_prev = 0.0;
+    /* predictor-corrector mode (opt.ipm_corrector) until the first inertia correction of this solve */
+    int mpc = q->opt.ipm_corrector != 0;
+    double *soc = mpc ? (double *)calloc((size_t)(2 * n + 4 * m + 1), sizeof(double)) : NULL;
     int verbose = getenv("ORA_IPM_VERBOSE") != NULL;
     for (int it = 0; it < q->opt.ipm_max_iter; ++it) {
         ipm_meas ms;
@@ -613,7 +621,7 @@ static int ipm_run(ora_qp *q, const double *p_start)
         n_acc2 = e0 <= 1000.0 * tol ? n_acc2 + 1 : 0;
         if (n_acc >= 8 || n_acc2 >= 15) { rc = 0; break; }
         /* barrier update */
-        for (int k = 0; k < 20; ++k) {
+        for (int k = 0; k < 20 && !mpc; ++k) {
             double emu = fmax(fmax(ms.rd / sd, ms.rp), ipm_compl_err(q, mu) / sd);
             if (emu > 10.0 * mu || mu <= mu_min) break;
             mu = fmax(mu_min, fmin(0.2 * mu, pow(mu, 1.5)));
@@ -646,8 +654,49 @@ static int ipm_run(ora_qp *q, const double *p_start)
         double dw_floor = dw_prev > 3e-10 ? fmax(1e-20, dw_prev / 3.0) : 0.0;
         for (int attempt = 0; attempt < 12 && !ok; ++attempt) {
             if (kkt_factor(q, dw_floor, &dw) != 0) break;
-            relres = ipm_direction(q, dw, mu, rd, rp);
             double apm, adm;
+            if (mpc && dw > 0.0) {
+                /* first inertia correction: the sub-problem is not convex along the path; from here on the
+                 * monotone rule, restarted from the current average complementarity */
+                mpc = 0;
+                mu = fmax(mu_min, fmin(1.0, ms.cavg));
+                tau = fmax(0.99, 1.0 - mu);
+            }
+            if (mpc) {
+                /* predictor: affine-scaling direction (target 0), largest steps to the boundary */
+                relres = ipm_direction(q, dw, 0.0, rd, rp, NULL);
+                ipm_max_steps(q, &apm, &adm);
+                const double ap1 = fmin(1.0, apm), ad1 = fmin(1.0, adm);
+                double csum = 0.0;
+                int64_t nc = 0;
+#define PR(zz, dz, xx, dx, slot) do { csum += ((zz) + ad1 * (dz)) * ((xx) + ap1 * (dx)); ++nc; soc[slot] = (dz) * (dx); } while (0)
+                for (int64_t j = 0; j < n; ++j) {
+                    soc[j] = 0.0; soc[n + j] = 0.0;
+                    if (isfinite(q->lb[j])) PR(q->zl[j], q->dzl[j], q->p[j] - q->lb[j], q->dp[j], j);
+                    if (isfinite(q->ub[j])) PR(q->zu[j], q->dzu[j], q->ub[j] - q->p[j], -q->dp[j], n + j);
+                }
+                for (int64_t i = 0; i < m; ++i) {
+                    soc[2 * n + i] = soc[2 * n + m + i] = soc[2 * n + 2 * m + i] = soc[2 * n + 3 * m + i] = 0.0;
+                    if (q->rtype[i] == ROW_FREE) continue;
+                    PR(q->zp[i], -q->dy[i], q->tp[i], q->dtp[i], 2 * n + i);
+                    PR(q->zm[i], q->dy[i], q->tm[i], q->dtm[i], 2 * n + m + i);
+                    if (q->rtype[i] == ROW_INEQ) {
+                        if (isfinite(q->lo[i])) PR(q->vl[i], q->dvl[i], q->s[i] - q->lo[i], q->ds[i], 2 * n + 2 * m + i);
+                        if (isfinite(q->hi[i])) PR(q->vu[i], q->dvu[i], q->hi[i] - q->s[i], -q->ds[i], 2 * n + 3 * m + i);
+                    }
+                }
+#undef PR
+                /* Mehrotra's centring parameter sigma = (mu_aff / mu_now)^3, clamped to [1e-4, 1] */
+                const double mu_aff = nc ? csum / (double)nc : 0.0;
+                double sigma = ms.cavg > 0.0 ? pow(fmax(0.0, mu_aff) / ms.cavg, 3.0) : 1.0;
+                sigma = fmin(1.0, fmax(sigma, 1e-4));
+                mu = fmax(mu_min, sigma * ms.cavg);
+                tau = fmax(0.99, 1.0 - mu);
+                /* corrector: centring target mu with the second-order terms, same factorisation */
+                relres = ipm_direction(q, dw, mu, rd, rp, soc);
+            } else {
+                relres = ipm_direction(q, dw, mu, rd, rp, NULL);
+            }
             ipm_max_steps(q, &apm, &adm);
             alpha = fmin(1.0, tau * apm);
             a_d = fmin(1.0, tau * adm);
@@ -676,7 +725,7 @@ static int ipm_run(ora_qp *q, const double *p_start)
             fprintf(stderr, "  ipm %3d mu=%.2e e0=%.2e rd=%.2e rp=%.1e cmax=%.2e a=%.3f ad=%.3f dw=%.1e rr=%.1e\n",
                     it, mu, e0, ms.rd, ms.rp, ms.cmax, alpha, a_d, dw, relres);
     }
-    free(rd); free(rp);
+    free(rd); free(rp); free(soc);
     return rc;
 }
 
