@@ -64,6 +64,8 @@ def main():
                          "default keeps one group and a clean roofline measurement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--literal-quirks", type=int, default=1)
+    ap.add_argument("--ipm-corrector", type=int, default=1,
+                    help="options.ipm_corrector (library default 1: predictor-corrector interior-point iterations)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event timing of k_trailing")
     ap.add_argument("--sqp-options", default="example", choices=["example", "defaults"],
                     help="example: tol_infeas 1e-6, tol_residual 1e-4, use_soc (examples/acopf/opf.jl:76-79, the headline); "
@@ -106,7 +108,8 @@ def main():
     # examples/acopf/opf.jl:72-80
     use_soc = 1 if args.sqp_options == "example" else 0
     sqp_kw = dict(tol_infeas=1e-6, tol_residual=1e-4, use_soc=1) if use_soc else {}
-    opts = pkg.default_options(max_iter=3000, literal_quirks=args.literal_quirks, device=local_rank, **sqp_kw)
+    opts = pkg.default_options(max_iter=3000, literal_quirks=args.literal_quirks, device=local_rank,
+                               ipm_corrector=args.ipm_corrector, **sqp_kw)
     import threading
     G = max(1, min(args.groups, hi - lo))
     ctxs, nets = [], []
@@ -202,7 +205,8 @@ def main():
             cores = max(1, min(16, len(os.sched_getaffinity(0))))   # the GPU box grants 16 host cores per GPU
         except AttributeError:
             cores = max(1, min(16, os.cpu_count() or 1))
-        oo = O.default_options(max_iter=6, literal_quirks=args.literal_quirks, num_threads=cores, **sqp_kw)
+        oo = O.default_options(max_iter=6, literal_quirks=args.literal_quirks, num_threads=cores,
+                               ipm_corrector=args.ipm_corrector, **sqp_kw)
         ro = O.sqp_solve(O.problem_acopf(*nets[0]), oo)
         cpu = {"value": ro["n_qp"] / ro["qp_seconds"] if ro["qp_seconds"] > 0 else 0.0,
                "unit": "QP subproblems/s", "cores": cores, "kind": "port",
@@ -228,7 +232,7 @@ def main():
                                    f"(BASELINE.json configs[3] shard), dense KKT N={N}, SQP-TR outer iterations",
                        "instances_total": total, "kkt_order": N, "use_soc": use_soc, "sqp_options": args.sqp_options,
                        "groups_per_gpu": G,
-                       "literal_quirks": args.literal_quirks,
+                       "literal_quirks": args.literal_quirks, "ipm_corrector": args.ipm_corrector,
                        "qp_solved": n_qp, "ipm_iterations": n_ipm, "kkt_factorisations": n_fac,
                        "ldlt_tflops_wall": n_fac * (N ** 3 / 3.0) / elapsed / 1e12 if elapsed > 0 else 0.0,
                        "instances_done": int(np.sum(g_done))},

@@ -56,6 +56,8 @@ typedef struct {
     int32_t ipm_max_iter;    /* default 200 */
     int32_t ipm_phase1;      /* 1: confirm infeasibility verdicts with a phase-1 run (default 0) */
     int32_t device;          /* HIP device ordinal */
+    int32_t ipm_corrector;   /* 1 (default): Mehrotra predictor-corrector iterations until the first inertia
+                              * correction of a solve; 0: monotone Fiacco-McCormick rule throughout */
 } sqphip_options;
 
 void sqphip_default_options(sqphip_options *o);

@@ -24,7 +24,7 @@ void ora_default_options(ora_options *o)
     o->ipm_max_iter = 200;
     o->ipm_phase1 = 0;
     o->num_threads = 1;
-    o->ipm_corrector = 0;
+    o->ipm_corrector = 1;
 }
 
 /* Julia's isapprox(a, b) with default rtol = sqrt(eps), atol = 0

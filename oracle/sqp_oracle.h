@@ -60,9 +60,9 @@ typedef struct {
     int ipm_phase1;    /* 1: confirm an infeasibility verdict with a phase-1 run and escalate the penalty if it
                           disagrees; 0 (default): elastic mass left on a hard row means infeasible */
     int num_threads;   /* OpenMP threads for the dense LDL^T (cpu_baseline reports this) */
-    int ipm_corrector; /* 1: Mehrotra predictor-corrector (adaptive barrier parameter + second-order term, two solves
-                          per factorisation) while the sub-problem behaves convex, monotone rule from the first
-                          inertia correction on; 0 (default): monotone Fiacco-McCormick rule throughout */
+    int ipm_corrector; /* 1 (default): Mehrotra predictor-corrector (adaptive barrier parameter + second-order term,
+                          two solves per factorisation) while the sub-problem behaves convex, monotone rule from the
+                          first inertia correction on; 0: monotone Fiacco-McCormick rule throughout */
 } ora_options;
 
 typedef double (*ora_eval_f_t)(void *ud, const double *x);

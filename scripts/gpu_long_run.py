@@ -5,9 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sqpsolver_jl_amd as pkg
 from sqpsolver_jl_amd.acopf_synth import acopf_synth, acopf_layout, contingency, CASES
 case = sys.argv[1]; B = int(sys.argv[2]); iters = int(sys.argv[3]); quirks = int(sys.argv[4])
+extra = {"ipm_corrector": int(sys.argv[5])} if len(sys.argv) > 5 else {}
 nb, ng, nl, seed = CASES[case]
 base = acopf_synth(nb, ng, nl, seed); lay0 = acopf_layout(base)
-opts = pkg.default_options(tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, max_iter=iters, literal_quirks=quirks)
+opts = pkg.default_options(tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, max_iter=iters, literal_quirks=quirks, **extra)
 ctx = pkg.Context(lay0.n, lay0.m, lay0.num_linear, lay0.jrow, lay0.jcol, lay0.hrow, lay0.hcol, lay0.xL, lay0.xU, lay0.gL, lay0.gU, opts, batch=B)
 ctx.acopf_attach(base, lay0)
 for b in range(B):
@@ -16,7 +17,7 @@ for b in range(B):
 ctx.sqp_reset(); t0 = time.time(); ctx.sqp_run(0); t = time.time() - t0
 ret, it, done = ctx.sqp_status()
 c = ctx.counters()
-print(f"{case} B={B} max_iter={iters} quirks={quirks}: {t:.1f}s  ret codes {dict(collections.Counter(ret.tolist()))}  iters min/mean/max {it.min()}/{it.mean():.1f}/{it.max()}  n_qp {c['n_qp']} ipm/qp {c['n_ipm_iter']/c['n_qp']:.1f} QP/s {c['n_qp']/t:.1f}")
+print(f"{case} B={B} max_iter={iters} quirks={quirks} {extra}: {t:.1f}s  ret codes {dict(collections.Counter(ret.tolist()))}  iters min/mean/max {it.min()}/{it.mean():.1f}/{it.max()}  n_qp {c['n_qp']} ipm/qp {c['n_ipm_iter']/c['n_qp']:.1f} QP/s {c['n_qp']/t:.1f}")
 bad = [b for b in range(B) if ret[b] == -5]
 for b in bad[:3]:
     tr = ctx.sqp_trace(b)

@@ -99,7 +99,7 @@ extern "C" void sqphip_default_options(sqphip_options *o)
     o->init_mu = 1.0; o->max_mu = 1e10; o->tr_size = 10.0;
     o->rho = 0.8; o->eta = 0.4; o->tau = 0.9; o->min_alpha = 1e-6;
     o->max_iter = 3000; o->use_soc = 0; o->literal_quirks = 1;
-    o->ipm_tol = 1e-9; o->ipm_max_iter = 200; o->ipm_phase1 = 0; o->device = 0;
+    o->ipm_tol = 1e-9; o->ipm_max_iter = 200; o->ipm_phase1 = 0; o->device = 0; o->ipm_corrector = 1;
 }
 
 extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num_linear, int64_t nnzJ,
@@ -161,11 +161,12 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
         d.jv = C.dalloc<double>((size_t)B * d.nnzjc); d.hv = C.dalloc<double>((size_t)B * d.nnzhc);
         double **nvec[] = { &d.c, &d.hd, &d.lb, &d.ub, &d.p, &d.zl, &d.zu, &d.dp, &d.dzl, &d.dzu, &d.rd,
                             &d.sigp, &d.wn, &d.op, &d.omxU, &d.omxL, &d.x, &d.mxL, &d.mxU, &d.df, &d.pstep,
-                            &d.psoc, &d.pmxL, &d.pmxU, &d.tmpx, &d.x0 };
+                            &d.psoc, &d.pmxL, &d.pmxU, &d.tmpx, &d.x0, &d.socZL, &d.socZU };
         for (auto pp : nvec) *pp = C.dalloc<double>(Bn);
         double **mvec[] = { &d.lo, &d.hi, &d.wp, &d.wm, &d.s, &d.tp, &d.tm, &d.y, &d.vl, &d.vu, &d.ds,
                             &d.dtp, &d.dtm, &d.dy, &d.dvl, &d.dvu, &d.rp, &d.Dd, &d.olam, &d.lambda, &d.E,
-                            &d.plam, &d.Esoc, &d.tmpE, &d.hlam, &d.zp, &d.zm, &d.rdir };
+                            &d.plam, &d.Esoc, &d.tmpE, &d.hlam, &d.zp, &d.zm, &d.rdir,
+                            &d.socZP, &d.socZM, &d.socVL, &d.socVU };
         for (auto pp : mvec) *pp = C.dalloc<double>(Bm);
         d.oslack = C.dalloc<double>(2 * Bm);
         d.rtype = C.dalloc<int>(Bm); d.rbase = C.dalloc<int>(Bm); d.hard = C.dalloc<int>(Bm);
@@ -175,7 +176,7 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
         d.ist = C.dalloc<IpmState>(B); d.sst = C.dalloc<SqpState>(B);
         d.phase = C.dalloc<int>(B); d.counters = C.dalloc<int>(8);
         d.trace = C.dalloc<double>((size_t)B * SQPHIP_TRACE_CAP * SQPHIP_TRACE_COLS);
-        d.ipm_tol = opt->ipm_tol; d.ipm_max_iter = opt->ipm_max_iter; d.ipm_phase1 = opt->ipm_phase1;
+        d.ipm_tol = opt->ipm_tol; d.ipm_max_iter = opt->ipm_max_iter; d.ipm_phase1 = opt->ipm_phase1; d.ipm_corrector = opt->ipm_corrector;
         d.tol_direction = opt->tol_direction; d.tol_residual = opt->tol_residual;
         d.tol_infeas = opt->tol_infeas; d.init_mu = opt->init_mu; d.tr_size = opt->tr_size;
         d.max_iter = opt->max_iter; d.use_soc = opt->use_soc; d.literal_quirks = opt->literal_quirks;

@@ -8,7 +8,7 @@
 namespace sqphip {
 
 // interior-point phases of one instance (kernels act only on instances in the phase they serve)
-enum { PH_IDLE = 0, PH_PREP = 1, PH_FACTOR = 2, PH_SOLVE = 3, PH_STEP = 4, PH_DONE = 9 };
+enum { PH_IDLE = 0, PH_PREP = 1, PH_FACTOR = 2, PH_SOLVE = 3, PH_STEP = 4, PH_MPC = 5, PH_SOLVE2 = 6, PH_DONE = 9 };
 enum { ROW_FREE = 0, ROW_EQ = 1, ROW_INEQ = 2 };
 
 struct IpmState {
@@ -20,6 +20,8 @@ struct IpmState {
     // iteration
     double mu, tau, dw, dw_last, dw_floor, cn, relres, rn, e0;
     int iter, rc, fac_attempt, dir_attempt, refine_it, n_acc, n_acc2;
+    int mpc, use_soc;              // predictor-corrector mode of this solve; second-order terms valid for the step
+    double cavg;                   // average complementarity at the top of the iteration
     // outcome
     int status, ipm_iters, n_factor;
     double elastic;
@@ -58,6 +60,7 @@ struct DV {
     double *p, *zl, *zu, *s, *tp, *tm, *y, *vl, *vu, *zp, *zm, *rdir;
     double *dp, *dzl, *dzu, *ds, *dtp, *dtm, *dy, *dvl, *dvu;
     double *rd, *rp, *sigp, *Dd, *rhs, *sol, *wn, *wN;
+    double *socZL, *socZU, *socZP, *socZM, *socVL, *socVU;   // predictor's dz*dx per complementarity pair
     // linear algebra
     double *K, *dinv, *xv, *vv;
     // QP outputs
@@ -66,7 +69,7 @@ struct DV {
     int *phase;
     int *counters;      // [0] instances iterating, [1] start flags, [2] SQP not done, [3] start flags
     double ipm_tol;
-    int ipm_max_iter, ipm_phase1;
+    int ipm_max_iter, ipm_phase1, ipm_corrector;
     // ---- SQP level
     double *x, *lambda, *mxL, *mxU, *df, *E, *pstep, *psoc, *plam, *pmxL, *pmxU, *Esoc, *tmpx, *tmpE,
         *hlam;

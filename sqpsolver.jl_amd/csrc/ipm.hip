@@ -230,6 +230,7 @@ __global__ __launch_bounds__(TPB) void k_ipm_start(DV d)
         st.sf = sf; st.soft_w = soft_w; st.hsc = (st.stage == 0 && use_obj) ? sf : 0.0;
         st.mu = 1.0; st.iter = 0; st.rc = -1; st.dw_last = 0.0; st.dw = 0.0; st.dw_floor = 0.0; st.n_acc = 0; st.n_acc2 = 0;
         st.cn = 0.0;
+        st.mpc = d.ipm_corrector != 0; st.use_soc = 0; st.cavg = 0.0;
         st.start = 0;
         d.phase[inst] = PH_PREP;
     }
@@ -300,7 +301,8 @@ __global__ __launch_bounds__(TPB) void k_ipm_prepare(DV d)
     // barrier update: mu <- max(mu_min, min(0.2 mu, mu^1.5)) while the barrier problem is solved
     double mu = st.mu;
     const double mu_min = d.ipm_tol / 10.0;
-    for (int kk = 0; kk < 20; ++kk) {
+    const int mpc = st.mpc;           // predictor-corrector mode picks mu after the predictor (k_mpc)
+    for (int kk = 0; kk < 20 && !mpc; ++kk) {
         double ce = 0.0;
         for (int j = threadIdx.x; j < d.n; j += TPB) {
             if (fin(lb[j])) ce = fmax(ce, fabs(zl[j] * (p[j] - lb[j]) - mu));
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(TPB) void k_ipm_prepare(DV d)
         mu = fmax(mu_min, fmin(0.2 * mu, pow(mu, 1.5)));
     }
     if (threadIdx.x == 0) {
-        st.mu = mu; st.tau = fmax(0.99, 1.0 - mu); st.e0 = e0;
+        st.mu = mu; st.tau = fmax(0.99, 1.0 - mu); st.e0 = e0; st.cavg = cavg; st.use_soc = 0;
         st.ipm_iters++;
         // st.dw still holds the correction the previous iteration of this solve ended with: if it needed one,
         // skip the zero trial and start from a third of it
@@ -367,33 +369,35 @@ __global__ __launch_bounds__(128) void k_kkt_assemble(DV d)
 }
 
 // ---------------------------------------------------------------------------------------------
-// before the factorisation: the Newton right-hand side (it does not depend on delta_w) and its working copy
-// xv, which the panel kernels of the factorisation turn into L^-1 rhs on the fly (fused forward elimination).
-// Runs for every instance in PH_FACTOR, i.e. again before each re-factorisation.
-__global__ __launch_bounds__(TPB) void k_build_rhs(DV d)
+// second-order terms of the predictor (options.ipm_corrector): dz_aff * dx_aff per complementarity pair
+#define SOC_PTRS                                                                                    \
+    const double *sZL = d.socZL + on, *sZU = d.socZU + on, *sZP = d.socZP + om, *sZM = d.socZM + om, \
+                 *sVL = d.socVL + om, *sVU = d.socVU + om;
+#define SOCV(a, k) (soc ? (a)[k] : 0.0)
+
+// Newton right-hand side for centring target tgt (minus the second-order terms when soc), its working copy xv
+// for the triangular solves, sol = 0.  Returns max |rhs| (block-wide).
+__device__ double build_rhs(const DV &d, int inst, double tgt, bool soc)
 {
-    const int inst = blockIdx.x;
-    if (d.phase[inst] != PH_FACTOR) return;
-    IpmState &st = d.ist[inst];
     INST_PTRS
-    const double tgt = st.mu;
+    SOC_PTRS
     double rn = 0.0;
     for (int j = threadIdx.x; j < d.n; j += TPB) {
         double g = -rd[j];
-        if (fin(lb[j])) { const double gl = p[j] - lb[j]; g += (tgt - zl[j] * gl) / gl; }
-        if (fin(ub[j])) { const double gu = ub[j] - p[j]; g -= (tgt - zu[j] * gu) / gu; }
+        if (fin(lb[j])) { const double gl = p[j] - lb[j]; g += (tgt - SOCV(sZL, j) - zl[j] * gl) / gl; }
+        if (fin(ub[j])) { const double gu = ub[j] - p[j]; g -= (tgt - SOCV(sZU, j) - zu[j] * gu) / gu; }
         rhs[j] = g; rn = fmax(rn, fabs(g));
     }
     for (int i = threadIdx.x; i < d.m; i += TPB) {
         double b = 0.0;
         if (rt[i] != ROW_FREE) {
             const double zp = zpv[i], zm = zmv[i];
-            const double cp = tgt - zp * tp[i], cm = tgt - zm * tm[i];
+            const double cp = tgt - SOCV(sZP, i) - zp * tp[i], cm = tgt - SOCV(sZM, i) - zm * tm[i];
             b = -rp[i] - cp / zp + cm / zm;
             if (rt[i] == ROW_INEQ) {
                 double sig = 0.0, t = 0.0;
-                if (fin(lo[i])) { const double al = s[i] - lo[i]; sig += vl[i] / al; t += (tgt - vl[i] * al) / al; }
-                if (fin(hi[i])) { const double au = hi[i] - s[i]; sig += vu[i] / au; t -= (tgt - vu[i] * au) / au; }
+                if (fin(lo[i])) { const double al = s[i] - lo[i]; sig += vl[i] / al; t += (tgt - SOCV(sVL, i) - vl[i] * al) / al; }
+                if (fin(hi[i])) { const double au = hi[i] - s[i]; sig += vu[i] / au; t -= (tgt - SOCV(sVU, i) - vu[i] * au) / au; }
                 b += t / sig;
             }
         }
@@ -406,6 +410,19 @@ __global__ __launch_bounds__(TPB) void k_build_rhs(DV d)
         xv[i] = v;
         sol[i] = 0.0;
     }
+    return rn;
+}
+
+// before the factorisation: the Newton right-hand side (it does not depend on delta_w) and its working copy
+// xv, which the panel kernels of the factorisation turn into L^-1 rhs on the fly (fused forward elimination).
+// Runs for every instance in PH_FACTOR, i.e. again before each re-factorisation.  In predictor-corrector mode
+// this is the predictor's (affine-scaling, target 0) right-hand side.
+__global__ __launch_bounds__(TPB) void k_build_rhs(DV d)
+{
+    const int inst = blockIdx.x;
+    if (d.phase[inst] != PH_FACTOR) return;
+    IpmState &st = d.ist[inst];
+    const double rn = build_rhs(d, inst, st.mpc ? 0.0 : st.mu, false);
     if (threadIdx.x == 0) st.rn = fmax(1.0, rn);
 }
 
@@ -440,10 +457,10 @@ __global__ __launch_bounds__(TPB) void k_inertia(DV d)
 }
 
 // after a triangular solve: accumulate, form the residual against the sparse operator, decide
-__global__ __launch_bounds__(TPB) void k_refine(DV d, int last)
+__global__ __launch_bounds__(TPB) void k_refine(DV d, int last, int want)
 {
     const int inst = blockIdx.x;
-    if (d.phase[inst] != PH_SOLVE) return;
+    if (d.phase[inst] != want) return;
     IpmState &st = d.ist[inst];
     INST_PTRS
     double *xv = d.xv + (long)inst * d.Npad;
@@ -472,7 +489,8 @@ __global__ __launch_bounds__(TPB) void k_refine(DV d, int last)
         for (int i = threadIdx.x; i < d.Npad; i += TPB) xv[i] = i < d.N ? wN[i] : 0.0;
     if (threadIdx.x == 0) {
         st.relres = en / st.rn;
-        if (stop) d.phase[inst] = PH_STEP; else st.refine_it++;
+        // predictor-corrector mode: the first solve was the predictor, k_mpc builds the corrector's system
+        if (stop) d.phase[inst] = (want == PH_SOLVE && st.mpc) ? PH_MPC : PH_STEP; else st.refine_it++;
     }
 }
 
@@ -483,21 +501,18 @@ __device__ __forceinline__ double ratio(double x, double dx, double a)
     return a;
 }
 
-// directions, fraction-to-boundary step lengths, update
-__global__ __launch_bounds__(TPB) void k_ipm_step(DV d)
+// expand the solution of the reduced system to all directions (centring target tgt, minus the second-order terms
+// when soc); ap / ad: this thread's largest primal / dual steps to the boundary
+__device__ void expand_directions(const DV &d, int inst, double tgt, bool soc, double &ap, double &ad)
 {
-    const int inst = blockIdx.x;
-    if (d.phase[inst] != PH_STEP) return;
-    IpmState &st = d.ist[inst];
     INST_PTRS
-    const double tgt = st.mu, mu = st.mu;
-    double ap = 1e300, ad = 1e300;
+    SOC_PTRS
     for (int j = threadIdx.x; j < d.n; j += TPB) {
         const double dpj = sol[j];
         dp[j] = dpj;
         double a = 0.0, b = 0.0;
-        if (fin(lb[j])) { const double gl = p[j] - lb[j]; a = (tgt - zl[j] * gl - zl[j] * dpj) / gl; ap = ratio(gl, dpj, ap); ad = ratio(zl[j], a, ad); }
-        if (fin(ub[j])) { const double gu = ub[j] - p[j]; b = (tgt - zu[j] * gu + zu[j] * dpj) / gu; ap = ratio(gu, -dpj, ap); ad = ratio(zu[j], b, ad); }
+        if (fin(lb[j])) { const double gl = p[j] - lb[j]; a = (tgt - SOCV(sZL, j) - zl[j] * gl - zl[j] * dpj) / gl; ap = ratio(gl, dpj, ap); ad = ratio(zl[j], a, ad); }
+        if (fin(ub[j])) { const double gu = ub[j] - p[j]; b = (tgt - SOCV(sZU, j) - zu[j] * gu + zu[j] * dpj) / gu; ap = ratio(gu, -dpj, ap); ad = ratio(zu[j], b, ad); }
         dzl[j] = a; dzu[j] = b;
     }
     for (int i = threadIdx.x; i < d.m; i += TPB) {
@@ -505,15 +520,15 @@ __global__ __launch_bounds__(TPB) void k_ipm_step(DV d)
         if (rt[i] != ROW_FREE) {
             dyi = -sol[d.n + i];
             const double zp = zpv[i], zm = zmv[i];
-            dtpi = (tgt - zp * tp[i] + tp[i] * dyi) / zp;
-            dtmi = (tgt - zm * tm[i] - tm[i] * dyi) / zm;
+            dtpi = (tgt - SOCV(sZP, i) - zp * tp[i] + tp[i] * dyi) / zp;
+            dtmi = (tgt - SOCV(sZM, i) - zm * tm[i] - tm[i] * dyi) / zm;
             ap = ratio(tp[i], dtpi, ap); ap = ratio(tm[i], dtmi, ap);
             ad = ratio(zp, -dyi, ad); ad = ratio(zm, dyi, ad);
             if (rt[i] == ROW_INEQ) {
                 double sig = 0, t = 0, al = 0, au = 0, cl = 0, cu = 0;
                 const bool hl = fin(lo[i]), hu = fin(hi[i]);
-                if (hl) { al = s[i] - lo[i]; cl = tgt - vl[i] * al; sig += vl[i] / al; t += cl / al; }
-                if (hu) { au = hi[i] - s[i]; cu = tgt - vu[i] * au; sig += vu[i] / au; t -= cu / au; }
+                if (hl) { al = s[i] - lo[i]; cl = tgt - SOCV(sVL, i) - vl[i] * al; sig += vl[i] / al; t += cl / al; }
+                if (hu) { au = hi[i] - s[i]; cu = tgt - SOCV(sVU, i) - vu[i] * au; sig += vu[i] / au; t -= cu / au; }
                 dsi = (t - dyi) / sig;
                 if (hl) { dvli = (cl - vl[i] * dsi) / al; ap = ratio(al, dsi, ap); ad = ratio(vl[i], dvli, ad); }
                 if (hu) { dvui = (cu + vu[i] * dsi) / au; ap = ratio(au, -dsi, ap); ad = ratio(vu[i], dvui, ad); }
@@ -521,6 +536,78 @@ __global__ __launch_bounds__(TPB) void k_ipm_step(DV d)
         }
         dy[i] = dyi; ds[i] = dsi; dtp[i] = dtpi; dtm[i] = dtmi; dvl[i] = dvli; dvu[i] = dvui;
     }
+}
+
+// predictor-corrector mode, between the two solves of an iteration (oracle/qp_ipm.c, ipm_run, `if (mpc)`):
+// the solution in `sol` is the affine-scaling predictor.  Mehrotra's rule picks the centring parameter from the
+// complementarity the predictor would reach, the products dz_aff * dx_aff become second-order terms, and the
+// corrector's right-hand side goes through the same factorisation.  If this factorisation needed an inertia
+// correction the sub-problem is not convex along the path: the solve falls back to the monotone rule for good,
+// restarted from the current average complementarity.
+__global__ __launch_bounds__(TPB) void k_mpc(DV d)
+{
+    const int inst = blockIdx.x;
+    if (d.phase[inst] != PH_MPC) return;
+    IpmState &st = d.ist[inst];
+    INST_PTRS
+    const double cavg = st.cavg, mu_min = d.ipm_tol / 10.0;
+    const bool corr = !(st.dw > 0.0);
+    double mu;
+    if (corr) {
+        double ap = 1e300, ad = 1e300;
+        expand_directions(d, inst, 0.0, false, ap, ad);
+        ap = block_reduce<OpMin>(ap); ad = block_reduce<OpMin>(ad);
+        const double ap1 = fmin(1.0, ap), ad1 = fmin(1.0, ad);
+        double *sZL = d.socZL + on, *sZU = d.socZU + on, *sZP = d.socZP + om, *sZM = d.socZM + om,
+               *sVL = d.socVL + om, *sVU = d.socVU + om;
+        double csum = 0.0, nc = 0.0;
+#define PR(zz, dz, xx, dx, dst) do { csum += ((zz) + ad1 * (dz)) * ((xx) + ap1 * (dx)); nc += 1; dst = (dz) * (dx); } while (0)
+        for (int j = threadIdx.x; j < d.n; j += TPB) {
+            double a = 0.0, b = 0.0;
+            if (fin(lb[j])) PR(zl[j], dzl[j], p[j] - lb[j], dp[j], a);
+            if (fin(ub[j])) PR(zu[j], dzu[j], ub[j] - p[j], -dp[j], b);
+            sZL[j] = a; sZU[j] = b;
+        }
+        for (int i = threadIdx.x; i < d.m; i += TPB) {
+            double a = 0.0, b = 0.0, e = 0.0, f = 0.0;
+            if (rt[i] != ROW_FREE) {
+                PR(zpv[i], -dy[i], tp[i], dtp[i], a);
+                PR(zmv[i], dy[i], tm[i], dtm[i], b);
+                if (rt[i] == ROW_INEQ) {
+                    if (fin(lo[i])) PR(vl[i], dvl[i], s[i] - lo[i], ds[i], e);
+                    if (fin(hi[i])) PR(vu[i], dvu[i], hi[i] - s[i], -ds[i], f);
+                }
+            }
+            sZP[i] = a; sZM[i] = b; sVL[i] = e; sVU[i] = f;
+        }
+#undef PR
+        csum = block_reduce<OpSum>(csum); nc = block_reduce<OpSum>(nc);
+        const double mu_aff = nc > 0 ? csum / nc : 0.0;
+        double sigma = cavg > 0.0 ? pow(fmax(0.0, mu_aff) / cavg, 3.0) : 1.0;
+        sigma = fmin(1.0, fmax(sigma, 1e-4));
+        mu = fmax(mu_min, sigma * cavg);
+        __syncthreads();             // second-order terms visible to every thread of build_rhs
+    } else {
+        mu = fmax(mu_min, fmin(1.0, cavg));
+    }
+    const double rn = build_rhs(d, inst, mu, corr);
+    if (threadIdx.x == 0) {
+        st.mu = mu; st.tau = fmax(0.99, 1.0 - mu); st.use_soc = corr ? 1 : 0;
+        if (!corr) st.mpc = 0;
+        st.rn = fmax(1.0, rn);
+        d.phase[inst] = PH_SOLVE2;
+    }
+}
+
+// directions, fraction-to-boundary step lengths, update
+__global__ __launch_bounds__(TPB) void k_ipm_step(DV d)
+{
+    const int inst = blockIdx.x;
+    if (d.phase[inst] != PH_STEP) return;
+    IpmState &st = d.ist[inst];
+    INST_PTRS
+    double ap = 1e300, ad = 1e300;
+    expand_directions(d, inst, st.mu, st.use_soc != 0, ap, ad);
     ap = block_reduce<OpMin>(ap); ad = block_reduce<OpMin>(ad);
     // plain fraction-to-boundary step lengths, primal and dual separately
     const double a = fmin(1.0, st.tau * ap), a_d = fmin(1.0, st.tau * ad);
@@ -668,7 +755,14 @@ void ipm_sweep(Ctx &C, bool sqp_level)
     // the sparse operator.  No iterative refinement: one step of it (the policy until late in round 1, two more
     // launch chains per sweep) changed no iteration count on any test problem -- see oracle/qp_ipm.c, kkt_solve.
     ldlt_solve(C.plan, d.K, d.dinv, d.xv, d.vv, d.phase, PH_SOLVE, true);
-    hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, 1);
+    hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, 1, (int)PH_SOLVE);
+    if (d.ipm_corrector) {
+        // predictor-corrector mode: centring parameter + second-order terms, then the corrector's right-hand side
+        // through the same factors (full forward + backward solve)
+        hipLaunchKernelGGL(k_mpc, gB, bT, 0, s, d);
+        ldlt_solve(C.plan, d.K, d.dinv, d.xv, d.vv, d.phase, PH_SOLVE2, false);
+        hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, 1, (int)PH_SOLVE2);
+    }
     if (C.tm.enabled) { hipEventRecord(ev.second, s); C.tm.pending_solve.push_back(ev); }
     hipLaunchKernelGGL(k_ipm_step, gB, bT, 0, s, d);
     hipLaunchKernelGGL(k_ipm_prepare, gB, bT, 0, s, d);

@@ -297,3 +297,40 @@ def test_acopf_optimum_agrees_with_scipy_trust_constr():
     assert res.constr_violation < 1e-8
     assert abs(res.fun - r["obj_val"]) <= 1e-8 * abs(r["obj_val"])
     assert np.abs(res.x - r["x"]).max() < 1e-5
+
+
+def test_predictor_corrector_and_monotone_rule_agree_on_the_qp_solution():
+    """options.ipm_corrector only changes the path to the solution: both barrier strategies must return the same
+    status, multipliers and optimal value on every sub-problem mode (and the same step p where the Hessian of the
+    Lagrangian makes it unique), and the corrector must need fewer iterations."""
+    import scipy.sparse as sp
+    from sqpsolver_jl_amd.acopf_synth import acopf_synth, acopf_layout, CASES
+    nb, ng, nl, seed = CASES["case14"]
+    net = acopf_synth(nb, ng, nl, seed); lay = acopf_layout(net)
+    P = O.problem_acopf(net, lay); S = P.structure()
+    n = S["n"]
+    jcp, jrv, jslot, _ = O.coo_to_csc(n, S["jrow"], S["jcol"])
+    hcp, hrv, hslot, hslot_t = O.coo_to_csc(n, S["hrow"], S["hcol"], sym=True)
+    solvers = [O.QpSolver(n, S["m"], S["num_linear"], jcp, jrv, hcp, hrv, S["xL"], S["xU"], S["gL"], S["gU"],
+                          O.default_options(ipm_corrector=c)) for c in (0, 1)]
+    rng = np.random.default_rng(2)
+    xr = np.clip(lay.x0 + 0.02 * rng.standard_normal(lay.n), lay.xL, lay.xU)
+    it = [0, 0]
+    for x, lam, unique_p in ((lay.x0, np.zeros(lay.m), False), (xr, 50 * rng.standard_normal(lay.m), True)):
+        df, E, jcoo, hcoo = P.eval_grad_f(x), P.eval_g(x), P.eval_jac_g(x), P.eval_h(x, 1.0, lam)
+        jv = np.zeros(len(jrv)); np.add.at(jv, jslot, jcoo)
+        hv = np.zeros(len(hrv)); np.add.at(hv, hslot, hcoo); ok = hslot_t >= 0; np.add.at(hv, hslot_t[ok], hcoo[ok])
+        Hl = sp.coo_matrix((hcoo, (lay.hrow - 1, lay.hcol - 1)), shape=(n, n)).toarray()
+        H = Hl + Hl.T - np.diag(np.diag(Hl))
+        for mode, delta in ((O.MODE_QP, 10.0), (O.MODE_QP, 0.2), (O.MODE_FR, 0.2), (O.MODE_SOC, 1.0),
+                            (O.MODE_L1QP, 1.0), (O.MODE_INFEAS, 1.0)):
+            r0, r1 = (q.solve(mode, x, delta, 3.0, df, E, jv, hv) for q in solvers)
+            assert r0["status"] == r1["status"]
+            it[0] += r0["ipm_iters"]; it[1] += r1["ipm_iters"]
+            assert np.abs(r0["lam"] - r1["lam"]).max() <= 1e-6 * max(1.0, np.abs(r0["lam"]).max())
+            if mode in (O.MODE_QP, O.MODE_SOC):                # same optimal value of the quadratic model
+                q0, q1 = (df @ r["p"] + 0.5 * r["p"] @ H @ r["p"] for r in (r0, r1))
+                assert abs(q0 - q1) <= 1e-8 * max(1.0, abs(q0))
+                if unique_p and r0["status"] == O.MOI_LOCALLY_SOLVED:
+                    assert np.abs(r0["p"] - r1["p"]).max() <= 1e-7
+    assert it[1] < 0.85 * it[0]
