@@ -64,6 +64,8 @@ def main():
                          "default keeps one group and a clean roofline measurement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--literal-quirks", type=int, default=1)
+    ap.add_argument("--kkt-condense", type=int, default=None,
+                    help="options.kkt_condense (default: the library default)")
     ap.add_argument("--ipm-corrector", type=int, default=1,
                     help="options.ipm_corrector (library default 1: predictor-corrector interior-point iterations)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event timing of k_trailing")
@@ -108,8 +110,9 @@ def main():
     # examples/acopf/opf.jl:72-80
     use_soc = 1 if args.sqp_options == "example" else 0
     sqp_kw = dict(tol_infeas=1e-6, tol_residual=1e-4, use_soc=1) if use_soc else {}
+    lin_kw = {} if args.kkt_condense is None else {"kkt_condense": args.kkt_condense}
     opts = pkg.default_options(max_iter=3000, literal_quirks=args.literal_quirks, device=local_rank,
-                               ipm_corrector=args.ipm_corrector, **sqp_kw)
+                               ipm_corrector=args.ipm_corrector, **lin_kw, **sqp_kw)
     import threading
     G = max(1, min(args.groups, hi - lo))
     ctxs, nets = [], []
@@ -178,7 +181,8 @@ def main():
     n_qp, n_ipm, n_fac = (float(v) for v in stats.tolist())
 
     # roofline of the dominant kernel (k_trailing, fp64 MFMA), rank-0 local measurement
-    N = lay0.n + lay0.m
+    N = int(c1["kkt_order"])            # order of the factorised matrices (n + m, or the condensed order)
+    N_full = lay0.n + lay0.m
     loc_fac = c1["n_factor"] - c0["n_factor"]
     tr_sec = c1["trailing_seconds"] - c0["trailing_seconds"]
     tr_launch = c1["trailing_launches"] - c0["trailing_launches"]
@@ -206,7 +210,7 @@ def main():
         except AttributeError:
             cores = max(1, min(16, os.cpu_count() or 1))
         oo = O.default_options(max_iter=6, literal_quirks=args.literal_quirks, num_threads=cores,
-                               ipm_corrector=args.ipm_corrector, **sqp_kw)
+                               ipm_corrector=args.ipm_corrector, kkt_condense=int(opts.kkt_condense), **sqp_kw)
         ro = O.sqp_solve(O.problem_acopf(*nets[0]), oo)
         cpu = {"value": ro["n_qp"] / ro["qp_seconds"] if ro["qp_seconds"] > 0 else 0.0,
                "unit": "QP subproblems/s", "cores": cores, "kind": "port",
@@ -229,10 +233,12 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{B} x IEEE-{nb}-bus-shaped ACOPF contingency scenarios per GPU "
-                                   f"(BASELINE.json configs[3] shard), dense KKT N={N}, SQP-TR outer iterations",
+                                   f"(BASELINE.json configs[3] shard), KKT order {N_full}"
+                                   + (f" condensed to {N}" if N != N_full else "") + ", dense fp64 LDL^T, SQP-TR outer iterations",
                        "instances_total": total, "kkt_order": N, "use_soc": use_soc, "sqp_options": args.sqp_options,
                        "groups_per_gpu": G,
                        "literal_quirks": args.literal_quirks, "ipm_corrector": args.ipm_corrector,
+                       "kkt_condense": int(opts.kkt_condense), "kkt_order_full": N_full,
                        "qp_solved": n_qp, "ipm_iterations": n_ipm, "kkt_factorisations": n_fac,
                        "ldlt_tflops_wall": n_fac * (N ** 3 / 3.0) / elapsed / 1e12 if elapsed > 0 else 0.0,
                        "instances_done": int(np.sum(g_done))},

@@ -58,6 +58,8 @@ typedef struct {
     int32_t device;          /* HIP device ordinal */
     int32_t ipm_corrector;   /* 1 (default): Mehrotra predictor-corrector iterations until the first inertia
                               * correction of a solve; 0: monotone Fiacco-McCormick rule throughout */
+    int32_t kkt_condense;    /* 1: rows with gL != gU (diagonal block -D of the Newton matrix) are eliminated before
+                              * the factorisation: dense LDL^T of order n + #(gL == gU) instead of n + m */
 } sqphip_options;
 
 void sqphip_default_options(sqphip_options *o);
@@ -173,6 +175,7 @@ typedef struct {
     int64_t n_qp, n_ipm_iter, n_factor;
     double ldlt_flops, ldlt_seconds, trailing_seconds, solve_seconds, total_seconds;
     int64_t trailing_launches;
+    int64_t kkt_order;       /* order of the matrices the LDL^T factorises (n + m, or the condensed order) */
 } sqphip_counters;
 int sqphip_get_counters(sqphip_ctx *ctx, sqphip_counters *c);
 int sqphip_reset_counters(sqphip_ctx *ctx);

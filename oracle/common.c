@@ -25,6 +25,7 @@ void ora_default_options(ora_options *o)
     o->ipm_phase1 = 0;
     o->num_threads = 1;
     o->ipm_corrector = 1;
+    o->kkt_condense = 1;
 }
 
 /* Julia's isapprox(a, b) with default rtol = sqrt(eps), atol = 0

@@ -25,7 +25,7 @@ class Options(C.Structure):
                [("max_iter", C.c_int), ("use_soc", C.c_int), ("literal_quirks", C.c_int),
                 ("ipm_tol", C.c_double),
                 ("ipm_max_iter", C.c_int), ("ipm_phase1", C.c_int), ("num_threads", C.c_int),
-                ("ipm_corrector", C.c_int)]
+                ("ipm_corrector", C.c_int), ("kkt_condense", C.c_int)]
 
 
 class TraceRow(C.Structure):

@@ -63,6 +63,8 @@ typedef struct {
     int ipm_corrector; /* 1 (default): Mehrotra predictor-corrector (adaptive barrier parameter + second-order term,
                           two solves per factorisation) while the sub-problem behaves convex, monotone rule from the
                           first inertia correction on; 0: monotone Fiacco-McCormick rule throughout */
+    int kkt_condense;  /* 1: eliminate the rows with gL != gU (their block of the Newton matrix is the diagonal -D)
+                          before factorising: dense LDL^T of order n + #equality rows instead of n + m */
 } ora_options;
 
 typedef double (*ora_eval_f_t)(void *ud, const double *x);

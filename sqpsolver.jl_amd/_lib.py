@@ -38,14 +38,15 @@ class Options(C.Structure):
                  "rho", "eta", "tau", "min_alpha")] + \
                [("max_iter", C.c_int32), ("use_soc", C.c_int32), ("literal_quirks", C.c_int32),
                 ("ipm_tol", C.c_double), ("ipm_max_iter", C.c_int32), ("ipm_phase1", C.c_int32),
-                ("device", C.c_int32), ("ipm_corrector", C.c_int32)]
+                ("device", C.c_int32), ("ipm_corrector", C.c_int32),
+                ("kkt_condense", C.c_int32)]
 
 
 class Counters(C.Structure):
     _fields_ = [("n_qp", C.c_int64), ("n_ipm_iter", C.c_int64), ("n_factor", C.c_int64),
                 ("ldlt_flops", C.c_double), ("ldlt_seconds", C.c_double),
                 ("trailing_seconds", C.c_double), ("solve_seconds", C.c_double),
-                ("total_seconds", C.c_double), ("trailing_launches", C.c_int64)]
+                ("total_seconds", C.c_double), ("trailing_launches", C.c_int64), ("kkt_order", C.c_int64)]
 
 
 def lib():

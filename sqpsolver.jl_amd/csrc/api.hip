@@ -99,7 +99,7 @@ extern "C" void sqphip_default_options(sqphip_options *o)
     o->init_mu = 1.0; o->max_mu = 1e10; o->tr_size = 10.0;
     o->rho = 0.8; o->eta = 0.4; o->tau = 0.9; o->min_alpha = 1e-6;
     o->max_iter = 3000; o->use_soc = 0; o->literal_quirks = 1;
-    o->ipm_tol = 1e-9; o->ipm_max_iter = 200; o->ipm_phase1 = 0; o->device = 0; o->ipm_corrector = 1;
+    o->ipm_tol = 1e-9; o->ipm_max_iter = 200; o->ipm_phase1 = 0; o->device = 0; o->ipm_corrector = 1; o->kkt_condense = 1;
 }
 
 extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num_linear, int64_t nnzJ,
@@ -127,7 +127,17 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
         C.n = n; C.m = m;
         const int B = batch;
         d.n = (int)n; d.m = (int)m; d.nlin = (int)num_linear; d.N = (int)(n + m);
-        d.Npad = (d.N + 63) / 64 * 64; d.ld = d.Npad; d.B = B;
+        d.Npad = (d.N + 63) / 64 * 64; d.B = B;
+        {   // condensed form: rows with gL == gU stay in the factorised matrix, all others are eliminated
+            std::vector<int> kpos(m > 0 ? m : 1, -1), krow;
+            for (int64_t i = 0; i < m; ++i) if (gL[i] == gU[i]) { kpos[i] = (int)krow.size(); krow.push_back((int)i); }
+            d.condense = opt->kkt_condense != 0; d.mk = (int)krow.size();
+            if (krow.empty()) krow.push_back(0);
+            d.kpos = C.upload(kpos); d.krow = C.upload(krow);
+            C.h_kpos = kpos;
+            d.Nf = d.condense ? d.n + d.mk : d.N;
+            d.Fpad = (d.Nf + 63) / 64 * 64; d.ld = d.Fpad;
+        }
         d.nnzj_coo = (int)nnzJ; d.nnzh_coo = (int)nnzH;
         Pattern PJ = build_pattern(n, nnzJ, jrow, jcol, false);
         Pattern PH = build_pattern(n, nnzH, hrow, hcol, true);
@@ -172,17 +182,18 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
         d.rtype = C.dalloc<int>(Bm); d.rbase = C.dalloc<int>(Bm); d.hard = C.dalloc<int>(Bm);
         d.rhs = C.dalloc<double>(BN); d.sol = C.dalloc<double>(BN); d.wN = C.dalloc<double>(BN);
         d.xv = C.dalloc<double>(BN); d.vv = C.dalloc<double>(BN); d.dinv = C.dalloc<double>(BN);
-        d.K = C.dalloc<double>((size_t)B * d.ld * d.Npad);
+        d.K = C.dalloc<double>((size_t)B * d.ld * d.Fpad);
         d.ist = C.dalloc<IpmState>(B); d.sst = C.dalloc<SqpState>(B);
         d.phase = C.dalloc<int>(B); d.counters = C.dalloc<int>(8);
         d.trace = C.dalloc<double>((size_t)B * SQPHIP_TRACE_CAP * SQPHIP_TRACE_COLS);
         d.ipm_tol = opt->ipm_tol; d.ipm_max_iter = opt->ipm_max_iter; d.ipm_phase1 = opt->ipm_phase1; d.ipm_corrector = opt->ipm_corrector;
+        d.refine_tol = getenv("SQPHIP_REFINE_TOL") ? atof(getenv("SQPHIP_REFINE_TOL")) : 1e-11;
         d.tol_direction = opt->tol_direction; d.tol_residual = opt->tol_residual;
         d.tol_infeas = opt->tol_infeas; d.init_mu = opt->init_mu; d.tr_size = opt->tr_size;
         d.max_iter = opt->max_iter; d.use_soc = opt->use_soc; d.literal_quirks = opt->literal_quirks;
-        C.plan.N = d.N; C.plan.Npad = d.Npad; C.plan.T = d.Npad / 64; C.plan.ld = d.ld; C.plan.B = B;
+        C.plan.N = d.Nf; C.plan.Npad = d.Fpad; C.plan.T = d.Fpad / 64; C.plan.ld = d.ld; C.plan.B = B;
         C.plan.stream = C.stream;
-        C.plan.Wbuf = C.dalloc<double>((size_t)2 * LdltPlan::MAX_R * B * d.Npad * 64);
+        C.plan.Wbuf = C.dalloc<double>((size_t)2 * LdltPlan::MAX_R * B * d.Fpad * 64);
         C.plan.init_lookahead();
         SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
         return SQPHIP_OK;
@@ -211,6 +222,15 @@ extern "C" int sqphip_set_bounds(sqphip_ctx *h, int32_t inst, const double *xL, 
     if (!h || inst < 0 || inst >= h->c.d.B) return SQPHIP_EINVAL;
     return guarded(h, [&](Ctx &C) {
         DV &d = C.d;
+        // condensed form: the kept-row set was fixed at creation; an instance may not turn an eliminated row into
+        // an equality (its D would sit at the regularisation and 1/D in the condensed matrix at 1e8)
+        if (d.condense)
+            for (int i = 0; i < d.m; ++i)
+                if (gL[i] == gU[i] && C.h_kpos[i] < 0) {
+                    C.err = "sqphip_set_bounds: row " + std::to_string(i) + " is an equality for this instance but was "
+                            "not one when the context was created (options.kkt_condense = 1 fixes the kept rows)";
+                    return SQPHIP_EINVAL;
+                }
         h2d(C, d.xL + (size_t)inst * d.n, xL, d.n); h2d(C, d.xU + (size_t)inst * d.n, xU, d.n);
         h2d(C, d.gL + (size_t)inst * d.m, gL, d.m); h2d(C, d.gU + (size_t)inst * d.m, gU, d.m);
         SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
@@ -551,7 +571,8 @@ extern "C" int sqphip_get_counters(sqphip_ctx *h, sqphip_counters *c)
         int64_t nqp = C.n_qp, nip = C.n_ipm_iter, nf = C.n_factor;
         for (auto &s : S) { nqp += s.n_qp; nip += s.tot_ipm; nf += s.tot_fac; }
         c->n_qp = nqp; c->n_ipm_iter = nip; c->n_factor = nf;
-        const double N = (double)C.d.N;
+        const double N = (double)C.d.Nf;
+        c->kkt_order = C.d.Nf;
         c->ldlt_flops = (double)nf * N * N * N / 3.0;
         c->ldlt_seconds = C.tm.factor_seconds; c->trailing_seconds = C.tm.trailing_seconds;
         c->solve_seconds = C.tm.solve_seconds; c->total_seconds = C.total_seconds;

@@ -2,6 +2,7 @@
 // dimensions and sparsity, and the per-instance state machines of the interior-point method and
 // of the SQP-TR outer loop.  Everything numerical lives in HBM; the host only sequences kernels.
 #pragma once
+#include <vector>
 #include "../../include/sqphip.h"
 #include "sqphip_internal.hpp"
 
@@ -43,7 +44,11 @@ struct SqpState {
 
 // everything kernels need, by value
 struct DV {
-    int n, m, nlin, N, Npad, ld, B;
+    int n, m, nlin, N, Npad, ld, B;       // N = n + m, Npad = stride of the full-length vectors rhs / sol / wN
+    int Nf, Fpad;                         // order of the factorised matrix (N, or n + mk condensed) and its padding:
+                                          // K is Fpad x Fpad (ld = Fpad); xv / vv / dinv have stride Fpad
+    int condense, mk;                     // options.kkt_condense; number of kept (gL == gU) rows
+    const int *kpos, *krow;               // row -> position among the kept rows or -1; kept position -> row
     int nnzj_coo, nnzh_coo, nnzjc, nnzhc;
     // shared structure
     const int *jcolptr, *jrowval, *jrowptr, *jrcol, *jrslot;
@@ -70,6 +75,7 @@ struct DV {
     int *counters;      // [0] instances iterating, [1] start flags, [2] SQP not done, [3] start flags
     double ipm_tol;
     int ipm_max_iter, ipm_phase1, ipm_corrector;
+    double refine_tol;                    // refinement step when the relative residual is above this (condensed form)
     // ---- SQP level
     double *x, *lambda, *mxL, *mxU, *df, *E, *pstep, *psoc, *plam, *pmxL, *pmxU, *Esoc, *tmpx, *tmpE,
         *hlam;
@@ -94,6 +100,7 @@ struct Ctx {
     std::string err;
     hipStream_t stream = nullptr;
     int *h_counters = nullptr;  // pinned
+    std::vector<int> h_kpos;    // host copy of DV::kpos (row -> kept position or -1)
     bool acopf_attached = false;
     // host copies of structure for misc use
     int64_t n = 0, m = 0;

@@ -336,25 +336,31 @@ __global__ __launch_bounds__(TPB) void k_ipm_prepare(DV d)
 // ---------------------------------------------------------------------------------------------
 // K4: dense KKT assembly, one workgroup per column: zero the column from the diagonal down, then
 // scatter H (lower), J and the diagonals.  Padding columns are identity.
+// Condensed form (options.kkt_condense, oracle/qp_ipm.c kkt_assemble_condensed): rows with gL != gU have the
+// diagonal block -(D + reg) and are eliminated exactly,
+//   [ W + J_I' (D_I + reg)^-1 J_I    J_E' ]      order n + mk instead of n + m;
+//   [ J_E                       -(D_E + reg) ]
+// the inertia rule is unchanged (n positive pivots): the eliminated block is negative definite.
 __global__ __launch_bounds__(128) void k_kkt_assemble(DV d)
 {
     const int inst = blockIdx.y;
     if (d.phase[inst] != PH_FACTOR) return;
     const int j = blockIdx.x;
     const IpmState &st = d.ist[inst];
-    double *col = d.K + (long)inst * d.ld * d.Npad + (long)j * d.ld;
-    for (int i = j + threadIdx.x; i < d.Npad; i += 128) col[i] = 0.0;
+    double *col = d.K + (long)inst * d.ld * d.Fpad + (long)j * d.ld;
+    for (int i = j + threadIdx.x; i < d.Fpad; i += 128) col[i] = 0.0;
     __syncthreads();
     if (threadIdx.x != 0) return;
-    if (j >= d.N) { col[j] = 1.0; return; }
+    if (j >= d.Nf) { col[j] = 1.0; return; }
     if (j >= d.n) {
-        const int i = j - d.n;
+        const int i = d.condense ? d.krow[j - d.n] : j - d.n;
         col[j] = d.rtype[(long)inst * d.m + i] == ROW_FREE ? -1.0 : -(d.Dd[(long)inst * d.m + i] + IPM_REG_D);
         return;
     }
     const double hsc = st.hsc;
     const double *hv = d.hv + (long)inst * d.nnzhc, *jv = d.jv + (long)inst * d.nnzjc;
     const int *rt = d.rtype + (long)inst * d.m;
+    const double *Dd = d.Dd + (long)inst * d.m;
     double diag = d.hd[(long)inst * d.n + j] + d.sigp[(long)inst * d.n + j] + st.dw + IPM_REG_P;
     for (int k = d.hcolptr[j]; k < d.hcolptr[j + 1]; ++k) {
         const int i = d.hrowval[k];
@@ -364,7 +370,13 @@ __global__ __launch_bounds__(128) void k_kkt_assemble(DV d)
     col[j] = diag;
     for (int k = d.jcolptr[j]; k < d.jcolptr[j + 1]; ++k) {
         const int i = d.jrowval[k];
-        if (rt[i] != ROW_FREE) col[d.n + i] += jv[k];
+        if (rt[i] == ROW_FREE) continue;
+        if (!d.condense) { col[d.n + i] += jv[k]; continue; }
+        if (d.kpos[i] >= 0) { col[d.n + d.kpos[i]] += jv[k]; continue; }
+        // eliminated row i: its share J_i' (D_i + reg)^-1 J_i of column j (lower part)
+        const double f = jv[k] / (Dd[i] + IPM_REG_D);
+        for (int t = d.jrowptr[i]; t < d.jrowptr[i + 1]; ++t)
+            if (d.jrcol[t] >= j) col[d.jrcol[t]] += f * jv[d.jrslot[t]];
     }
 }
 
@@ -374,6 +386,27 @@ __global__ __launch_bounds__(128) void k_kkt_assemble(DV d)
     const double *sZL = d.socZL + on, *sZU = d.socZU + on, *sZP = d.socZP + om, *sZM = d.socZM + om, \
                  *sVL = d.socVL + om, *sVU = d.socVU + om;
 #define SOCV(a, k) (soc ? (a)[k] : 0.0)
+
+// working vector of the triangular solves from a full-length right-hand side src = [g; b] (published to the
+// workgroup by the caller).  Full form: a copy.  Condensed form: g + J_I' (D_I + reg)^-1 b_I on top, b_E below.
+__device__ void load_solve_vector(const DV &d, int inst, const double *src, double *xv)
+{
+    if (!d.condense) {
+        for (int i = threadIdx.x; i < d.Fpad; i += TPB) xv[i] = i < d.N ? src[i] : 0.0;
+        return;
+    }
+    const double *jv = d.jv + (long)inst * d.nnzjc, *Dd = d.Dd + (long)inst * d.m;
+    const int *rt = d.rtype + (long)inst * d.m;
+    for (int j = threadIdx.x; j < d.n; j += TPB) {
+        double acc = 0.0;
+        for (int k = d.jcolptr[j]; k < d.jcolptr[j + 1]; ++k) {
+            const int i = d.jrowval[k];
+            if (rt[i] != ROW_FREE && d.kpos[i] < 0) acc += jv[k] * src[d.n + i] / (Dd[i] + IPM_REG_D);
+        }
+        xv[j] = src[j] + acc;
+    }
+    for (int k = threadIdx.x; k < d.Fpad - d.n; k += TPB) xv[d.n + k] = k < d.mk ? src[d.n + d.krow[k]] : 0.0;
+}
 
 // Newton right-hand side for centring target tgt (minus the second-order terms when soc), its working copy xv
 // for the triangular solves, sol = 0.  Returns max |rhs| (block-wide).
@@ -403,13 +436,9 @@ __device__ double build_rhs(const DV &d, int inst, double tgt, bool soc)
         }
         rhs[d.n + i] = b; rn = fmax(rn, fabs(b));
     }
-    rn = block_reduce<OpMax>(rn);
-    double *xv = d.xv + (long)inst * d.Npad;
-    for (int i = threadIdx.x; i < d.Npad; i += TPB) {
-        const double v = i < d.N ? rhs[i] : 0.0;
-        xv[i] = v;
-        sol[i] = 0.0;
-    }
+    rn = block_reduce<OpMax>(rn);        // (its barriers also publish rhs to the whole workgroup)
+    for (int i = threadIdx.x; i < d.Npad; i += TPB) sol[i] = 0.0;
+    load_solve_vector(d, inst, rhs, d.xv + (long)inst * d.Fpad);
     return rn;
 }
 
@@ -432,9 +461,9 @@ __global__ __launch_bounds__(TPB) void k_inertia(DV d)
     const int inst = blockIdx.x;
     if (d.phase[inst] != PH_FACTOR) return;
     IpmState &st = d.ist[inst];
-    const double *dinv = d.dinv + (long)inst * d.Npad;
+    const double *dinv = d.dinv + (long)inst * d.Fpad;
     double np = 0, bad = 0;
-    for (int i = threadIdx.x; i < d.N; i += TPB) {
+    for (int i = threadIdx.x; i < d.Nf; i += TPB) {
         const double v = dinv[i];
         if (!fin(v) || v == 0.0) bad += 1; else if (v > 0) np += 1;
     }
@@ -456,15 +485,36 @@ __global__ __launch_bounds__(TPB) void k_inertia(DV d)
     d.phase[inst] = PH_SOLVE;
 }
 
-// after a triangular solve: accumulate, form the residual against the sparse operator, decide
+// after a triangular solve: accumulate (expanding the eliminated rows in the condensed form), form the residual
+// against the full sparse operator, decide.  Condensed form: one refinement step when the residual is above 1e-11
+// relative (the elimination puts 1/D-sized terms into the matrix; see oracle/qp_ipm.c, kkt_solve) -- the residual
+// becomes the next right-hand side, the sweep runs one more forward/backward solve and calls this kernel with last = 1.
 __global__ __launch_bounds__(TPB) void k_refine(DV d, int last, int want)
 {
     const int inst = blockIdx.x;
     if (d.phase[inst] != want) return;
     IpmState &st = d.ist[inst];
     INST_PTRS
-    double *xv = d.xv + (long)inst * d.Npad;
-    for (int i = threadIdx.x; i < d.N; i += TPB) sol[i] += xv[i];
+    double *xv = d.xv + (long)inst * d.Fpad;
+    const int refine_it = st.refine_it;      // read before the first barrier, written by thread 0 at the end
+    if (!d.condense) {
+        for (int i = threadIdx.x; i < d.N; i += TPB) sol[i] += xv[i];
+    } else {
+        // the right-hand side this solve answered: the Newton rhs, or the residual of the first pass
+        const double *cur = refine_it == 0 ? rhs : wN;
+        for (int j = threadIdx.x; j < d.n; j += TPB) sol[j] += xv[j];
+        for (int i = threadIdx.x; i < d.m; i += TPB) {
+            double v;
+            if (d.kpos[i] >= 0) v = xv[d.n + d.kpos[i]];
+            else if (rt[i] == ROW_FREE) v = -cur[d.n + i];
+            else {      // eliminated row: q_i = (J_i dp - b_i) / (D_i + reg)
+                double acc = 0.0;
+                for (int t = d.jrowptr[i]; t < d.jrowptr[i + 1]; ++t) acc += jv[d.jrslot[t]] * xv[d.jrcol[t]];
+                v = (acc - cur[d.n + i]) / (Dd[i] + IPM_REG_D);
+            }
+            sol[d.n + i] += v;
+        }
+    }
     __syncthreads();
     const double hsc = st.hsc;
     // res = rhs - K sol : top block (H + hd + sigp + dw) dp + J' q ; bottom J dp - D q
@@ -482,11 +532,9 @@ __global__ __launch_bounds__(TPB) void k_refine(DV d, int last, int want)
         const double r = rhs[d.n + i] - (wN[d.n + i] - dd * sol[d.n + i]);
         wN[d.n + i] = r; en = fmax(en, fabs(r));
     }
-    const int refine_it = st.refine_it;      // read before the reduction's barriers, written by thread 0 below
-    en = block_reduce<OpMax>(en);
-    const bool stop = last || refine_it >= 1 || !(en > 1e-11 * st.rn);
-    if (!stop)
-        for (int i = threadIdx.x; i < d.Npad; i += TPB) xv[i] = i < d.N ? wN[i] : 0.0;
+    en = block_reduce<OpMax>(en);            // (its barriers publish wN)
+    const bool stop = last || refine_it >= 1 || !(en > d.refine_tol * st.rn);
+    if (!stop) load_solve_vector(d, inst, wN, xv);
     if (threadIdx.x == 0) {
         st.relres = en / st.rn;
         // predictor-corrector mode: the first solve was the predictor, k_mpc builds the corrector's system
@@ -594,7 +642,7 @@ __global__ __launch_bounds__(TPB) void k_mpc(DV d)
     if (threadIdx.x == 0) {
         st.mu = mu; st.tau = fmax(0.99, 1.0 - mu); st.use_soc = corr ? 1 : 0;
         if (!corr) st.mpc = 0;
-        st.rn = fmax(1.0, rn);
+        st.rn = fmax(1.0, rn); st.refine_it = 0;
         d.phase[inst] = PH_SOLVE2;
     }
 }
@@ -743,7 +791,7 @@ void ipm_sweep(Ctx &C, bool sqp_level)
     hipLaunchKernelGGL(k_qp_gather, gB, bT, 0, s, d);
     hipLaunchKernelGGL(k_ipm_start, gB, bT, 0, s, d);
     hipLaunchKernelGGL(k_ipm_prepare, gB, bT, 0, s, d);
-    hipLaunchKernelGGL(k_kkt_assemble, dim3(d.Npad, d.B), dim3(128), 0, s, d);
+    hipLaunchKernelGGL(k_kkt_assemble, dim3(d.Fpad, d.B), dim3(128), 0, s, d);
     hipLaunchKernelGGL(k_build_rhs, gB, bT, 0, s, d);
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (C.tm.enabled) { ev = C.tm.get(); hipEventRecord(ev.first, s); }
@@ -755,13 +803,22 @@ void ipm_sweep(Ctx &C, bool sqp_level)
     // the sparse operator.  No iterative refinement: one step of it (the policy until late in round 1, two more
     // launch chains per sweep) changed no iteration count on any test problem -- see oracle/qp_ipm.c, kkt_solve.
     ldlt_solve(C.plan, d.K, d.dinv, d.xv, d.vv, d.phase, PH_SOLVE, true);
-    hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, 1, (int)PH_SOLVE);
+    const bool refine = d.condense != 0;     // condensed form: one conditional refinement step per direction
+    hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, refine ? 0 : 1, (int)PH_SOLVE);
+    if (refine) {
+        ldlt_solve(C.plan, d.K, d.dinv, d.xv, d.vv, d.phase, PH_SOLVE, false);
+        hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, 1, (int)PH_SOLVE);
+    }
     if (d.ipm_corrector) {
         // predictor-corrector mode: centring parameter + second-order terms, then the corrector's right-hand side
         // through the same factors (full forward + backward solve)
         hipLaunchKernelGGL(k_mpc, gB, bT, 0, s, d);
         ldlt_solve(C.plan, d.K, d.dinv, d.xv, d.vv, d.phase, PH_SOLVE2, false);
-        hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, 1, (int)PH_SOLVE2);
+        hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, refine ? 0 : 1, (int)PH_SOLVE2);
+        if (refine) {
+            ldlt_solve(C.plan, d.K, d.dinv, d.xv, d.vv, d.phase, PH_SOLVE2, false);
+            hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, 1, (int)PH_SOLVE2);
+        }
     }
     if (C.tm.enabled) { hipEventRecord(ev.second, s); C.tm.pending_solve.push_back(ev); }
     hipLaunchKernelGGL(k_ipm_step, gB, bT, 0, s, d);

@@ -162,28 +162,46 @@ def _oracle_qp(P, S, opts=None):
     return solve
 
 
-def _compare_qp(ro, rg, mult_tol=TOL):
+def _compare_qp(ro, rg, mult_tol=TOL, p_tol=TOL):
     assert rg["status"] == ro["status"]
     for k in ("p", "lam", "mult_x_U", "mult_x_L"):
-        assert rel(rg[k], ro[k]) < (TOL if k == "p" else mult_tol), k
+        assert rel(rg[k], ro[k]) < (p_tol if k == "p" else mult_tol), k
+    if p_tol > TOL and ro["status"] == O.MOI_LOCALLY_SOLVED:  # p compared loosely: the optimal value must still agree
+        vo, vg = float(np.sum(ro["slack"])), float(np.sum(rg["slack"]))
+        assert abs(vg - vo) <= TOL * max(1.0, abs(vo))
     if ro["status"] == O.MOI_LOCALLY_SOLVED:
-        assert rg["ipm_iters"] == ro["ipm_iters"]
+        if p_tol > TOL:      # optimal face + jammed ratio tests: see the note above _tols (hs071 FR: 18 vs 13 iterations)
+            assert abs(rg["ipm_iters"] - ro["ipm_iters"]) <= max(2, ro["ipm_iters"] // 2)
+        else:
+            assert rg["ipm_iters"] == ro["ipm_iters"]
     else:
         assert not rg["p"].any() and not rg["lam"].any()      # subproblem_JuMP.jl:551-555
 
 
-# FR / INFEAS / LP-phase programmes are linear programmes with a non-trivial optimal dual face on these problems:
-# p is unique, the multipliers are the point of that face the central path ends in.  The predictor-corrector
-# iterations (options.ipm_corrector = 1, the default) reach the tolerance in about four long steps, and the last
-# linear solve (relative residual 1e-12 instead of 1e-16) leaves the position inside the face determined to ~1e-6
-# only -- the same effect as in test_qp_full_size_case118_kkt_properties.  With the corrector the multipliers of
-# those modes are compared at 1e-5; everything else, and everything under the monotone rule, at 1e-8.
+# FR / INFEAS / LP-phase programmes are linear programmes with non-trivial optimal faces on these problems.
+# * FR and INFEAS minimise the elastic mass only: every p that reaches the minimum is optimal (hs071 at x0, FR,
+#   radius 0.5: the whole segment p0 + p3 = 0.2 is), and an interior-point run ends at whatever point of that face
+#   its path leads to.  Two implementations agree on it only as far as they stay on one trajectory, and a run
+#   that spends iterations with step lengths of 1e-3 (the ratio test jammed on a bound) amplifies last-digit
+#   differences a million-fold.  For these two modes p is compared at 1e-5, the optimal value (total elastic
+#   mass) at 1e-8 and the iteration count within a half -- the same treatment as in
+#   test_qp_full_size_case118_kkt_properties.  (With SQPHIP_REFINE_TOL=0 ORA_REFINE_TOL=0, i.e. a refinement step
+#   after every solve of the condensed system, both sides stay on one trajectory and every count is equal again;
+#   the default refines above a relative residual of 1e-11 only, which is 13 % faster.)
+# * All three have a non-trivial optimal DUAL face.  The monotone rule ends on well-centred iterates and pins the
+#   multipliers to 1e-8; the predictor-corrector iterations (options.ipm_corrector = 1, the default) reach the
+#   tolerance in about four long steps, the last linear solve has a relative residual of 1e-12 instead of 1e-16,
+#   and the position inside the dual face is determined to ~2e-6 only: multipliers at 1e-5 with the corrector.
+# Everything else -- p of the QP / SOC / L1QP / LP-phase programmes, their multipliers, statuses, iteration
+# counts -- is compared at 1e-8.
 LP_LIKE = (O.MODE_FR, O.MODE_INFEAS, O.MODE_LP)
 LP_MULT_TOL = 1e-5
+FACE_P_TOL = 1e-5
 
 
-def _mult_tol(mode, corrector):
-    return LP_MULT_TOL if (corrector and mode in LP_LIKE) else TOL
+def _tols(mode, corrector):
+    return dict(mult_tol=LP_MULT_TOL if (corrector and mode in LP_LIKE) else TOL,
+                p_tol=FACE_P_TOL if mode in (O.MODE_FR, O.MODE_INFEAS) else TOL)
 
 
 @pytest.mark.parametrize("corrector", [1, 0])
@@ -202,7 +220,7 @@ def test_qp_modes_small_problems(name, corrector):
         for mode in (O.MODE_QP, O.MODE_FR, O.MODE_SOC, O.MODE_LP, O.MODE_L1QP, O.MODE_INFEAS):
             for delta in (10.0, 0.5):
                 _compare_qp(osolve(mode, x, delta, 7.0, df, E, jv, hv), ctx.qp_solve(mode, x, delta, 7.0, df, E, jv, hv),
-                            mult_tol=_mult_tol(mode, corrector))
+                            **_tols(mode, corrector))
     ctx.close()
 
 
@@ -223,7 +241,7 @@ def test_qp_modes_case14(corrector):
         for mode, delta in ((O.MODE_LP, 10.0), (O.MODE_QP, 10.0), (O.MODE_QP, 0.2), (O.MODE_FR, 0.2),
                             (O.MODE_SOC, 1.0), (O.MODE_L1QP, 1.0), (O.MODE_INFEAS, 1.0)):
             _compare_qp(osolve(mode, x, delta, 3.0, df, E, jv, hv), ctx.qp_solve(mode, x, delta, 3.0, df, E, jv, hv),
-                        mult_tol=_mult_tol(mode, corrector))
+                        **_tols(mode, corrector))
     ctx.close()
 
 
@@ -235,6 +253,62 @@ def test_batched_sqp_with_monotone_barrier(quirks):
     nets = [base, contingency(base, 2, seed), contingency(base, 5, seed)]
     lays = [acopf_layout(nt) for nt in nets]
     kw = dict(max_iter=25, tol_infeas=1e-6, tol_residual=1e-4, literal_quirks=quirks, ipm_corrector=0)
+    ctx = pkg.Context(lays[0].n, lays[0].m, lays[0].num_linear, lays[0].jrow, lays[0].jcol, lays[0].hrow, lays[0].hcol,
+                      lays[0].xL, lays[0].xU, lays[0].gL, lays[0].gU, pkg.default_options(**kw), batch=len(nets))
+    ctx.acopf_attach(base, lays[0])
+    for b in range(len(nets)):
+        ctx.acopf_set_instance(b, nets[b], lays[b])
+    ctx.sqp_reset(); ctx.sqp_run(0)
+    for b in range(len(nets)):
+        ro = O.sqp_solve(O.problem_acopf(nets[b], lays[b]), O.default_options(**kw))
+        rg = ctx.sqp_get(b)
+        assert (rg["status"], rg["iter"]) == (ro["status"], ro["iter"])
+        tol = TOL if ro["status"] == 0 else TOL_TRAJ
+        assert rel(rg["x"], ro["x"]) < tol and abs(rg["obj_val"] - ro["obj_val"]) <= tol * abs(ro["obj_val"])
+    ctx.close()
+
+
+def test_condensed_kkt_qp_modes_match_oracle():
+    """options.kkt_condense = 1: the rows with gL != gU are eliminated before the factorisation (order n + mk
+    instead of n + m).  Exact block elimination, so every mode must reproduce the oracle's condensed run at 1e-8
+    with the same iteration counts -- and the oracle's condensed and full runs agree with each other (CPU test)."""
+    nb, ng, nl, seed = CASES["case14"]
+    net = acopf_synth(nb, ng, nl, seed); lay = acopf_layout(net)
+    P = O.problem_acopf(net, lay); S = P.structure()
+    for corrector in (1, 0):
+        ctx = pkg.Context(lay.n, lay.m, lay.num_linear, lay.jrow, lay.jcol, lay.hrow, lay.hcol, lay.xL, lay.xU,
+                          lay.gL, lay.gU, pkg.default_options(ipm_corrector=corrector, kkt_condense=1))
+        assert ctx.counters()["kkt_order"] == lay.n + int((lay.gL == lay.gU).sum()) < lay.n + lay.m
+        osolve = _oracle_qp(P, S, O.default_options(ipm_corrector=corrector, kkt_condense=1))
+        rng = np.random.default_rng(2)
+        xr = np.clip(lay.x0 + 0.02 * rng.standard_normal(lay.n), lay.xL, lay.xU)
+        for x, lam in ((lay.x0, np.zeros(lay.m)), (xr, 50 * rng.standard_normal(lay.m))):
+            df, E, jv, hv = P.eval_grad_f(x), P.eval_g(x), P.eval_jac_g(x), P.eval_h(x, 1.0, lam)
+            for mode, delta in ((O.MODE_LP, 10.0), (O.MODE_QP, 10.0), (O.MODE_QP, 0.2), (O.MODE_FR, 0.2),
+                                (O.MODE_SOC, 1.0), (O.MODE_L1QP, 1.0), (O.MODE_INFEAS, 1.0)):
+                _compare_qp(osolve(mode, x, delta, 3.0, df, E, jv, hv), ctx.qp_solve(mode, x, delta, 3.0, df, E, jv, hv),
+                            **_tols(mode, corrector))
+        ctx.close()
+    for name in ("toy", "hs071"):                              # no / few equality rows: the condensed order is ~ n
+        P = getattr(O, "problem_" + name)(); S = P.structure()
+        ctx = pkg.Context(S["n"], S["m"], S["num_linear"], S["jrow"], S["jcol"], S["hrow"], S["hcol"], S["xL"], S["xU"],
+                          S["gL"], S["gU"], pkg.default_options(kkt_condense=1))
+        osolve = _oracle_qp(P, S, O.default_options(kkt_condense=1))
+        x = P.x0
+        df, E, jv, hv = P.eval_grad_f(x), P.eval_g(x), P.eval_jac_g(x), P.eval_h(x, 1.0, np.zeros(S["m"]))
+        for mode in (O.MODE_QP, O.MODE_FR, O.MODE_SOC, O.MODE_LP, O.MODE_L1QP, O.MODE_INFEAS):
+            _compare_qp(osolve(mode, x, 10.0, 7.0, df, E, jv, hv), ctx.qp_solve(mode, x, 10.0, 7.0, df, E, jv, hv),
+                        **_tols(mode, 1))
+        ctx.close()
+
+
+@pytest.mark.parametrize("quirks", [1, 0])
+def test_batched_sqp_with_condensed_kkt(quirks):
+    nb, ng, nl, seed = CASES["case14"]
+    base = acopf_synth(nb, ng, nl, seed)
+    nets = [base, contingency(base, 1, seed), contingency(base, 4, seed), contingency(base, 7, seed)]
+    lays = [acopf_layout(nt) for nt in nets]
+    kw = dict(max_iter=25, tol_infeas=1e-6, tol_residual=1e-4, literal_quirks=quirks, use_soc=1, kkt_condense=1)
     ctx = pkg.Context(lays[0].n, lays[0].m, lays[0].num_linear, lays[0].jrow, lays[0].jcol, lays[0].hrow, lays[0].hcol,
                       lays[0].xL, lays[0].xU, lays[0].gL, lays[0].gU, pkg.default_options(**kw), batch=len(nets))
     ctx.acopf_attach(base, lays[0])
