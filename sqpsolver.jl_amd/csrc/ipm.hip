@@ -538,7 +538,8 @@ __global__ __launch_bounds__(TPB) void k_refine(DV d, int last, int want)
     if (threadIdx.x == 0) {
         st.relres = en / st.rn;
         // predictor-corrector mode: the first solve was the predictor, k_mpc builds the corrector's system
-        if (stop) d.phase[inst] = (want == PH_SOLVE && st.mpc) ? PH_MPC : PH_STEP; else st.refine_it++;
+        if (stop) d.phase[inst] = (want == PH_SOLVE && st.mpc) ? PH_MPC : PH_STEP;
+        else { st.refine_it++; d.counters[4] = 1; }       // tells the host that a refinement pass is wanted
     }
 }
 
@@ -803,22 +804,30 @@ void ipm_sweep(Ctx &C, bool sqp_level)
     // the sparse operator.  No iterative refinement: one step of it (the policy until late in round 1, two more
     // launch chains per sweep) changed no iteration count on any test problem -- see oracle/qp_ipm.c, kkt_solve.
     ldlt_solve(C.plan, d.K, d.dinv, d.xv, d.vv, d.phase, PH_SOLVE, true);
-    const bool refine = d.condense != 0;     // condensed form: one conditional refinement step per direction
-    hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, refine ? 0 : 1, (int)PH_SOLVE);
-    if (refine) {
-        ldlt_solve(C.plan, d.K, d.dinv, d.xv, d.vv, d.phase, PH_SOLVE, false);
-        hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, 1, (int)PH_SOLVE);
-    }
+    // condensed form: one conditional refinement step per direction.  Whether any instance wants it is read back
+    // (4 bytes + a stream synchronise, the sweep loop synchronises once per sweep anyway): on most sweeps none
+    // does, and 2 x 33 gated-off launches per skipped pass cost more than the round trip.
+    const bool refine = d.condense != 0;
+    auto refine_pass = [&](int want) {
+        if (!refine) { hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, 1, want); return; }
+        static const bool readback = !getenv("SQPHIP_NO_REFINE_READBACK");
+        if (readback) hipMemsetAsync(d.counters + 4, 0, sizeof(int), s);
+        hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, 0, want);
+        if (readback) {
+            SQPHIP_HIP_OK(hipMemcpyAsync(C.h_counters + 4, d.counters + 4, sizeof(int), hipMemcpyDeviceToHost, s));
+            SQPHIP_HIP_OK(hipStreamSynchronize(s));
+            if (C.h_counters[4] == 0) return;
+        }
+        ldlt_solve(C.plan, d.K, d.dinv, d.xv, d.vv, d.phase, want, false);
+        hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, 1, want);
+    };
+    refine_pass((int)PH_SOLVE);
     if (d.ipm_corrector) {
         // predictor-corrector mode: centring parameter + second-order terms, then the corrector's right-hand side
         // through the same factors (full forward + backward solve)
         hipLaunchKernelGGL(k_mpc, gB, bT, 0, s, d);
         ldlt_solve(C.plan, d.K, d.dinv, d.xv, d.vv, d.phase, PH_SOLVE2, false);
-        hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, refine ? 0 : 1, (int)PH_SOLVE2);
-        if (refine) {
-            ldlt_solve(C.plan, d.K, d.dinv, d.xv, d.vv, d.phase, PH_SOLVE2, false);
-            hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, 1, (int)PH_SOLVE2);
-        }
+        refine_pass((int)PH_SOLVE2);
     }
     if (C.tm.enabled) { hipEventRecord(ev.second, s); C.tm.pending_solve.push_back(ev); }
     hipLaunchKernelGGL(k_ipm_step, gB, bT, 0, s, d);

@@ -697,7 +697,7 @@ static void launch_update(const LdltPlan &P, hipStream_t s, double *K, int kp, i
     const bool timed = tm && tm->enabled && count;
     if (timed) { ev = tm->get(); hipEventRecord(ev.first, s); }
     if (count && P.kc == 16)
-        hipLaunchKernelGGL(k_trailing<16>, dim3(nrun * P.B), dim3(256), 0, s, K, strideK, P.ld, P.Wbuf, strideW, P.Npad,
+        hipLaunchKernelGGL(k_trailing<16>, dim3(nrun * P.B), dim3(256), P.trail_pad, s, K, strideK, P.ld, P.Wbuf, strideW, P.Npad,
                            P.T, kp, nsub, wslot, jlo, jhi, P.supertile, ntl, tpb, nrun, P.B, phase, want);
     else if (count)
         hipLaunchKernelGGL(k_trailing<32>, dim3(nrun * P.B), dim3(256), 0, s, K, strideK, P.ld, P.Wbuf, strideW, P.Npad,

@@ -59,6 +59,7 @@ struct LdltPlan {
     hipEvent_t ev[6] = {};          // start, panel[2], head[2], join
     int trsm_mfma = 1;          // panel solve on the MFMA pipe, one wave per tile (SQPHIP_TRSM_MFMA=0: LDS substitution)
     int supertile = 8;          // tile columns per super-tile of the Schur-update schedule (SQPHIP_SUPERTILE; 1 = column-major)
+    int trail_pad = 0;          // extra dynamic LDS bytes per k_trailing workgroup (SQPHIP_TRAIL_PAD): caps its residency
     int kc = 16;                // k-columns per LDS stage of the Schur-update kernel (SQPHIP_KC = 16 | 32)
     int tpb_max = 1;            // longest run of tiles one Schur-update workgroup takes (SQPHIP_TPB): runs of 8
                                 // speed the bulk kernel up by 10 % but starve the look-ahead panel chain of CU
@@ -77,6 +78,7 @@ struct LdltPlan {
         if (const char *e = getenv("SQPHIP_TRSM_MFMA")) trsm_mfma = atoi(e);
         if (const char *e = getenv("SQPHIP_SUPERTILE")) { supertile = atoi(e); if (supertile < 1) supertile = 1; }
         if (const char *e = getenv("SQPHIP_KC")) kc = atoi(e) == 32 ? 32 : 16;
+        if (const char *e = getenv("SQPHIP_TRAIL_PAD")) { trail_pad = atoi(e); if (trail_pad < 0) trail_pad = 0; }
         if (const char *e = getenv("SQPHIP_TPB")) { tpb_max = atoi(e); if (tpb_max < 1) tpb_max = 1; }
         for (auto &e : ev) hipEventCreateWithFlags(&e, hipEventDisableTiming);
     }
