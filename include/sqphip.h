@@ -68,7 +68,9 @@ void sqphip_default_options(sqphip_options *o);
  * (one instance = one SqpSolver.Model, src/model.jl:37-67).  COO structures as produced by
  * MOI_wrapper.jl:930-945 (Jacobian) and :1010-1025 (Hessian, triangular, duplicates allowed);
  * nnzH = 0 means no Hessian (LP / SLP).  Bounds may be +-Inf; they apply to every instance
- * until overridden with sqphip_set_bounds. */
+ * until overridden with sqphip_set_bounds.  With options.kkt_condense = 1 the rows with gL == gU given HERE are the
+ * ones that stay in the factorised matrix: sqphip_set_bounds may change their values per instance but returns
+ * SQPHIP_EINVAL if it would turn one of the other rows into an equality. */
 int sqphip_create(sqphip_ctx **ctx, int64_t n, int64_t m, int64_t num_linear,
                   int64_t nnzJ, const int64_t *jrow, const int64_t *jcol,
                   int64_t nnzH, const int64_t *hrow, const int64_t *hcol,

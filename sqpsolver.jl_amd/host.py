@@ -165,6 +165,11 @@ class Context:
         self._ck(self.L.sqphip_acopf_attach(self.h, net.nb, net.ng, net.nl, *[_i(a) for a in keep],
                                             _d(coef), int(net.ref_bus)))
 
+    def set_bounds(self, inst, lay):
+        """Per-instance variable / row bounds (anything with xL, xU, gL, gU attributes)."""
+        self._ck(self.L.sqphip_set_bounds(self.h, inst, _d(_f(lay.xL)), _d(_f(lay.xU)), _d(_f(lay.gL)),
+                                          _d(_f(lay.gU))))
+
     def acopf_set_instance(self, inst, net, lay, x0=None):
         co = net.branch_coeffs()
         g, b, bsh = (_f(co[:, k]) for k in range(3))

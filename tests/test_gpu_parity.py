@@ -4,6 +4,7 @@ fixtures, and -- at full IEEE-118 size -- through size-independent properties (K
 factorisation residuals).  Tolerance: 1e-8 relative on iterates (BASELINE.json north_star),
 discrete decisions (status codes, accept/reject, FR entries, iteration counts) exact."""
 import ctypes as C
+import dataclasses
 import json
 import math
 import os
@@ -299,6 +300,30 @@ def test_condensed_kkt_qp_modes_match_oracle():
         for mode in (O.MODE_QP, O.MODE_FR, O.MODE_SOC, O.MODE_LP, O.MODE_L1QP, O.MODE_INFEAS):
             _compare_qp(osolve(mode, x, 10.0, 7.0, df, E, jv, hv), ctx.qp_solve(mode, x, 10.0, 7.0, df, E, jv, hv),
                         **_tols(mode, 1))
+        ctx.close()
+
+
+def test_condensed_kkt_fixes_the_kept_rows_at_creation():
+    """The condensed order is n + #(gL == gU) of the creation bounds and is reported by the counters; per-instance
+    bounds may move the equality values (contingency loads do) but may not create an equality among the
+    eliminated rows -- that row's D would sit at the regularisation (sqphip_set_bounds -> SQPHIP_EINVAL)."""
+    nb, ng, nl, seed = CASES["case14"]
+    net = acopf_synth(nb, ng, nl, seed); lay = acopf_layout(net)
+    mk = int((lay.gL == lay.gU).sum())
+    for cond, order in ((1, lay.n + mk), (0, lay.n + lay.m)):
+        ctx = pkg.Context(lay.n, lay.m, lay.num_linear, lay.jrow, lay.jcol, lay.hrow, lay.hcol, lay.xL, lay.xU,
+                          lay.gL, lay.gU, pkg.default_options(kkt_condense=cond), batch=2)
+        assert ctx.counters()["kkt_order"] == order
+        i = int(np.flatnonzero((lay.gL != lay.gU) & np.isfinite(lay.gU))[0])
+        bad = dataclasses.replace(lay, gL=lay.gL.copy(), gU=lay.gU.copy())
+        bad.gL[i] = bad.gU[i]
+        if cond:
+            with pytest.raises(pkg.SqpHipError, match="kkt_condense"):
+                ctx.set_bounds(1, bad)
+        else:
+            ctx.set_bounds(1, bad)
+        shifted = dataclasses.replace(lay, gL=lay.gL + 0.01 * (lay.gL == lay.gU), gU=lay.gU + 0.01 * (lay.gL == lay.gU))
+        ctx.set_bounds(0, shifted)                            # equality values may move
         ctx.close()
 
 
