@@ -147,8 +147,11 @@ int sqphip_acopf_attach(sqphip_ctx *ctx, int32_t nb, int32_t ng, int32_t nl,
                         const int32_t *f_bus, const int32_t *t_bus, const int32_t *gen_bus,
                         const int32_t *bal_ptr, const int32_t *bal_colP, const int32_t *bal_colQ,
                         const double *bal_coef, int32_t ref_bus);
-int sqphip_acopf_set_instance(sqphip_ctx *ctx, int32_t inst, const double *g, const double *b,
-                              const double *bsh, const double *c2, const double *c1,
+/* ohm[nl][12]: per branch the coefficients (A, Bc, Bs) of the four flow equations p_f, q_f, p_t, q_t,
+ *   F_k = A_k v_self^2 + v_f v_t (Bc_k cos(va_f - va_t) + Bs_k sin(va_f - va_t)),
+ * i.e. the pi model with an ideal transformer (tap ratio, phase shift) at the from end folded into 12 numbers on the
+ * host (sqpsolver.jl_amd/acopf_synth.py, Network.branch_coeffs); an outaged branch is 12 zeros. */
+int sqphip_acopf_set_instance(sqphip_ctx *ctx, int32_t inst, const double *ohm, const double *c2, const double *c1,
                               const double *x0);
 /* Evaluate the five callbacks on the device for instance `inst` at host point x (parity tests).
  * Any output may be NULL. lambda/sigma only matter for hval. */

@@ -98,7 +98,7 @@ def lib():
         for nm in ("ora_problem_toy", "ora_problem_readme1", "ora_problem_hs071"):
             getattr(L, nm).restype = C.c_void_p
         L.ora_problem_acopf.restype = C.c_void_p
-        L.ora_problem_acopf.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, dp, dp, dp, ip, dp, dp,
+        L.ora_problem_acopf.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, dp, ip, dp, dp,
                                         ip, ip, ip, dp, C.c_int64, lp, lp, C.c_int64, lp, lp,
                                         dp, dp, dp, dp]
         L.ora_problem_nlp.restype = C.POINTER(Nlp)
@@ -209,8 +209,7 @@ def problem_hs071():
 
 
 def problem_acopf(net, lay):
-    co = net.branch_coeffs()
-    g, b, bsh = (f64(co[:, k]) for k in range(3))
+    ohm = f64(net.branch_coeffs().ravel())                    # [nl][12], row-major
     keep = [np.ascontiguousarray(a) for a in
             (net.f_bus.astype(np.int32), net.t_bus.astype(np.int32), net.gen_bus.astype(np.int32),
              lay.bal_ptr.astype(np.int32), lay.bal_colP.astype(np.int32),
@@ -220,7 +219,7 @@ def problem_acopf(net, lay):
     c2, c1, coef, xL, xU, gL, gU = args
     jr, jc, hr, hc = (np.ascontiguousarray(a, dtype=np.int64)
                       for a in (lay.jrow, lay.jcol, lay.hrow, lay.hcol))
-    h = lib().ora_problem_acopf(net.nb, net.ng, net.nl, _i(fb), _i(tb), _d(g), _d(b), _d(bsh),
+    h = lib().ora_problem_acopf(net.nb, net.ng, net.nl, _i(fb), _i(tb), _d(ohm),
                                 _i(gb), _d(c2), _d(c1), _i(bp), _i(bcp), _i(bcq), _d(coef),
                                 len(jr), _l(jr), _l(jc), len(hr), _l(hr), _l(hc),
                                 _d(xL), _d(xU), _d(gL), _d(gU))

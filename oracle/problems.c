@@ -17,7 +17,7 @@ struct ora_problem {
     /* acopf */
     int nb, ng, nl, ref_bus;
     int32_t *f_bus, *t_bus, *gen_bus, *bal_ptr, *bal_colP, *bal_colQ;
-    double *g, *b, *bsh, *c2, *c1, *bal_coef;
+    double *ohm, *c2, *c1, *bal_coef;      /* ohm[nl][12]: (A, Bc, Bs) of p_f, q_f, p_t, q_t per branch */
 };
 
 static int64_t *i64dup(const int64_t *s, int64_t k)
@@ -49,7 +49,7 @@ void ora_problem_destroy(ora_problem *P)
 {
     if (!P) return;
     void *ptrs[] = { P->x0, P->jrow, P->jcol, P->hrow, P->hcol, P->xL, P->xU, P->gL, P->gU,
-        P->f_bus, P->t_bus, P->gen_bus, P->bal_ptr, P->bal_colP, P->bal_colQ, P->g, P->b, P->bsh,
+        P->f_bus, P->t_bus, P->gen_bus, P->bal_ptr, P->bal_colP, P->bal_colQ, P->ohm,
         P->c2, P->c1, P->bal_coef };
     for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) free(ptrs[i]);
     free(P);
@@ -143,13 +143,10 @@ ora_problem *ora_problem_hs071(void)
 /* Row k of branch l:  flow_k - F_k,  F_k = A_k v_self^2 + vf vt (Bc_k cos th + Bs_k sin th) */
 static void ohm_coef(const ora_problem *P, int l, int k, double *A, double *Bc, double *Bs, int *self_t)
 {
-    double g = P->g[l], b = P->b[l], bs = P->bsh[l];
-    switch (k) {
-    case 0: *A = g; *Bc = -g; *Bs = -b; *self_t = 0; break;
-    case 1: *A = -(b + bs); *Bc = b; *Bs = -g; *self_t = 0; break;
-    case 2: *A = g; *Bc = -g; *Bs = b; *self_t = 1; break;
-    default: *A = -(b + bs); *Bc = b; *Bs = g; *self_t = 1; break;
-    }
+    /* twelve numbers per branch from the host (pi model, tap ratio and phase shift at the from end folded in:
+     * sqpsolver.jl_amd/acopf_synth.py, Network.branch_coeffs) */
+    const double *oc = P->ohm + 12 * (size_t)l + 3 * k;
+    *A = oc[0]; *Bc = oc[1]; *Bs = oc[2]; *self_t = k >= 2;
 }
 #define IDX(P) \
     const int nb = (P)->nb, ng = (P)->ng, nl = (P)->nl; \
@@ -256,8 +253,8 @@ static void ac_h(void *u, const double *x, double sig, const double *lam, double
 }
 
 ora_problem *ora_problem_acopf(int nb, int ng, int nl, const int32_t *f_bus,
-                               const int32_t *t_bus, const double *g, const double *b,
-                               const double *bsh, const int32_t *gen_bus, const double *c2,
+                               const int32_t *t_bus, const double *ohm,
+                               const int32_t *gen_bus, const double *c2,
                                const double *c1, const int32_t *bal_ptr, const int32_t *bal_colP,
                                const int32_t *bal_colQ, const double *bal_coef,
                                int64_t nnzj, const int64_t *jrow, const int64_t *jcol,
@@ -276,7 +273,7 @@ ora_problem *ora_problem_acopf(int nb, int ng, int nl, const int32_t *f_bus,
     int64_t nbal = bal_ptr[nb];
     P->bal_colP = i32dup(bal_colP, nbal); P->bal_colQ = i32dup(bal_colQ, nbal);
     P->bal_coef = ddup(bal_coef, nbal);
-    P->g = ddup(g, nl); P->b = ddup(b, nl); P->bsh = ddup(bsh, nl);
+    P->ohm = ddup(ohm, 12 * (int64_t)nl);
     P->c2 = ddup(c2, ng); P->c1 = ddup(c1, ng);
     P->nlp.eval_f = ac_f; P->nlp.eval_grad_f = ac_df; P->nlp.eval_g = ac_g;
     P->nlp.eval_jac_g = ac_jac; P->nlp.eval_h = ac_h;

@@ -172,8 +172,8 @@ ora_problem *ora_problem_readme1(void);
 ora_problem *ora_problem_hs071(void);
 /* ACOPF evaluator over the arrays of sqpsolver.jl_amd/acopf_synth.py (Network + NlpLayout) */
 ora_problem *ora_problem_acopf(int nb, int ng, int nl, const int32_t *f_bus,
-                               const int32_t *t_bus, const double *g, const double *b,
-                               const double *bsh, const int32_t *gen_bus, const double *c2,
+                               const int32_t *t_bus, const double *ohm /* [nl][12] */,
+                               const int32_t *gen_bus, const double *c2,
                                const double *c1, const int32_t *bal_ptr, const int32_t *bal_colP,
                                const int32_t *bal_colQ, const double *bal_coef,
                                int64_t nnzj, const int64_t *jrow, const int64_t *jcol,

@@ -87,7 +87,7 @@ def lib():
                                            C.c_double, C.c_double, ip, dp]
             L.sqphip_acopf_attach.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, ip, ip, ip, ip, ip,
                                               ip, dp, C.c_int32]
-            L.sqphip_acopf_set_instance.argtypes = [vp, C.c_int32, dp, dp, dp, dp, dp, dp]
+            L.sqphip_acopf_set_instance.argtypes = [vp, C.c_int32, dp, dp, dp, dp]
             L.sqphip_acopf_eval.argtypes = [vp, C.c_int32, dp, C.c_double, dp, dp, dp, dp, dp, dp]
             L.sqphip_sqp_reset.argtypes = [vp]
             L.sqphip_sqp_run.argtypes = [vp, C.c_int32]

@@ -69,20 +69,35 @@ class Network:
     angmin: np.ndarray
     angmax: np.ndarray
     status: np.ndarray       # 1.0 in service, 0.0 outaged (admittance zeroed, pattern kept)
+    tap: np.ndarray = None   # off-nominal turns ratio at the from end (None = 1)
+    shift: np.ndarray = None # phase shift at the from end, radians (None = 0)
 
     def branch_coeffs(self):
-        """Per-branch Ohm's-law coefficients (tap=1, shift=0), SURVEY.md App. B.
+        """Per-branch Ohm's-law coefficients of the pi model with an ideal transformer (ratio tau, shift phi) at the
+        from end (MATPOWER / PowerModels convention; SURVEY.md App. B is the case tau = 1, phi = 0).
 
-        p_f = gff*vm_f^2 + (-g)*vm_f*vm_t*cos(th) + (-b)*vm_f*vm_t*sin(th)
-        q_f = -bff*vm_f^2 - (-b)*vm_f*vm_t*cos(th) + (-g)*vm_f*vm_t*sin(th)
-        (to-end: same with th -> -th and f<->t)
-        Returned array [nl, 4] = (g, b, gff=g, bff=b+bc/2) scaled by status.
+        Flow k of branch l (k = 0..3: p_f, q_f, p_t, q_t), th = va_f - va_t:
+            F_k = A_k * v_self^2 + v_f v_t (Bc_k cos th + Bs_k sin th),   v_self = v_f (k < 2) or v_t
+        with y = g + jb the series admittance and bc the total charging susceptance:
+            p_f: A = g/tau^2          Bc = -(g cos phi - b sin phi)/tau   Bs = -(g sin phi + b cos phi)/tau
+            q_f: A = -(b+bc/2)/tau^2  Bc =  (g sin phi + b cos phi)/tau   Bs = -(g cos phi - b sin phi)/tau
+            p_t: A = g                Bc = -(g cos phi + b sin phi)/tau   Bs = -(g sin phi - b cos phi)/tau
+            q_t: A = -(b+bc/2)        Bc =  (b cos phi - g sin phi)/tau   Bs =  (g cos phi + b sin phi)/tau
+        Returned array [nl, 12] = (A, Bc, Bs) for k = 0..3, scaled by status (outaged branch: all zero).
         """
         z2 = self.r ** 2 + self.x ** 2
-        g = self.r / z2 * self.status
-        b = -self.x / z2 * self.status
-        bsh = 0.5 * self.bc * self.status
-        return np.stack([g, b, bsh], axis=1)
+        g = self.r / z2
+        b = -self.x / z2
+        bh = 0.5 * self.bc
+        tau = np.ones(self.nl) if self.tap is None else np.asarray(self.tap, dtype=np.float64)
+        phi = np.zeros(self.nl) if self.shift is None else np.asarray(self.shift, dtype=np.float64)
+        c, sn = np.cos(phi), np.sin(phi)
+        co = np.stack([
+            g / tau ** 2, -(g * c - b * sn) / tau, -(g * sn + b * c) / tau,
+            -(b + bh) / tau ** 2, (g * sn + b * c) / tau, -(g * c - b * sn) / tau,
+            g, -(g * c + b * sn) / tau, -(g * sn - b * c) / tau,
+            -(b + bh), (b * c - g * sn) / tau, (g * c + b * sn) / tau], axis=1)
+        return co * self.status[:, None]
 
 
 def _bridges(nb, f, t):

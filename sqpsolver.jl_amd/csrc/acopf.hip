@@ -3,7 +3,7 @@
 // Seat in the reference: the closures eval_f / eval_grad_f / eval_g / eval_jac_g / eval_h built in
 // /root/reference/src/MOI_wrapper.jl:1115-1146 and called at src/algorithms/sqp.jl:86-117,
 // :130-138, :170-183, for a PowerModels ACPPowerModel + build_opf model
-// (/root/reference/test/opf.jl:5-9; equations SURVEY.md Appendix B, tap = 1, shift = 0).
+// (/root/reference/test/opf.jl:5-9; equations SURVEY.md Appendix B, generalised to tap ratios and phase shifts).
 // Variable / row / COO-entry layout is the one documented in sqpsolver.jl_amd/acopf_synth.py.
 // One workgroup per instance; threads stride over branches, buses and generators; every output
 // entry is written by exactly one thread (no atomics).

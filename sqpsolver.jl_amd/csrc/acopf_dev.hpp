@@ -6,15 +6,12 @@
 
 namespace sqphip {
 
+// flow k of a branch (k = 0..3: p_f, q_f, p_t, q_t):  F_k = A v_self^2 + v_f v_t (Bc cos th + Bs sin th); the twelve
+// coefficients per branch come from the host (tap ratio and phase shift folded in, acopf_synth.py branch_coeffs)
 struct Ohm { double A, Bc, Bs; int self_t; };
-static __device__ __forceinline__ Ohm ohm_coef(double g, double b, double bs, int k)
+static __device__ __forceinline__ Ohm ohm_coef(const double *__restrict__ oc, int k)
 {
-    switch (k) {
-    case 0: return {g, -g, -b, 0};
-    case 1: return {-(b + bs), b, -g, 0};
-    case 2: return {g, -g, b, 1};
-    default: return {-(b + bs), b, g, 1};
-    }
+    return {oc[3 * k], oc[3 * k + 1], oc[3 * k + 2], k >= 2};
 }
 
 // any of f_out, grad, gv, jv, hv may be null
@@ -26,8 +23,7 @@ static __device__ void acopf_eval(const DV &d, int inst, const double *__restric
     const int VA = 0, VM = nb, PG = 2 * nb, QG = 2 * nb + ng, PF = 2 * nb + 2 * ng;
     const int PT = PF + nl, QF = PF + 2 * nl, QT = PF + 3 * nl;
     const int T0 = 2 * nl + 1 + 2 * nb, O0 = T0 + 2 * nl;
-    const double *bg = d.br_g + (long)inst * nl, *bb = d.br_b + (long)inst * nl,
-                 *bs = d.br_bsh + (long)inst * nl;
+    const double *ohm = d.br_ohm + (long)inst * nl * 12;
     const double *c2 = d.c2 + (long)inst * ng, *c1 = d.c1 + (long)inst * ng;
     (void)QG;
     // objective and gradient
@@ -96,7 +92,7 @@ static __device__ void acopf_eval(const DV &d, int inst, const double *__restric
         const double own[4] = {pf, qf, pt, qt};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const Ohm o = ohm_coef(bg[l], bb[l], bs[l], k);
+            const Ohm o = ohm_coef(ohm + 12 * l, k);
             const double T0v = o.Bc * cs + o.Bs * sn, T1 = -o.Bc * sn + o.Bs * cs;
             if (gv) {
                 const double vs = o.self_t ? vt : vf;

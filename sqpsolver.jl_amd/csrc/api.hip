@@ -441,8 +441,7 @@ extern "C" int sqphip_acopf_attach(sqphip_ctx *h, int32_t nb, int32_t ng, int32_
         d.bal_colP = C.upload(std::vector<int>(bal_colP, bal_colP + nbal));
         d.bal_colQ = C.upload(std::vector<int>(bal_colQ, bal_colQ + nbal));
         d.bal_coef = C.upload(std::vector<double>(bal_coef, bal_coef + nbal));
-        d.br_g = C.dalloc<double>((size_t)d.B * nl); d.br_b = C.dalloc<double>((size_t)d.B * nl);
-        d.br_bsh = C.dalloc<double>((size_t)d.B * nl);
+        d.br_ohm = C.dalloc<double>((size_t)d.B * nl * 12);
         d.c2 = C.dalloc<double>((size_t)d.B * ng); d.c1 = C.dalloc<double>((size_t)d.B * ng);
         SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
         C.acopf_attached = true;
@@ -450,14 +449,13 @@ extern "C" int sqphip_acopf_attach(sqphip_ctx *h, int32_t nb, int32_t ng, int32_
     });
 }
 
-extern "C" int sqphip_acopf_set_instance(sqphip_ctx *h, int32_t inst, const double *g, const double *b,
-                                         const double *bsh, const double *c2, const double *c1, const double *x0)
+extern "C" int sqphip_acopf_set_instance(sqphip_ctx *h, int32_t inst, const double *ohm, const double *c2,
+                                         const double *c1, const double *x0)
 {
     if (!h || !h->c.acopf_attached || inst < 0 || inst >= h->c.d.B) return SQPHIP_EINVAL;
     return guarded(h, [&](Ctx &C) {
         DV &d = C.d;
-        h2d(C, d.br_g + (size_t)inst * d.nl, g, d.nl); h2d(C, d.br_b + (size_t)inst * d.nl, b, d.nl);
-        h2d(C, d.br_bsh + (size_t)inst * d.nl, bsh, d.nl);
+        h2d(C, d.br_ohm + (size_t)inst * d.nl * 12, ohm, (size_t)d.nl * 12);
         h2d(C, d.c2 + (size_t)inst * d.ng, c2, d.ng); h2d(C, d.c1 + (size_t)inst * d.ng, c1, d.ng);
         h2d(C, d.x0 + (size_t)inst * d.n, x0, d.n);
         SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));

@@ -85,7 +85,7 @@ struct DV {
     int nb, ng, nl, ref_bus;
     const int *f_bus, *t_bus, *gen_bus, *bal_ptr, *bal_colP, *bal_colQ;
     const double *bal_coef;
-    double *br_g, *br_b, *br_bsh, *c2, *c1, *x0;   // per instance
+    double *br_ohm, *c2, *c1, *x0;   // per instance; br_ohm[inst][nl][12] = (A, Bc, Bs) of p_f, q_f, p_t, q_t
     // options
     double tol_direction, tol_residual, tol_infeas, init_mu, tr_size;
     int max_iter, use_soc, literal_quirks;

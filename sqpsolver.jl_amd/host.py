@@ -171,11 +171,10 @@ class Context:
                                           _d(_f(lay.gU))))
 
     def acopf_set_instance(self, inst, net, lay, x0=None):
-        co = net.branch_coeffs()
-        g, b, bsh = (_f(co[:, k]) for k in range(3))
+        ohm = _f(net.branch_coeffs().ravel())                 # [nl][12], row-major
         self._ck(self.L.sqphip_set_bounds(self.h, inst, _d(_f(lay.xL)), _d(_f(lay.xU)), _d(_f(lay.gL)),
                                           _d(_f(lay.gU))))
-        self._ck(self.L.sqphip_acopf_set_instance(self.h, inst, _d(g), _d(b), _d(bsh), _d(_f(net.c2)),
+        self._ck(self.L.sqphip_acopf_set_instance(self.h, inst, _d(ohm), _d(_f(net.c2)),
                                                   _d(_f(net.c1)), _d(_f(lay.x0 if x0 is None else x0))))
 
     def acopf_eval(self, inst, x, sigma=1.0, lam=None):

@@ -7,9 +7,9 @@ example file is /root/reference/examples/acopf/case3.m:7-36 with `mpc.baseMVA`,
 that format (MATPOWER case format version 2) and converts it into the `Network` the
 device evaluator and the oracle consume (`acopf_synth.Network`), in per-unit.
 
-Supported subset = what the evaluator models (polar ACOPF): transformer
-taps 0/1, zero phase shift, no bus shunts, polynomial (model 2) generator costs of degree
-<= 2.  Anything else raises `UnsupportedCase` naming the offending rows, never a silent
+Supported subset = what the evaluator models (polar ACOPF, SURVEY.md App. B, with off-nominal
+transformer taps and phase shifters at the from end as MATPOWER defines them): no bus shunts,
+polynomial (model 2) generator costs of degree <= 2.  Anything else raises `UnsupportedCase` naming the offending rows, never a silent
 approximation.  HVDC lines (`mpc.dcline`, modelled by the reference's custom build at
 examples/acopf/opf.jl:40-42) are rejected unless `dcline="drop"` is passed.
 
@@ -160,11 +160,9 @@ def network_from_matpower(mpc: Dict, dcline: str = "error", unlimited_rate: floa
                 c1[k] = co[0]
     else:
         c2 = np.zeros(len(g)); c1 = np.zeros(len(g))
-    ratio, shift = br[:, 8], br[:, 9]
-    if np.any((ratio != 0.0) & (ratio != 1.0)):
-        problems.append(f"off-nominal transformer taps on branches {np.flatnonzero((ratio != 0) & (ratio != 1)).tolist()}")
-    if np.any(shift != 0.0):
-        problems.append(f"phase shifters on branches {np.flatnonzero(shift != 0).tolist()}")
+    ratio, shift = br[:, 8], br[:, 9]                # ratio 0 means "no transformer" = 1; shift in degrees
+    if np.any(ratio < 0.0):
+        problems.append(f"negative tap ratios on branches {np.flatnonzero(ratio < 0).tolist()}")
     if "dcline" in mpc and mpc["dcline"].size and dcline != "drop":
         problems.append(f"{mpc['dcline'].shape[0]} HVDC line(s) (pass dcline='drop' to ignore them)")
     for col, nm in ((0, "gen"),):
@@ -198,6 +196,7 @@ def network_from_matpower(mpc: Dict, dcline: str = "error", unlimited_rate: floa
         t_bus=np.asarray([idx[int(b)] for b in br[:, 1]], dtype=np.int32),
         r=br[:, 2].copy(), x=br[:, 3].copy(), bc=br[:, 4].copy(), rate_a=rate,
         angmin=amin, angmax=amax, status=(br[:, 10] > 0).astype(np.float64),
+        tap=np.where(ratio == 0.0, 1.0, ratio), shift=np.deg2rad(shift),
     )
 
 
@@ -226,7 +225,9 @@ def write_matpower(net: Network, name: str = "case_synth", base_mva: float = 100
     L += ["];", "mpc.branch = ["]
     for l in range(net.nl):
         L.append("\t" + "\t".join([str(int(net.f_bus[l]) + 1), str(int(net.t_bus[l]) + 1), f(net.r[l]), f(net.x[l]), f(net.bc[l]),
-                                   f(net.rate_a[l] * base_mva), "0.0", "0.0", "0.0", "0.0", str(int(net.status[l] > 0)),
+                                   f(net.rate_a[l] * base_mva), "0.0", "0.0",
+                                   f(0.0 if net.tap is None or net.tap[l] == 1.0 else net.tap[l]),
+                                   f(0.0 if net.shift is None else np.rad2deg(net.shift[l])), str(int(net.status[l] > 0)),
                                    f(np.rad2deg(net.angmin[l])), f(np.rad2deg(net.angmax[l]))]) + ";")
     L += ["];", ""]
     return "\n".join(L)

@@ -93,10 +93,21 @@ def test_ldlt_full_size_residuals():
 
 
 # ------------------------------------------------------------------ K1: device ACOPF evaluator
-@pytest.mark.parametrize("case", ["case14", "case118"])
+def _with_transformers(net, seed):
+    """A third of the branches become transformers with off-nominal taps, a few of them phase shifters."""
+    rng = np.random.default_rng(seed)
+    tr = rng.random(net.nl) < 0.33
+    return dataclasses.replace(net, tap=np.where(tr, rng.uniform(0.93, 1.07, net.nl), 1.0),
+                               shift=np.where(tr & (rng.random(net.nl) < 0.3), rng.uniform(-0.08, 0.08, net.nl), 0.0))
+
+
+@pytest.mark.parametrize("case", ["case14", "case118", "case14-taps", "case118-taps"])
 def test_acopf_evaluator_matches_oracle(case):
-    nb, ng, nl, seed = CASES[case]
-    net = contingency(acopf_synth(nb, ng, nl, seed), 5, seed); lay = acopf_layout(net)
+    nb, ng, nl, seed = CASES[case.split("-")[0]]
+    net = contingency(acopf_synth(nb, ng, nl, seed), 5, seed)
+    if case.endswith("taps"):
+        net = _with_transformers(net, seed)
+    lay = acopf_layout(net)
     P = O.problem_acopf(net, lay)
     ctx = pkg.Context(lay.n, lay.m, lay.num_linear, lay.jrow, lay.jcol, lay.hrow, lay.hcol, lay.xL, lay.xU,
                       lay.gL, lay.gU, batch=2)
@@ -301,6 +312,32 @@ def test_condensed_kkt_qp_modes_match_oracle():
             _compare_qp(osolve(mode, x, 10.0, 7.0, df, E, jv, hv), ctx.qp_solve(mode, x, 10.0, 7.0, df, E, jv, hv),
                         **_tols(mode, 1))
         ctx.close()
+
+
+def test_batched_sqp_on_networks_with_taps_and_phase_shifters():
+    """Off-nominal taps and phase shifts change only the twelve Ohm's-law coefficients per branch (same
+    sparsity): a batch mixing a plain network with two transformer variants, to convergence, against the oracle."""
+    nb, ng, nl, seed = CASES["case14"]
+    base = acopf_synth(nb, ng, nl, seed)
+    nets = [base, _with_transformers(base, 1), _with_transformers(contingency(base, 3, seed), 2)]
+    lays = [acopf_layout(nt) for nt in nets]
+    kw = dict(max_iter=40, tol_infeas=1e-6, tol_residual=1e-4, literal_quirks=0, use_soc=1)
+    ctx = pkg.Context(lays[0].n, lays[0].m, lays[0].num_linear, lays[0].jrow, lays[0].jcol, lays[0].hrow, lays[0].hcol,
+                      lays[0].xL, lays[0].xU, lays[0].gL, lays[0].gU, pkg.default_options(**kw), batch=len(nets))
+    ctx.acopf_attach(base, lays[0])
+    for b in range(len(nets)):
+        ctx.acopf_set_instance(b, nets[b], lays[b])
+    ctx.sqp_reset(); ctx.sqp_run(0)
+    objs = []
+    for b in range(len(nets)):
+        ro = O.sqp_solve(O.problem_acopf(nets[b], lays[b]), O.default_options(**kw))
+        rg = ctx.sqp_get(b)
+        assert (rg["status"], rg["iter"]) == (ro["status"], ro["iter"])
+        tol = TOL if ro["status"] == 0 else TOL_TRAJ
+        assert rel(rg["x"], ro["x"]) < 100 * tol and abs(rg["obj_val"] - ro["obj_val"]) <= tol * abs(ro["obj_val"])
+        objs.append(rg["obj_val"])
+    assert abs(objs[1] - objs[0]) > 1e-6 * abs(objs[0])       # the transformers do change the optimum
+    ctx.close()
 
 
 def test_condensed_kkt_fixes_the_kept_rows_at_creation():

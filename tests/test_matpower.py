@@ -74,8 +74,7 @@ def test_conversion_per_unit_renumbering_status():
 
 
 @pytest.mark.parametrize("edit,needle", [
-    (("0.01 0.10 0.02  100 0 0 0 0 1 -30 30", "0.01 0.10 0.02  100 0 0 0.98 0 1 -30 30"), "taps"),
-    (("0.01 0.10 0.02  100 0 0 0 0 1 -30 30", "0.01 0.10 0.02  100 0 0 0 5.0 1 -30 30"), "phase shifters"),
+    (("0.01 0.10 0.02  100 0 0 0 0 1 -30 30", "0.01 0.10 0.02  100 0 0 -0.98 0 1 -30 30"), "negative tap"),
     (("20  1  40.0  10.0  0 0", "20  1  40.0  10.0  0 4.5"), "shunts"),
     (("2 0 0 3  0.02 12.0 100.0", "1 0 0 3  0.02 12.0 100.0"), "piecewise"),
     (("mpc.bus_name", "mpc.dcline = [10 20 1 10 10 5 0 1 1 10 90 -90 90 -90 90 0 0 0 0 0 0 0 0];\nmpc.bus_name"), "HVDC"),
@@ -87,6 +86,64 @@ def test_unsupported_features_are_rejected_loudly(edit, needle):
         MP.network_from_matpower(MP.read_matpower(txt))
     if needle == "HVDC":
         assert MP.network_from_matpower(MP.read_matpower(txt), dcline="drop").nl == 4
+
+
+def test_taps_and_phase_shifters_are_read_and_reach_the_flow_equations():
+    """ratio / angle columns of mpc.branch -> Network.tap / shift (radians) -> the twelve Ohm's-law coefficients per
+    branch, checked against the complex-power flows of MATPOWER's branch admittance matrix
+        [I_f; I_t] = [[(y + j bc/2)/tau^2, -y/(tau e^{-j phi})], [-y/(tau e^{j phi}), y + j bc/2]] [V_f; V_t]."""
+    txt = HAND.replace("0.01 0.10 0.02  100 0 0 0 0 1 -30 30", "0.01 0.10 0.02  100 0 0 0.97 4.0 1 -30 30")
+    assert txt != HAND
+    net = MP.network_from_matpower(MP.read_matpower(txt))
+    l = int(np.flatnonzero(net.tap != 1.0)[0])
+    assert net.tap[l] == 0.97 and np.isclose(net.shift[l], np.deg2rad(4.0))
+    assert (np.delete(net.tap, l) == 1.0).all() and (np.delete(net.shift, l) == 0.0).all()
+    rng = np.random.default_rng(0)
+    net.tap = rng.uniform(0.9, 1.1, net.nl); net.shift = rng.uniform(-0.2, 0.2, net.nl)
+    co = net.branch_coeffs()
+    va = rng.uniform(-0.3, 0.3, net.nb); vm = rng.uniform(0.9, 1.1, net.nb)
+    V = vm * np.exp(1j * va)
+    y = 1.0 / (net.r + 1j * net.x)
+    for b in range(net.nl):
+        f, t = net.f_bus[b], net.t_bus[b]
+        tau, phi = net.tap[b], net.shift[b]
+        i_f = (y[b] + 0.5j * net.bc[b]) / tau ** 2 * V[f] - y[b] / (tau * np.exp(-1j * phi)) * V[t]
+        i_t = -y[b] / (tau * np.exp(1j * phi)) * V[f] + (y[b] + 0.5j * net.bc[b]) * V[t]
+        s_f, s_t = V[f] * np.conj(i_f) * net.status[b], V[t] * np.conj(i_t) * net.status[b]
+        th, uu = va[f] - va[t], vm[f] * vm[t]
+        F = [co[b, 3 * k] * (vm[t] if k >= 2 else vm[f]) ** 2 + uu * (co[b, 3 * k + 1] * np.cos(th) + co[b, 3 * k + 2] * np.sin(th))
+             for k in range(4)]
+        assert np.allclose(F, [s_f.real, s_f.imag, s_t.real, s_t.imag], rtol=1e-13, atol=1e-14)
+    back = MP.load_case(MP.write_matpower(net, "tapped"))
+    assert np.allclose(back.tap, net.tap, rtol=1e-15) and np.allclose(back.shift, net.shift, rtol=1e-13, atol=1e-16)
+
+
+def test_tapped_network_evaluator_derivatives_match_finite_differences():
+    """The oracle's ACOPF callbacks on a network with random taps and shifts: Jacobian and Hessian of the
+    Lagrangian against central differences of eval_g / eval_jac_g."""
+    from oracle import oracle as O
+    import scipy.sparse as sp
+    net = acopf_synth(14, 5, 20, 14)
+    rng = np.random.default_rng(3)
+    net.tap = rng.uniform(0.92, 1.08, net.nl); net.shift = rng.uniform(-0.1, 0.1, net.nl)
+    lay = acopf_layout(net)
+    P = O.problem_acopf(net, lay)
+    x = np.clip(lay.x0 + 0.05 * rng.standard_normal(lay.n), lay.xL, lay.xU)
+    lam = rng.standard_normal(lay.m)
+    J = sp.coo_matrix((P.eval_jac_g(x), (lay.jrow - 1, lay.jcol - 1)), shape=(lay.m, lay.n)).toarray()
+    Hl = sp.coo_matrix((P.eval_h(x, 0.7, lam), (lay.hrow - 1, lay.hcol - 1)), shape=(lay.n, lay.n)).toarray()
+    H = Hl + Hl.T - np.diag(np.diag(Hl))
+    h = 1e-6
+    Jfd = np.zeros_like(J); Hfd = np.zeros_like(H)
+    for j in range(lay.n):
+        e = np.zeros(lay.n); e[j] = h
+        Jfd[:, j] = (P.eval_g(x + e) - P.eval_g(x - e)) / (2 * h)
+        def lag_grad(z):
+            Jz = sp.coo_matrix((P.eval_jac_g(z), (lay.jrow - 1, lay.jcol - 1)), shape=(lay.m, lay.n)).toarray()
+            return 0.7 * P.eval_grad_f(z) + Jz.T @ lam
+        Hfd[:, j] = (lag_grad(x + e) - lag_grad(x - e)) / (2 * h)
+    assert np.abs(J - Jfd).max() < 1e-7 * max(1.0, np.abs(J).max())
+    assert np.abs(H - Hfd).max() < 1e-6 * max(1.0, np.abs(H).max())
 
 
 def test_write_read_round_trip_of_a_synthetic_case():
