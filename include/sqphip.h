@@ -147,6 +147,12 @@ int sqphip_acopf_attach(sqphip_ctx *ctx, int32_t nb, int32_t ng, int32_t nl,
                         const int32_t *f_bus, const int32_t *t_bus, const int32_t *gen_bus,
                         const int32_t *bal_ptr, const int32_t *bal_colP, const int32_t *bal_colQ,
                         const double *bal_coef, int32_t ref_bus);
+/* Bus shunts (optional, after sqphip_acopf_attach): bus sh_bus[s] consumes gs[s] vm^2 of active and injects
+ * bs[s] vm^2 of reactive power.  The context must have been created with the matching structure: two more Jacobian
+ * COO entries (P row, Q row; column vm) and one more Hessian COO entry (vm, vm) per shunted bus at the END of the
+ * lists, and num_linear = 2 nl + 1 (the balance rows are no longer linear) -- sqpsolver.jl_amd/acopf_synth.py,
+ * acopf_layout.  Shared by every instance of the batch. */
+int sqphip_acopf_set_shunts(sqphip_ctx *ctx, int32_t nsh, const int32_t *sh_bus, const double *gs, const double *bs);
 /* ohm[nl][12]: per branch the coefficients (A, Bc, Bs) of the four flow equations p_f, q_f, p_t, q_t,
  *   F_k = A_k v_self^2 + v_f v_t (Bc_k cos(va_f - va_t) + Bs_k sin(va_f - va_t)),
  * i.e. the pi model with an ideal transformer (tap ratio, phase shift) at the from end folded into 12 numbers on the

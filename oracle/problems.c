@@ -17,6 +17,7 @@ struct ora_problem {
     /* acopf */
     int nb, ng, nl, ref_bus;
     int32_t *f_bus, *t_bus, *gen_bus, *bal_ptr, *bal_colP, *bal_colQ;
+    int nsh; int32_t *sh_bus; double *sh_gs, *sh_bs;   /* bus shunts: + gs vm^2 (P row), - bs vm^2 (Q row) */
     double *ohm, *c2, *c1, *bal_coef;      /* ohm[nl][12]: (A, Bc, Bs) of p_f, q_f, p_t, q_t per branch */
 };
 
@@ -50,7 +51,7 @@ void ora_problem_destroy(ora_problem *P)
     if (!P) return;
     void *ptrs[] = { P->x0, P->jrow, P->jcol, P->hrow, P->hcol, P->xL, P->xU, P->gL, P->gU,
         P->f_bus, P->t_bus, P->gen_bus, P->bal_ptr, P->bal_colP, P->bal_colQ, P->ohm,
-        P->c2, P->c1, P->bal_coef };
+        P->c2, P->c1, P->bal_coef, P->sh_bus, P->sh_gs, P->sh_bs };
     for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) free(ptrs[i]);
     free(P);
 }
@@ -185,6 +186,10 @@ static void ac_g(void *u, const double *x, double *gv)
         }
         gv[2 * nl + 1 + 2 * i] = sp; gv[2 * nl + 2 + 2 * i] = sq;
     }
+    for (int s = 0; s < P->nsh; ++s) {
+        int i = P->sh_bus[s]; double vm = x[VM + i];
+        gv[2 * nl + 1 + 2 * i] += P->sh_gs[s] * vm * vm; gv[2 * nl + 2 + 2 * i] -= P->sh_bs[s] * vm * vm;
+    }
     for (int l = 0; l < nl; ++l) {
         gv[T0 + 2 * l] = x[PF + l] * x[PF + l] + x[QF + l] * x[QF + l];
         gv[T0 + 2 * l + 1] = x[PT + l] * x[PT + l] + x[QT + l] * x[QT + l];
@@ -222,6 +227,10 @@ static void ac_jac(void *u, const double *x, double *v)
             v[o++] = -((st ? 0.0 : 2 * A * vf) + vt * T0v);
             v[o++] = -((st ? 2 * A * vt : 0.0) + vf * T0v);
         }
+    for (int s = 0; s < P->nsh; ++s) {
+        double vm = x[VM + P->sh_bus[s]];
+        v[o++] = 2 * P->sh_gs[s] * vm; v[o++] = -2 * P->sh_bs[s] * vm;
+    }
 }
 static void ac_h(void *u, const double *x, double sig, const double *lam, double *v)
 {
@@ -250,6 +259,11 @@ static void ac_h(void *u, const double *x, double sig, const double *lam, double
             blk[9 * nl + l] = w * (st ? 2 * A : 0.0); /* vm_t vm_t */
         }
     }
+    o += (int64_t)40 * nl;
+    for (int s = 0; s < P->nsh; ++s) {
+        int i = P->sh_bus[s];
+        v[o++] = lam[2 * nl + 1 + 2 * i] * 2 * P->sh_gs[s] - lam[2 * nl + 2 + 2 * i] * 2 * P->sh_bs[s];
+    }
 }
 
 ora_problem *ora_problem_acopf(int nb, int ng, int nl, const int32_t *f_bus,
@@ -260,11 +274,13 @@ ora_problem *ora_problem_acopf(int nb, int ng, int nl, const int32_t *f_bus,
                                int64_t nnzj, const int64_t *jrow, const int64_t *jcol,
                                int64_t nnzh, const int64_t *hrow, const int64_t *hcol,
                                const double *xL, const double *xU, const double *gL,
-                               const double *gU)
+                               const double *gU, int nsh, const int32_t *sh_bus, const double *sh_gs,
+                               const double *sh_bs)
 {
     int64_t n = 2 * nb + 2 * ng + 4 * nl, m = 1 + 2 * nb + 8 * nl;
     double *x0 = (double *)calloc((size_t)n, sizeof(double));
-    ora_problem *P = mk(n, m, 2 * nl + 1 + 2 * nb, nnzj, jrow, jcol, nnzh, hrow, hcol, xL, xU, gL, gU, x0);
+    /* with bus shunts the balance rows carry a vm^2 term: only the angle and reference rows stay linear */
+    ora_problem *P = mk(n, m, nsh > 0 ? 2 * nl + 1 : 2 * nl + 1 + 2 * nb, nnzj, jrow, jcol, nnzh, hrow, hcol, xL, xU, gL, gU, x0);
     free(x0);
     P->nb = nb; P->ng = ng; P->nl = nl;
     P->ref_bus = (int)(jcol[4 * nl] - 1);
@@ -274,6 +290,7 @@ ora_problem *ora_problem_acopf(int nb, int ng, int nl, const int32_t *f_bus,
     P->bal_colP = i32dup(bal_colP, nbal); P->bal_colQ = i32dup(bal_colQ, nbal);
     P->bal_coef = ddup(bal_coef, nbal);
     P->ohm = ddup(ohm, 12 * (int64_t)nl);
+    P->nsh = nsh; P->sh_bus = i32dup(sh_bus, nsh); P->sh_gs = ddup(sh_gs, nsh); P->sh_bs = ddup(sh_bs, nsh);
     P->c2 = ddup(c2, ng); P->c1 = ddup(c1, ng);
     P->nlp.eval_f = ac_f; P->nlp.eval_grad_f = ac_df; P->nlp.eval_g = ac_g;
     P->nlp.eval_jac_g = ac_jac; P->nlp.eval_h = ac_h;

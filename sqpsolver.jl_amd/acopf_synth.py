@@ -71,6 +71,16 @@ class Network:
     status: np.ndarray       # 1.0 in service, 0.0 outaged (admittance zeroed, pattern kept)
     tap: np.ndarray = None   # off-nominal turns ratio at the from end (None = 1)
     shift: np.ndarray = None # phase shift at the from end, radians (None = 0)
+    gs: np.ndarray = None    # bus shunt conductance, p.u. (MW consumed at vm = 1 / baseMVA); None = 0
+    bs: np.ndarray = None    # bus shunt susceptance, p.u. (MVAr injected at vm = 1 / baseMVA); None = 0
+
+    def shunts(self):
+        """(bus indices, gs, bs) of the buses with a shunt element; they add gs*vm^2 to the P balance and
+        -bs*vm^2 to the Q balance of the bus (MATPOWER manual eq. 3.7; PowerModels constraint_power_balance)."""
+        gs = np.zeros(self.nb) if self.gs is None else np.asarray(self.gs, dtype=np.float64)
+        bs = np.zeros(self.nb) if self.bs is None else np.asarray(self.bs, dtype=np.float64)
+        idx = np.flatnonzero((gs != 0.0) | (bs != 0.0)).astype(np.int32)
+        return idx, gs[idx], bs[idx]
 
     def branch_coeffs(self):
         """Per-branch Ohm's-law coefficients of the pi model with an ideal transformer (ratio tau, shift phi) at the
@@ -248,6 +258,12 @@ class NlpLayout:
     bal_colP: np.ndarray  # int32 column of the P-row entry
     bal_colQ: np.ndarray  # int32 column of the Q-row entry
     bal_coef: np.ndarray  # +1 arc, -1 generator
+    # bus shunts (empty for a network without them): the balance rows of a network WITH shunts carry a vm^2 term,
+    # so they are nonlinear rows (num_linear = 2 nl + 1), with two extra Jacobian entries (P row, Q row; column vm_i)
+    # and one extra Hessian entry (vm_i, vm_i) per shunted bus appended to the COO lists
+    sh_bus: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(0, dtype=np.int32))
+    sh_gs: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(0))
+    sh_bs: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(0))
 
 
 def acopf_layout(net: Network) -> NlpLayout:
@@ -303,6 +319,11 @@ def acopf_layout(net: Network) -> NlpLayout:
     for k in range(4):
         jr.append(np.repeat(O0 + 4 * L + k, 5))
         jc.append(np.stack([own[k] + L, VA + f, VA + t, VM + f, VM + t], 1).ravel())
+    sh_bus, sh_gs, sh_bs = net.shunts()
+    if len(sh_bus):
+        sb = sh_bus.astype(np.int64)
+        jr.append(np.stack([2 * nl + 1 + 2 * sb, 2 * nl + 2 + 2 * sb], 1).ravel())
+        jc.append(np.repeat(VM + sb, 2))
     jrow = np.concatenate(jr).astype(np.int64) + 1
     jcol = np.concatenate(jc).astype(np.int64) + 1
 
@@ -321,6 +342,8 @@ def acopf_layout(net: Network) -> NlpLayout:
             ia, ib = v4[:, a], v4[:, b]
             hr.append(np.maximum(ia, ib))
             hc.append(np.minimum(ia, ib))
+    if len(sh_bus):
+        hr.append(VM + sh_bus.astype(np.int64)); hc.append(VM + sh_bus.astype(np.int64))
     hrow = np.concatenate(hr).astype(np.int64) + 1
     hcol = np.concatenate(hc).astype(np.int64) + 1
 
@@ -344,7 +367,9 @@ def acopf_layout(net: Network) -> NlpLayout:
     x0 = np.zeros(n)
     x0[boxed] = 0.5 * (xL[boxed] + xU[boxed])
     x0[VM:VM + nb] = 1.0
-    return NlpLayout(n=n, m=m, num_linear=T0, jrow=jrow, jcol=jcol, hrow=hrow, hcol=hcol,
+    return NlpLayout(n=n, m=m, num_linear=T0 if len(sh_bus) == 0 else 2 * nl + 1,
+                     jrow=jrow, jcol=jcol, hrow=hrow, hcol=hcol,
                      xL=xL, xU=xU, gL=gL, gU=gU, x0=x0,
                      bal_ptr=bal_ptr, bal_colP=colP.astype(np.int32),
-                     bal_colQ=colQ.astype(np.int32), bal_coef=np.asarray(coef))
+                     bal_colQ=colQ.astype(np.int32), bal_coef=np.asarray(coef),
+                     sh_bus=sh_bus, sh_gs=sh_gs, sh_bs=sh_bs)

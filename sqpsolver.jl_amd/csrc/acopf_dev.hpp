@@ -50,6 +50,11 @@ static __device__ void acopf_eval(const DV &d, int inst, const double *__restric
                 sp += d.bal_coef[k] * x[d.bal_colP[k]];
                 sq += d.bal_coef[k] * x[d.bal_colQ[k]];
             }
+            if (d.nsh > 0 && d.sh_of_bus[i] >= 0) {          // bus shunt: + gs vm^2 (P), - bs vm^2 (Q)
+                const int s = d.sh_of_bus[i];
+                const double vm = x[VM + i];
+                sp += d.sh_gs[s] * vm * vm; sq -= d.sh_bs[s] * vm * vm;
+            }
             gv[2 * nl + 1 + 2 * i] = sp; gv[2 * nl + 2 + 2 * i] = sq;
         }
     }
@@ -65,6 +70,13 @@ static __device__ void acopf_eval(const DV &d, int inst, const double *__restric
     // branch rows
     const int TH = 4 * nl + 1 + 2 * d.bal_ptr[nb], OH = TH + 4 * nl;
     const int HO = ng + 4 * nl;
+    // shunt entries at the end of both COO lists
+    for (int s = threadIdx.x; s < d.nsh; s += TPB) {
+        const int i = d.sh_bus[s];
+        const double vm = x[VM + i];
+        if (jv) { jv[OH + 20 * nl + 2 * s] = 2 * d.sh_gs[s] * vm; jv[OH + 20 * nl + 2 * s + 1] = -2 * d.sh_bs[s] * vm; }
+        if (hv) hv[HO + 40 * nl + s] = lam[2 * nl + 1 + 2 * i] * 2 * d.sh_gs[s] - lam[2 * nl + 2 + 2 * i] * 2 * d.sh_bs[s];
+    }
     for (int l = threadIdx.x; l < nl; l += TPB) {
         const int fb = d.f_bus[l], tb = d.t_bus[l];
         const double th = x[VA + fb] - x[VA + tb];

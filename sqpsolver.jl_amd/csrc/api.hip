@@ -424,8 +424,10 @@ extern "C" int sqphip_acopf_attach(sqphip_ctx *h, int32_t nb, int32_t ng, int32_
     Ctx &C0 = h->c;
     if (C0.d.n != 2 * nb + 2 * ng + 4 * nl || C0.d.m != 1 + 2 * nb + 8 * nl) return SQPHIP_EINVAL;
     const int nbal = bal_ptr[nb];
-    if (C0.d.nnzj_coo != 32 * nl + 2 * ng + 1 || nbal != 2 * nl + ng || C0.d.nnzh_coo != ng + 44 * nl)
-        return SQPHIP_EINVAL;
+    // (a structure with bus shunts has 2 more Jacobian and 1 more Hessian entry per shunted bus at the end of the
+    // lists; sqphip_acopf_set_shunts checks the exact counts)
+    const int extraJ = C0.d.nnzj_coo - (32 * nl + 2 * ng + 1), extraH = C0.d.nnzh_coo - (ng + 44 * nl);
+    if (extraJ < 0 || extraJ != 2 * extraH || extraH > nb || nbal != 2 * nl + ng) return SQPHIP_EINVAL;
     for (int l = 0; l < nl; ++l)
         if (f_bus[l] < 0 || f_bus[l] >= nb || t_bus[l] < 0 || t_bus[l] >= nb) return SQPHIP_EINVAL;
     for (int k = 0; k < nbal; ++k)
@@ -445,6 +447,31 @@ extern "C" int sqphip_acopf_attach(sqphip_ctx *h, int32_t nb, int32_t ng, int32_
         d.c2 = C.dalloc<double>((size_t)d.B * ng); d.c1 = C.dalloc<double>((size_t)d.B * ng);
         SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
         C.acopf_attached = true;
+        return SQPHIP_OK;
+    });
+}
+
+extern "C" int sqphip_acopf_set_shunts(sqphip_ctx *h, int32_t nsh, const int32_t *sh_bus, const double *gs,
+                                       const double *bs)
+{
+    if (!h || !h->c.acopf_attached || nsh < 0) return SQPHIP_EINVAL;
+    Ctx &C0 = h->c;
+    const int nl = C0.d.nl, ng = C0.d.ng, nb = C0.d.nb;
+    if (C0.d.nnzj_coo != 32 * nl + 2 * ng + 1 + 2 * nsh || C0.d.nnzh_coo != ng + 44 * nl + nsh) return SQPHIP_EINVAL;
+    if (nsh > 0 && C0.d.nlin != 2 * nl + 1) return SQPHIP_EINVAL;     // balance rows must not be declared linear
+    std::vector<int> of(nb, -1);
+    for (int s = 0; s < nsh; ++s) {
+        if (sh_bus[s] < 0 || sh_bus[s] >= nb || of[sh_bus[s]] >= 0) return SQPHIP_EINVAL;
+        of[sh_bus[s]] = s;
+    }
+    return guarded(h, [&](Ctx &C) {
+        DV &d = C.d;
+        d.nsh = nsh;
+        d.sh_bus = C.upload(std::vector<int>(sh_bus, sh_bus + nsh));
+        d.sh_of_bus = C.upload(of);
+        d.sh_gs = C.upload(std::vector<double>(gs, gs + nsh));
+        d.sh_bs = C.upload(std::vector<double>(bs, bs + nsh));
+        SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
         return SQPHIP_OK;
     });
 }

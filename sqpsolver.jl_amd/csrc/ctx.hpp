@@ -83,6 +83,7 @@ struct DV {
     double *trace;      // [B][CAP][COLS]
     // ---- ACOPF evaluator data
     int nb, ng, nl, ref_bus;
+    int nsh; const int *sh_bus, *sh_of_bus; const double *sh_gs, *sh_bs;   // bus shunts (shared): list, bus -> index or -1
     const int *f_bus, *t_bus, *gen_bus, *bal_ptr, *bal_colP, *bal_colQ;
     const double *bal_coef;
     double *br_ohm, *c2, *c1, *x0;   // per instance; br_ohm[inst][nl][12] = (A, Bc, Bs) of p_f, q_f, p_t, q_t

@@ -8,7 +8,7 @@ that format (MATPOWER case format version 2) and converts it into the `Network` 
 device evaluator and the oracle consume (`acopf_synth.Network`), in per-unit.
 
 Supported subset = what the evaluator models (polar ACOPF, SURVEY.md App. B, with off-nominal
-transformer taps and phase shifters at the from end as MATPOWER defines them): no bus shunts,
+transformer taps and phase shifters at the from end and bus shunts Gs/Bs as MATPOWER defines them):
 polynomial (model 2) generator costs of degree <= 2.  Anything else raises `UnsupportedCase` naming the offending rows, never a silent
 approximation.  HVDC lines (`mpc.dcline`, modelled by the reference's custom build at
 examples/acopf/opf.jl:40-42) are rejected unless `dcline="drop"` is passed.
@@ -131,8 +131,6 @@ def network_from_matpower(mpc: Dict, dcline: str = "error", unlimited_rate: floa
         raise ValueError("duplicate bus numbers")
     idx = {int(b): k for k, b in enumerate(ids)}
     nb = len(ids)
-    if np.any(bus[:, 4] != 0.0) or np.any(bus[:, 5] != 0.0):
-        problems.append(f"bus shunts (Gs/Bs) at buses {ids[(bus[:, 4] != 0) | (bus[:, 5] != 0)].tolist()}")
     if np.any(bus[:, 1] == 4):
         problems.append(f"isolated buses (type 4) {ids[bus[:, 1] == 4].tolist()}")
     on = gen[:, 7] > 0
@@ -197,6 +195,7 @@ def network_from_matpower(mpc: Dict, dcline: str = "error", unlimited_rate: floa
         r=br[:, 2].copy(), x=br[:, 3].copy(), bc=br[:, 4].copy(), rate_a=rate,
         angmin=amin, angmax=amax, status=(br[:, 10] > 0).astype(np.float64),
         tap=np.where(ratio == 0.0, 1.0, ratio), shift=np.deg2rad(shift),
+        gs=bus[:, 4] / base, bs=bus[:, 5] / base,        # MW / MVAr at vm = 1 -> per unit
     )
 
 
@@ -213,7 +212,9 @@ def write_matpower(net: Network, name: str = "case_synth", base_mva: float = 100
     L = [f"function mpc = {name}", "mpc.version = '2';", f"mpc.baseMVA = {f(base_mva)};", "mpc.bus = ["]
     for i in range(net.nb):
         typ = 3 if i == net.ref_bus else (2 if i in gen_at else 1)
-        L.append("\t" + "\t".join([str(i + 1), str(typ), f(net.pd[i] * base_mva), f(net.qd[i] * base_mva), "0.0", "0.0", "1",
+        gsi = 0.0 if net.gs is None else net.gs[i] * base_mva
+        bsi = 0.0 if net.bs is None else net.bs[i] * base_mva
+        L.append("\t" + "\t".join([str(i + 1), str(typ), f(net.pd[i] * base_mva), f(net.qd[i] * base_mva), f(gsi), f(bsi), "1",
                                    "1.0", "0.0", "230.0", "1", f(net.vmax[i]), f(net.vmin[i])]) + ";")
     L += ["];", "mpc.gen = ["]
     for k in range(net.ng):

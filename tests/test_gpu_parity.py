@@ -101,13 +101,24 @@ def _with_transformers(net, seed):
                                shift=np.where(tr & (rng.random(net.nl) < 0.3), rng.uniform(-0.08, 0.08, net.nl), 0.0))
 
 
-@pytest.mark.parametrize("case", ["case14", "case118", "case14-taps", "case118-taps"])
+def _with_shunts(net, seed):
+    """Shunt conductance at a third of the buses, capacitor / reactor banks at 40 %."""
+    rng = np.random.default_rng(seed)
+    return dataclasses.replace(net, gs=np.where(rng.random(net.nb) < 0.3, rng.uniform(0, 0.03, net.nb), 0.0),
+                               bs=np.where(rng.random(net.nb) < 0.4, rng.uniform(-0.05, 0.19, net.nb), 0.0))
+
+
+@pytest.mark.parametrize("case", ["case14", "case118", "case14-taps", "case118-taps", "case14-taps-shunts",
+                                  "case118-shunts"])
 def test_acopf_evaluator_matches_oracle(case):
     nb, ng, nl, seed = CASES[case.split("-")[0]]
     net = contingency(acopf_synth(nb, ng, nl, seed), 5, seed)
-    if case.endswith("taps"):
+    if "taps" in case:
         net = _with_transformers(net, seed)
+    if "shunts" in case:
+        net = _with_shunts(net, seed)
     lay = acopf_layout(net)
+    assert (len(lay.sh_bus) > 0) == ("shunts" in case)
     P = O.problem_acopf(net, lay)
     ctx = pkg.Context(lay.n, lay.m, lay.num_linear, lay.jrow, lay.jcol, lay.hrow, lay.hcol, lay.xL, lay.xU,
                       lay.gL, lay.gU, batch=2)
@@ -338,6 +349,36 @@ def test_batched_sqp_on_networks_with_taps_and_phase_shifters():
         objs.append(rg["obj_val"])
     assert abs(objs[1] - objs[0]) > 1e-6 * abs(objs[0])       # the transformers do change the optimum
     ctx.close()
+
+
+def test_batched_sqp_on_networks_with_bus_shunts():
+    """Bus shunts put a vm^2 term into the balance rows (nonlinear rows, extra Jacobian / Hessian entries at the end
+    of the COO lists, sqphip_acopf_set_shunts): a batch of three scenarios of a shunted network against the oracle."""
+    nb, ng, nl, seed = CASES["case14"]
+    base = _with_shunts(acopf_synth(nb, ng, nl, seed), 7)
+    nets = [base, contingency(base, 3, seed), _with_transformers(contingency(base, 6, seed), 4)]
+    lays = [acopf_layout(nt) for nt in nets]
+    assert lays[0].num_linear == 2 * nl + 1 and len(lays[0].sh_bus) >= 3
+    kw = dict(max_iter=40, tol_infeas=1e-6, tol_residual=1e-4, literal_quirks=0, use_soc=1)
+    ctx = pkg.Context(lays[0].n, lays[0].m, lays[0].num_linear, lays[0].jrow, lays[0].jcol, lays[0].hrow, lays[0].hcol,
+                      lays[0].xL, lays[0].xU, lays[0].gL, lays[0].gU, pkg.default_options(**kw), batch=len(nets))
+    ctx.acopf_attach(base, lays[0])
+    for b in range(len(nets)):
+        ctx.acopf_set_instance(b, nets[b], lays[b])
+    ctx.sqp_reset(); ctx.sqp_run(0)
+    for b in range(len(nets)):
+        ro = O.sqp_solve(O.problem_acopf(nets[b], lays[b]), O.default_options(**kw))
+        rg = ctx.sqp_get(b)
+        assert (rg["status"], rg["iter"]) == (ro["status"], ro["iter"])
+        tol = TOL if ro["status"] == 0 else TOL_TRAJ
+        assert rel(rg["x"], ro["x"]) < 100 * tol and abs(rg["obj_val"] - ro["obj_val"]) <= tol * abs(ro["obj_val"])
+    # a context whose structure has no shunt entries refuses shunt data
+    plain = acopf_layout(acopf_synth(nb, ng, nl, seed))
+    c2 = pkg.Context(plain.n, plain.m, plain.num_linear, plain.jrow, plain.jcol, plain.hrow, plain.hcol, plain.xL,
+                     plain.xU, plain.gL, plain.gU)
+    with pytest.raises(pkg.SqpHipError):
+        c2.acopf_attach(base, lays[0])
+    c2.close(); ctx.close()
 
 
 def test_condensed_kkt_fixes_the_kept_rows_at_creation():

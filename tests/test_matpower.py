@@ -75,7 +75,6 @@ def test_conversion_per_unit_renumbering_status():
 
 @pytest.mark.parametrize("edit,needle", [
     (("0.01 0.10 0.02  100 0 0 0 0 1 -30 30", "0.01 0.10 0.02  100 0 0 -0.98 0 1 -30 30"), "negative tap"),
-    (("20  1  40.0  10.0  0 0", "20  1  40.0  10.0  0 4.5"), "shunts"),
     (("2 0 0 3  0.02 12.0 100.0", "1 0 0 3  0.02 12.0 100.0"), "piecewise"),
     (("mpc.bus_name", "mpc.dcline = [10 20 1 10 10 5 0 1 1 10 90 -90 90 -90 90 0 0 0 0 0 0 0 0];\nmpc.bus_name"), "HVDC"),
 ])
@@ -118,7 +117,36 @@ def test_taps_and_phase_shifters_are_read_and_reach_the_flow_equations():
     assert np.allclose(back.tap, net.tap, rtol=1e-15) and np.allclose(back.shift, net.shift, rtol=1e-13, atol=1e-16)
 
 
-def test_tapped_network_evaluator_derivatives_match_finite_differences():
+def test_bus_shunts_are_read_and_enter_the_balance_rows():
+    """Gs / Bs columns of mpc.bus -> Network.gs / bs (per unit) -> vm^2 terms of the balance rows, checked against
+    the complex bus injection  S_i = sum of branch flows + V_i conj(Y_sh V_i),  Y_sh = gs + j bs; the rows become
+    nonlinear rows and the structure gains 2 Jacobian + 1 Hessian entries per shunted bus."""
+    from oracle import oracle as O
+    txt = HAND.replace("20  1  40.0  10.0  0 0", "20  1  40.0  10.0  1.5 4.5")
+    assert txt != HAND
+    net = MP.network_from_matpower(MP.read_matpower(txt))
+    sb, gs, bs = net.shunts()
+    assert sb.tolist() == [1] and np.allclose(gs, [0.03]) and np.allclose(bs, [0.09])      # baseMVA = 50
+    plain = MP.network_from_matpower(MP.read_matpower(HAND))
+    lay, lay0 = acopf_layout(net), acopf_layout(plain)
+    assert lay.num_linear == 2 * net.nl + 1 and lay0.num_linear == 2 * net.nl + 1 + 2 * net.nb
+    assert len(lay.jrow) == len(lay0.jrow) + 2 and len(lay.hrow) == len(lay0.hrow) + 1
+    rng = np.random.default_rng(5)
+    x = np.clip(lay.x0 + 0.05 * rng.standard_normal(lay.n), lay.xL, lay.xU)
+    g, g0 = O.problem_acopf(net, lay).eval_g(x), O.problem_acopf(plain, lay0).eval_g(x)
+    vm = x[net.nb + 1]
+    d = g - g0
+    rp, rq = 2 * net.nl + 1 + 2 * 1, 2 * net.nl + 2 + 2 * 1
+    assert np.isclose(d[rp], 0.03 * vm ** 2, rtol=1e-13) and np.isclose(d[rq], -0.09 * vm ** 2, rtol=1e-13)
+    assert np.count_nonzero(d) == 2
+    s_sh = vm ** 2 * np.conj(0.03 + 0.09j)                      # V conj(Y V) = |V|^2 conj(Y)
+    assert np.isclose(d[rp], s_sh.real) and np.isclose(d[rq], s_sh.imag)
+    back = MP.load_case(MP.write_matpower(net, "shunted", base_mva=50.0))
+    assert np.allclose(back.gs, net.gs) and np.allclose(back.bs, net.bs)
+
+
+@pytest.mark.parametrize("shunts", [False, True])
+def test_tapped_network_evaluator_derivatives_match_finite_differences(shunts):
     """The oracle's ACOPF callbacks on a network with random taps and shifts: Jacobian and Hessian of the
     Lagrangian against central differences of eval_g / eval_jac_g."""
     from oracle import oracle as O
@@ -126,7 +154,11 @@ def test_tapped_network_evaluator_derivatives_match_finite_differences():
     net = acopf_synth(14, 5, 20, 14)
     rng = np.random.default_rng(3)
     net.tap = rng.uniform(0.92, 1.08, net.nl); net.shift = rng.uniform(-0.1, 0.1, net.nl)
+    if shunts:
+        net.gs = np.where(rng.random(net.nb) < 0.3, rng.uniform(0.0, 0.05, net.nb), 0.0)
+        net.bs = np.where(rng.random(net.nb) < 0.3, rng.uniform(-0.1, 0.2, net.nb), 0.0)
     lay = acopf_layout(net)
+    assert (len(lay.sh_bus) > 0) == shunts
     P = O.problem_acopf(net, lay)
     x = np.clip(lay.x0 + 0.05 * rng.standard_normal(lay.n), lay.xL, lay.xU)
     lam = rng.standard_normal(lay.m)
