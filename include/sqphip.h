@@ -77,6 +77,14 @@ int sqphip_create(sqphip_ctx **ctx, int64_t n, int64_t m, int64_t num_linear,
                   const double *xL, const double *xU, const double *gL, const double *gU,
                   const sqphip_options *opt, int32_t batch);
 void sqphip_destroy(sqphip_ctx *ctx);
+/* Host-only (no GPU): the ordering options.kkt_order = 1 gives the condensed Newton matrix of this structure.
+ * pos[u], u < n + #(gL == gU): position of variable u (u < n) or of the (u - n)-th row with gL == gU in the
+ * factorised matrix; the first n_lead_tiles 64-column tiles are mutually independent (block-diagonal leading block,
+ * identity padding inside the tiles), the positions from 64 * n_lead_tiles to order - 1 are the dense remainder.
+ * Same COO conventions as sqphip_create. */
+int sqphip_kkt_order(int64_t n, int64_t m, int64_t nnzJ, const int64_t *jrow, const int64_t *jcol,
+                     int64_t nnzH, const int64_t *hrow, const int64_t *hcol, const double *gL, const double *gU,
+                     int32_t rows_last, int32_t *pos, int32_t *n_lead_tiles, int32_t *order);
 const char *sqphip_last_error(const sqphip_ctx *ctx);
 int sqphip_set_bounds(sqphip_ctx *ctx, int32_t inst, const double *xL, const double *xU,
                       const double *gL, const double *gU);

@@ -126,6 +126,17 @@ def f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
+def set_kkt_order(pos=None):
+    """Order of the condensed Newton matrix for every solver created afterwards: `pos` as returned by the product
+    library's host-only `sqphip_kkt_order` (padding is squeezed out here); None restores the natural order."""
+    L = lib()
+    L.ora_set_kkt_order.argtypes = [C.POINTER(C.c_int32), C.c_int64]
+    if pos is None:
+        L.ora_set_kkt_order(None, 0); return
+    rank = np.empty(len(pos), dtype=np.int32); rank[np.argsort(pos, kind="stable")] = np.arange(len(pos), dtype=np.int32)
+    L.ora_set_kkt_order(rank.ctypes.data_as(C.POINTER(C.c_int32)), len(rank))
+
+
 def default_options(**kw) -> Options:
     o = Options()
     lib().ora_default_options(C.byref(o))

@@ -59,6 +59,7 @@ struct ora_qp {
      * all other rows are eliminated; CSR view of J for the row-wise products */
     int64_t mk, Nc;
     int64_t *kpos, *jrowptr, *jrcol, *jrslot;
+    int64_t *ord;      /* rank of unknown u (variable j, or n + kpos) in the factorised matrix (ora_set_kkt_order) */
     double *rhsc;
     double delta_w_last;
     /* stats */
@@ -67,6 +68,20 @@ struct ora_qp {
 };
 
 static double *dalloc(int64_t k) { return (double *)calloc((size_t)(k > 0 ? k : 1), sizeof(double)); }
+
+/* ordering of the condensed matrix (test hook: the rank of every unknown in the order the product library uses,
+ * sqphip_kkt_order with the padding squeezed out); applies to every ora_qp created afterwards whose condensed order
+ * matches `len`; len = 0 restores the natural order (variables, then kept rows) */
+static int64_t *g_kkt_rank = NULL;
+static int64_t g_kkt_len = 0;
+void ora_set_kkt_order(const int32_t *rank, int64_t len)
+{
+    free(g_kkt_rank); g_kkt_rank = NULL; g_kkt_len = 0;
+    if (len <= 0 || !rank) return;
+    g_kkt_rank = (int64_t *)malloc(sizeof(int64_t) * (size_t)len);
+    for (int64_t i = 0; i < len; ++i) g_kkt_rank[i] = rank[i];
+    g_kkt_len = len;
+}
 
 ora_qp *ora_qp_create(int64_t n, int64_t m, int64_t num_linear,
                       const int64_t *jcolptr, const int64_t *jrowval,
@@ -114,6 +129,8 @@ ora_qp *ora_qp_create(int64_t n, int64_t m, int64_t num_linear,
     q->mk = 0;
     for (int64_t i = 0; i < m; ++i) q->kpos[i] = (gL[i] == gU[i]) ? q->mk++ : -1;
     q->Nc = n + q->mk;
+    q->ord = (int64_t *)malloc(sizeof(int64_t) * (size_t)(q->Nc + 1));
+    for (int64_t u = 0; u < q->Nc; ++u) q->ord[u] = (g_kkt_len == q->Nc) ? g_kkt_rank[u] : u;
     q->rhsc = dalloc(q->Nc);
     q->jrowptr = (int64_t *)calloc((size_t)(m + 2), sizeof(int64_t));
     q->jrcol = (int64_t *)malloc(sizeof(int64_t) * (size_t)(q->nnzj + 1));
@@ -140,7 +157,7 @@ void ora_qp_destroy(ora_qp *q)
         q->p, q->zl, q->zu, q->s, q->tp, q->tm, q->y, q->vl, q->vu, q->dp, q->dzl, q->dzu, q->ds,
         q->dtp, q->dtm, q->dy, q->dvl, q->dvu, q->k_gl, q->k_gu, q->k_al, q->k_au, q->k_tp, q->k_tm,
         q->K, q->dinv, q->rhs, q->sol, q->res, q->sigp, q->D, q->zp, q->zm,
-        q->kpos, q->jrowptr, q->jrcol, q->jrslot, q->rhsc };
+        q->kpos, q->jrowptr, q->jrcol, q->jrslot, q->rhsc, q->ord };
     for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) free(ptrs[i]);
     free(q);
 }
@@ -323,26 +340,30 @@ static void kkt_assemble(ora_qp *q, double delta_w)
 static void kkt_assemble_condensed(ora_qp *q, double delta_w)
 {
     int64_t n = q->n, m = q->m, Nc = q->Nc, ld = q->ld;
+    const int64_t *ord = q->ord;
     memset(q->K, 0, sizeof(double) * (size_t)(ld * Nc));
+    /* entry (a, b) of the symmetric matrix, in the order `ord`, lower triangle */
+#define KADD(a, b, v) do { int64_t ra_ = ord[a], rb_ = ord[b]; \
+        if (ra_ >= rb_) q->K[rb_ * ld + ra_] += (v); else q->K[ra_ * ld + rb_] += (v); } while (0)
     for (int64_t j = 0; j < n; ++j) {
-        double *col = q->K + j * ld;
-        col[j] = q->hd[j] + q->sigp[j] + delta_w + ipm_reg_p();
+        KADD(j, j, q->hd[j] + q->sigp[j] + delta_w + ipm_reg_p());
         for (int64_t k = q->hcolptr[j]; k < q->hcolptr[j + 1]; ++k) {
             int64_t i = q->hrowval[k];
-            if (i >= j) col[i] += q->hv[k];
+            if (i >= j) KADD(i, j, q->hv[k]);
         }
         for (int64_t k = q->jcolptr[j]; k < q->jcolptr[j + 1]; ++k) {
             int64_t i = q->jrowval[k];
             if (q->rtype[i] == ROW_FREE) continue;
-            if (q->kpos[i] >= 0) { col[n + q->kpos[i]] += q->jv[k]; continue; }
+            if (q->kpos[i] >= 0) { KADD(n + q->kpos[i], j, q->jv[k]); continue; }
             const double f = q->jv[k] / (q->D[i] + ipm_reg_d());
             for (int64_t t = q->jrowptr[i]; t < q->jrowptr[i + 1]; ++t)
-                if (q->jrcol[t] >= j) col[q->jrcol[t]] += f * q->jv[q->jrslot[t]];
+                if (q->jrcol[t] >= j) KADD(q->jrcol[t], j, f * q->jv[q->jrslot[t]]);
         }
     }
     for (int64_t i = 0; i < m; ++i)
         if (q->kpos[i] >= 0)
-            q->K[(n + q->kpos[i]) * ld + n + q->kpos[i]] = q->rtype[i] == ROW_FREE ? -1.0 : -(q->D[i] + ipm_reg_d());
+            KADD(n + q->kpos[i], n + q->kpos[i], q->rtype[i] == ROW_FREE ? -1.0 : -(q->D[i] + ipm_reg_d()));
+#undef KADD
 }
 
 /* res = rhs - K sol  with K applied through its sparse pieces */
@@ -411,20 +432,20 @@ static void kkt_apply(ora_qp *q, const double *rhs, double *sol)
         /* condensed right-hand side g + J_I' (D_I + reg)^-1 b_I, solve, then q_I = (J_I dp - b_I) / (D_I + reg) */
         int64_t n = q->n, m = q->m;
         double *rc = q->rhsc;
-        memcpy(rc, rhs, sizeof(double) * (size_t)n);
+        const int64_t *ord = q->ord;
         for (int64_t j = 0; j < n; ++j) {
             double acc = 0.0;
             for (int64_t k = q->jcolptr[j]; k < q->jcolptr[j + 1]; ++k) {
                 int64_t i = q->jrowval[k];
                 if (q->rtype[i] != ROW_FREE && q->kpos[i] < 0) acc += q->jv[k] * rhs[n + i] / (q->D[i] + ipm_reg_d());
             }
-            rc[j] += acc;
+            rc[ord[j]] = rhs[j] + acc;
         }
-        for (int64_t i = 0; i < m; ++i) if (q->kpos[i] >= 0) rc[n + q->kpos[i]] = rhs[n + i];
+        for (int64_t i = 0; i < m; ++i) if (q->kpos[i] >= 0) rc[ord[n + q->kpos[i]]] = rhs[n + i];
         ora_ldlt_solve(q->Nc, q->K, q->ld, q->dinv, rc);
-        memcpy(sol, rc, sizeof(double) * (size_t)n);
+        for (int64_t j = 0; j < n; ++j) sol[j] = rc[ord[j]];
         for (int64_t i = 0; i < m; ++i) {
-            if (q->kpos[i] >= 0) { sol[n + i] = rc[n + q->kpos[i]]; continue; }
+            if (q->kpos[i] >= 0) { sol[n + i] = rc[ord[n + q->kpos[i]]]; continue; }
             if (q->rtype[i] == ROW_FREE) { sol[n + i] = -rhs[n + i]; continue; }     /* row -1 * q = b */
             double acc = 0.0;
             for (int64_t t = q->jrowptr[i]; t < q->jrowptr[i + 1]; ++t) acc += q->jv[q->jrslot[t]] * sol[q->jrcol[t]];

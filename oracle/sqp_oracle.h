@@ -170,6 +170,8 @@ typedef struct ora_problem ora_problem;
 ora_problem *ora_problem_toy(void);
 ora_problem *ora_problem_readme1(void);
 ora_problem *ora_problem_hs071(void);
+/* test hook: order of the condensed Newton matrix for every QP solver created afterwards (len 0 = natural) */
+void ora_set_kkt_order(const int32_t *rank, int64_t len);
 /* ACOPF evaluator over the arrays of sqpsolver.jl_amd/acopf_synth.py (Network + NlpLayout) */
 ora_problem *ora_problem_acopf(int nb, int ng, int nl, const int32_t *f_bus,
                                const int32_t *t_bus, const double *ohm /* [nl][12] */,

@@ -8,7 +8,7 @@ import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 SO_PATH = os.path.join(_CSRC, "libsqphip.so")
-SOURCES = ["ldlt.hip", "kernel_api.hip", "ipm.hip", "acopf.hip", "sqp.hip", "api.hip"]
+SOURCES = ["ldlt.hip", "kernel_api.hip", "ipm.hip", "acopf.hip", "sqp.hip", "api.hip", "order.hip"]
 HEADERS = ["sqphip_internal.hpp", "ctx.hpp", os.path.join("..", "..", "include", "sqphip.h")]
 
 _lib = None
@@ -89,6 +89,8 @@ def lib():
                                               ip, dp, C.c_int32]
             L.sqphip_acopf_set_instance.argtypes = [vp, C.c_int32, dp, dp, dp, dp]
             L.sqphip_acopf_set_shunts.argtypes = [vp, C.c_int32, ip, dp, dp]
+            L.sqphip_kkt_order.argtypes = [C.c_int64, C.c_int64, C.c_int64, lp, lp, C.c_int64, lp, lp, dp, dp, C.c_int32,
+                                           ip, ip, ip]
             L.sqphip_acopf_eval.argtypes = [vp, C.c_int32, dp, C.c_double, dp, dp, dp, dp, dp, dp]
             L.sqphip_sqp_reset.argtypes = [vp]
             L.sqphip_sqp_run.argtypes = [vp, C.c_int32]
@@ -107,7 +109,7 @@ EXPORTS = [
     "sqphip_set_bounds", "sqphip_qp_solve", "sqphip_qp_stats", "sqphip_norm_violations",
     "sqphip_kt_residuals", "sqphip_norm_complementarity", "sqphip_compute_phi",
     "sqphip_compute_qmodel", "sqphip_compute_derivative", "sqphip_tr_update",
-    "sqphip_acopf_attach", "sqphip_acopf_set_shunts", "sqphip_acopf_set_instance", "sqphip_acopf_eval", "sqphip_sqp_reset",
+    "sqphip_kkt_order", "sqphip_acopf_attach", "sqphip_acopf_set_shunts", "sqphip_acopf_set_instance", "sqphip_acopf_eval", "sqphip_sqp_reset",
     "sqphip_sqp_run", "sqphip_sqp_get", "sqphip_sqp_status", "sqphip_sqp_trace",
     "sqphip_get_counters", "sqphip_reset_counters", "sqphip_set_timing", "sqphip_ldlt_factor_host",
     "sqphip_ldlt_solve_host", "sqphip_ldlt_bench", "sqphip_ldlt_stress", "sqphip_mfma_f64_peak", "sqphip_armijo_alpha", "sqphip_compute_mu_rule",

@@ -1,0 +1,140 @@
+// order.hip -- host-only: ordering of the condensed Newton matrix that exposes its tile sparsity.
+//
+// The condensed matrix K_c (ipm.hip, k_kkt_assemble) of a structured NLP is very sparse: in an ACOPF instance
+// everything but the bus voltages hangs off them in small pieces.  This file finds, from the PATTERN alone, a vertex
+// separator R such that the rest of the unknowns S falls into connected components of at most 64 unknowns, and packs
+// those components into 64-slot tiles.  Ordered [tiles of S | R], the leading Ts x Ts tile block of K_c is block
+// diagonal, and stays so during the elimination (independent components create no fill between each other), so the
+// factorisation can treat the Ts leading tile columns as independent (ldlt.hip, ldlt_factor) and only the last
+// |R| unknowns as a dense matrix.  Any choice is numerically admissible: K_c is quasi-definite, an LDL^T without
+// pivoting exists under every symmetric permutation (Vanderbei 1995) and the inertia test (n positive pivots) does
+// not depend on the order -- the quality of the heuristic only decides how much work is saved.
+//
+// Heuristic: while some component of the graph of S has more than 64 vertices, move its vertex of highest degree
+// (ties: lowest index) to R.  Components sorted by size (ties: lowest vertex) are packed first-fit into tiles;
+// inside a tile variables come before rows.
+#include "sqphip_internal.hpp"
+#include "../../include/sqphip.h"
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+namespace sqphip {
+
+// unknown u: variable j (u = j < n) or kept row (u = n + kpos).  adj: symmetric adjacency lists (sorted, unique)
+KktOrder kkt_order_from_graph(int n, int nc, const std::vector<std::vector<int>> &adj, bool rows_last)
+{
+    std::vector<char> inS(nc, 1);
+    if (rows_last) for (int u = n; u < nc; ++u) inS[u] = 0;     // every kept row goes to the dense remainder
+    std::vector<int> comp(nc), deg(nc), stack;
+    std::vector<std::vector<int>> comps;
+    for (;;) {
+        // components of the graph induced on S
+        std::fill(comp.begin(), comp.end(), -1);
+        comps.clear();
+        for (int s = 0; s < nc; ++s) {
+            if (!inS[s] || comp[s] >= 0) continue;
+            const int id = (int)comps.size();
+            comps.emplace_back();
+            stack.assign(1, s); comp[s] = id;
+            while (!stack.empty()) {
+                const int u = stack.back(); stack.pop_back();
+                comps[id].push_back(u);
+                for (int v : adj[u]) if (inS[v] && comp[v] < 0) { comp[v] = id; stack.push_back(v); }
+            }
+        }
+        bool changed = false;
+        for (auto &c : comps) {
+            if ((int)c.size() <= 64) continue;
+            int best = -1, bestdeg = -1;
+            for (int u : c) {
+                int d = 0;
+                for (int v : adj[u]) d += inS[v];
+                if (d > bestdeg || (d == bestdeg && u < best)) { best = u; bestdeg = d; }
+            }
+            inS[best] = 0; changed = true;
+        }
+        if (!changed) break;
+    }
+    for (auto &c : comps) std::sort(c.begin(), c.end());
+    std::sort(comps.begin(), comps.end(), [](const std::vector<int> &a, const std::vector<int> &b) {
+        return a.size() != b.size() ? a.size() > b.size() : a[0] < b[0]; });
+    // first-fit packing into 64-slot tiles
+    std::vector<std::vector<int>> bins;
+    for (auto &c : comps) {
+        size_t b = 0;
+        while (b < bins.size() && bins[b].size() + c.size() > 64) ++b;
+        if (b == bins.size()) bins.emplace_back();
+        bins[b].insert(bins[b].end(), c.begin(), c.end());
+    }
+    KktOrder o;
+    o.pos.assign(nc, -1);
+    o.Ts = (int)bins.size();
+    for (size_t b = 0; b < bins.size(); ++b) {
+        std::sort(bins[b].begin(), bins[b].end());        // variables (u < n) first, then rows
+        for (size_t k = 0; k < bins[b].size(); ++k) o.pos[bins[b][k]] = (int)(64 * b + k);
+    }
+    int p = 64 * o.Ts;
+    for (int u = 0; u < nc; ++u) if (!inS[u]) o.pos[u] = p++;
+    o.Nf = p;
+    return o;
+}
+
+// graph of K_c from the NLP structure: H (full symmetric CSC), J (CSR), kept rows (kpos >= 0) as vertices,
+// eliminated rows as cliques among their variables (J_I' D^-1 J_I)
+KktOrder kkt_order(int n, int m, const std::vector<int> &kpos, int mk, const std::vector<int> &hcolptr,
+                   const std::vector<int> &hrowval, const std::vector<int> &jrowptr, const std::vector<int> &jrcol,
+                   bool rows_last)
+{
+    const int nc = n + mk;
+    std::vector<std::vector<int>> adj(nc);
+    auto edge = [&](int a, int b) { if (a != b) { adj[a].push_back(b); adj[b].push_back(a); } };
+    for (int j = 0; j < n; ++j)
+        for (int k = hcolptr[j]; k < hcolptr[j + 1]; ++k) if (hrowval[k] > j) edge(hrowval[k], j);
+    for (int i = 0; i < m; ++i) {
+        const int s = jrowptr[i], e = jrowptr[i + 1];
+        if (kpos[i] >= 0) { for (int t = s; t < e; ++t) edge(n + kpos[i], jrcol[t]); }
+        else for (int a = s; a < e; ++a) for (int b = a + 1; b < e; ++b) edge(jrcol[a], jrcol[b]);
+    }
+    for (auto &l : adj) { std::sort(l.begin(), l.end()); l.erase(std::unique(l.begin(), l.end()), l.end()); }
+    return kkt_order_from_graph(n, nc, adj, rows_last);
+}
+
+}  // namespace sqphip
+
+// C-ABI: pure host computation (no GPU needed), 1-based COO structures as in sqphip_create
+extern "C" int sqphip_kkt_order(int64_t n, int64_t m, int64_t nnzJ, const int64_t *jrow, const int64_t *jcol,
+                                int64_t nnzH, const int64_t *hrow, const int64_t *hcol, const double *gL,
+                                const double *gU, int32_t rows_last, int32_t *pos, int32_t *n_lead_tiles,
+                                int32_t *order_out)
+{
+    if (n <= 0 || m < 0 || !pos) return SQPHIP_EINVAL;
+    std::vector<int> kpos(m > 0 ? m : 1, -1);
+    int mk = 0;
+    for (int64_t i = 0; i < m; ++i) if (gL[i] == gU[i]) kpos[i] = mk++;
+    std::vector<std::vector<int>> hc(n), jr(m);
+    for (int64_t k = 0; k < nnzH; ++k) {
+        const int r = (int)hrow[k] - 1, c = (int)hcol[k] - 1;
+        if (r < 0 || r >= n || c < 0 || c >= n) return SQPHIP_EINVAL;
+        hc[c].push_back(r); if (r != c) hc[r].push_back(c);
+    }
+    for (int64_t k = 0; k < nnzJ; ++k) {
+        const int r = (int)jrow[k] - 1, c = (int)jcol[k] - 1;
+        if (r < 0 || r >= m || c < 0 || c >= n) return SQPHIP_EINVAL;
+        jr[r].push_back(c);
+    }
+    std::vector<int> hcolptr(n + 1, 0), hrowval, jrowptr(m + 1, 0), jrcol;
+    for (int j = 0; j < n; ++j) {
+        std::sort(hc[j].begin(), hc[j].end()); hc[j].erase(std::unique(hc[j].begin(), hc[j].end()), hc[j].end());
+        hrowval.insert(hrowval.end(), hc[j].begin(), hc[j].end()); hcolptr[j + 1] = (int)hrowval.size();
+    }
+    for (int i = 0; i < m; ++i) {
+        std::sort(jr[i].begin(), jr[i].end()); jr[i].erase(std::unique(jr[i].begin(), jr[i].end()), jr[i].end());
+        jrcol.insert(jrcol.end(), jr[i].begin(), jr[i].end()); jrowptr[i + 1] = (int)jrcol.size();
+    }
+    sqphip::KktOrder o = sqphip::kkt_order((int)n, (int)m, kpos, mk, hcolptr, hrowval, jrowptr, jrcol, rows_last != 0);
+    for (int u = 0; u < (int)n + mk; ++u) pos[u] = o.pos[u];
+    if (n_lead_tiles) *n_lead_tiles = o.Ts;
+    if (order_out) *order_out = o.Nf;
+    return SQPHIP_OK;
+}

@@ -107,4 +107,14 @@ void ldlt_solve(const LdltPlan &P, const double *K, const double *dinv, double *
         }                                                                                      \
     } while (0)
 
+// order.hip: ordering of the condensed Newton matrix that exposes its tile sparsity
+struct KktOrder {
+    std::vector<int> pos;   // unknown (variable j, or n + kept-row position) -> position in the factorised matrix
+    int Ts = 0;             // leading tile columns, mutually independent (block-diagonal leading Ts x Ts tile block)
+    int Nf = 0;             // positions used: 64 * Ts for the tiles (identity padding inside) + the dense remainder
+};
+KktOrder kkt_order(int n, int m, const std::vector<int> &kpos, int mk, const std::vector<int> &hcolptr,
+                   const std::vector<int> &hrowval, const std::vector<int> &jrowptr, const std::vector<int> &jrcol,
+                   bool rows_last);
+
 }  // namespace sqphip

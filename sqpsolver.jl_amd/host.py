@@ -63,6 +63,20 @@ def default_options(**kw) -> _lib.Options:
     return o
 
 
+def kkt_order(n, m, jrow, jcol, hrow, hcol, gL, gU, rows_last=True):
+    """(pos, n_lead_tiles, order) of `sqphip_kkt_order`: host-only, works without a GPU."""
+    L = _lib.lib()
+    jr, jc, hr, hc = (np.ascontiguousarray(a, dtype=np.int64) for a in (jrow, jcol, hrow, hcol))
+    mk = int(np.sum(np.asarray(gL) == np.asarray(gU)))
+    pos = np.zeros(n + mk, dtype=np.int32); ts = C.c_int32(); nf = C.c_int32()
+    rc = L.sqphip_kkt_order(n, m, len(jr), jr.ctypes.data_as(C.POINTER(C.c_int64)), jc.ctypes.data_as(C.POINTER(C.c_int64)),
+                            len(hr), hr.ctypes.data_as(C.POINTER(C.c_int64)), hc.ctypes.data_as(C.POINTER(C.c_int64)),
+                            _d(_f(gL)), _d(_f(gU)), int(rows_last), pos.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(ts), C.byref(nf))
+    if rc != 0:
+        raise SqpHipError(f"sqphip_kkt_order failed ({rc})")
+    return pos, ts.value, nf.value
+
+
 class Context:
     """Owns a sqphip_ctx (one NLP structure, `batch` instances)."""
 
