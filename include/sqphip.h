@@ -60,6 +60,10 @@ typedef struct {
                               * correction of a solve; 0: monotone Fiacco-McCormick rule throughout */
     int32_t kkt_condense;    /* 1: rows with gL != gU (diagonal block -D of the Newton matrix) are eliminated before
                               * the factorisation: dense LDL^T of order n + #(gL == gU) instead of n + m */
+    int32_t kkt_tile_order;  /* 1 (needs kkt_condense): the variables are ordered so that the leading tile columns of
+                              * the condensed matrix are mutually independent (sqphip_kkt_order, rows_last = 1) and
+                              * the factorisation treats them as such: one launch per kernel for all of them, the
+                              * dense chain only on the remainder */
 } sqphip_options;
 
 void sqphip_default_options(sqphip_options *o);

@@ -99,7 +99,7 @@ extern "C" void sqphip_default_options(sqphip_options *o)
     o->init_mu = 1.0; o->max_mu = 1e10; o->tr_size = 10.0;
     o->rho = 0.8; o->eta = 0.4; o->tau = 0.9; o->min_alpha = 1e-6;
     o->max_iter = 3000; o->use_soc = 0; o->literal_quirks = 1;
-    o->ipm_tol = 1e-9; o->ipm_max_iter = 200; o->ipm_phase1 = 0; o->device = 0; o->ipm_corrector = 1; o->kkt_condense = 1;
+    o->ipm_tol = 1e-9; o->ipm_max_iter = 200; o->ipm_phase1 = 0; o->device = 0; o->ipm_corrector = 1; o->kkt_condense = 1; o->kkt_tile_order = 0;
 }
 
 extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num_linear, int64_t nnzJ,
@@ -135,8 +135,6 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
             if (krow.empty()) krow.push_back(0);
             d.kpos = C.upload(kpos); d.krow = C.upload(krow);
             C.h_kpos = kpos;
-            d.Nf = d.condense ? d.n + d.mk : d.N;
-            d.Fpad = (d.Nf + 63) / 64 * 64; d.ld = d.Fpad;
         }
         d.nnzj_coo = (int)nnzJ; d.nnzh_coo = (int)nnzH;
         Pattern PJ = build_pattern(n, nnzJ, jrow, jcol, false);
@@ -156,6 +154,22 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
         }
         d.jcolptr = C.upload(PJ.colptr); d.jrowval = C.upload(PJ.rowval);
         d.jrowptr = C.upload(rptr); d.jrcol = C.upload(rcol); d.jrslot = C.upload(rslot);
+        {   // order of the factorised matrix
+            const std::vector<int> &kpos = C.h_kpos;
+            const int nu = d.condense ? d.n + d.mk : d.N;       // unknowns of the factorised system
+            std::vector<int> upos(nu);
+            d.Ts = 0; d.Nf = nu;
+            if (d.condense && opt->kkt_tile_order) {
+                KktOrder o = kkt_order(d.n, (int)m, kpos, d.mk, PH.colptr, PH.rowval, rptr, rcol, /*rows_last=*/true);
+                upos = o.pos; d.Ts = o.Ts; d.Nf = o.Nf;
+            } else {
+                for (int u = 0; u < nu; ++u) upos[u] = u;
+            }
+            d.Fpad = (d.Nf + 63) / 64 * 64; d.ld = d.Fpad;
+            std::vector<int> uinv(d.Fpad, -1);
+            for (int u = 0; u < nu; ++u) uinv[upos[u]] = u;
+            d.upos = C.upload(upos); d.uinv = C.upload(uinv);
+        }
         d.hcolptr = C.upload(PH.colptr); d.hrowval = C.upload(PH.rowval);
         d.jg_ptr = C.upload(PJ.g_ptr); d.jg_src = C.upload(PJ.g_src);
         d.hg_ptr = C.upload(PH.g_ptr); d.hg_src = C.upload(PH.g_src);
@@ -181,7 +195,8 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
         d.oslack = C.dalloc<double>(2 * Bm);
         d.rtype = C.dalloc<int>(Bm); d.rbase = C.dalloc<int>(Bm); d.hard = C.dalloc<int>(Bm);
         d.rhs = C.dalloc<double>(BN); d.sol = C.dalloc<double>(BN); d.wN = C.dalloc<double>(BN);
-        d.xv = C.dalloc<double>(BN); d.vv = C.dalloc<double>(BN); d.dinv = C.dalloc<double>(BN);
+        const size_t BF = (size_t)B * d.Fpad;          // solve vectors and pivots live in the factorised order
+        d.xv = C.dalloc<double>(BF); d.vv = C.dalloc<double>(BF); d.dinv = C.dalloc<double>(BF);
         d.K = C.dalloc<double>((size_t)B * d.ld * d.Fpad);
         d.ist = C.dalloc<IpmState>(B); d.sst = C.dalloc<SqpState>(B);
         d.phase = C.dalloc<int>(B); d.counters = C.dalloc<int>(8);

@@ -49,6 +49,11 @@ struct DV {
                                           // K is Fpad x Fpad (ld = Fpad); xv / vv / dinv have stride Fpad
     int condense, mk;                     // options.kkt_condense; number of kept (gL == gU) rows
     const int *kpos, *krow;               // row -> position among the kept rows or -1; kept position -> row
+    // order of the factorised matrix (options.kkt_tile_order; identity otherwise): unknown u = variable j or
+    // n + (kept-row position | row) -> position; position -> unknown or -1 (identity padding); Ts = leading tile
+    // columns that are mutually independent
+    const int *upos, *uinv;
+    int Ts;
     int nnzj_coo, nnzh_coo, nnzjc, nnzhc;
     // shared structure
     const int *jcolptr, *jrowval, *jrowptr, *jrcol, *jrslot;

@@ -345,38 +345,53 @@ __global__ __launch_bounds__(128) void k_kkt_assemble(DV d)
 {
     const int inst = blockIdx.y;
     if (d.phase[inst] != PH_FACTOR) return;
-    const int j = blockIdx.x;
+    const int p = blockIdx.x;                    // position (column of the factorised matrix)
+    const int u = d.uinv[p];                     // unknown at this position: variable, kept row, or -1 = padding
     const IpmState &st = d.ist[inst];
-    double *col = d.K + (long)inst * d.ld * d.Fpad + (long)j * d.ld;
-    for (int i = j + threadIdx.x; i < d.Fpad; i += 128) col[i] = 0.0;
+    double *col = d.K + (long)inst * d.ld * d.Fpad + (long)p * d.ld;
+    for (int i = p + threadIdx.x; i < d.Fpad; i += 128) col[i] = 0.0;
     __syncthreads();
     if (threadIdx.x != 0) return;
-    if (j >= d.Nf) { col[j] = 1.0; return; }
-    if (j >= d.n) {
-        const int i = d.condense ? d.krow[j - d.n] : j - d.n;
-        col[j] = d.rtype[(long)inst * d.m + i] == ROW_FREE ? -1.0 : -(d.Dd[(long)inst * d.m + i] + IPM_REG_D);
-        return;
-    }
-    const double hsc = st.hsc;
-    const double *hv = d.hv + (long)inst * d.nnzhc, *jv = d.jv + (long)inst * d.nnzjc;
+    if (u < 0) { col[p] = 1.0; return; }
+    const double *jv = d.jv + (long)inst * d.nnzjc;
     const int *rt = d.rtype + (long)inst * d.m;
     const double *Dd = d.Dd + (long)inst * d.m;
+    if (u >= d.n) {
+        // a row of the factorised matrix: diagonal, and its Jacobian entries towards variables placed after it
+        const int i = d.condense ? d.krow[u - d.n] : u - d.n;
+        col[p] = rt[i] == ROW_FREE ? -1.0 : -(Dd[i] + IPM_REG_D);
+        if (rt[i] != ROW_FREE)
+            for (int t = d.jrowptr[i]; t < d.jrowptr[i + 1]; ++t) {
+                const int q = d.upos[d.jrcol[t]];
+                if (q > p) col[q] += jv[d.jrslot[t]];
+            }
+        return;
+    }
+    const int j = u;
+    const double hsc = st.hsc;
+    const double *hv = d.hv + (long)inst * d.nnzhc;
     double diag = d.hd[(long)inst * d.n + j] + d.sigp[(long)inst * d.n + j] + st.dw + IPM_REG_P;
     for (int k = d.hcolptr[j]; k < d.hcolptr[j + 1]; ++k) {
         const int i = d.hrowval[k];
-        if (i == j) diag += hsc * hv[k];
-        else if (i > j) col[i] += hsc * hv[k];
+        if (i == j) { diag += hsc * hv[k]; continue; }
+        const int q = d.upos[i];
+        if (q > p) col[q] += hsc * hv[k];
     }
-    col[j] = diag;
+    col[p] = diag;
     for (int k = d.jcolptr[j]; k < d.jcolptr[j + 1]; ++k) {
         const int i = d.jrowval[k];
         if (rt[i] == ROW_FREE) continue;
-        if (!d.condense) { col[d.n + i] += jv[k]; continue; }
-        if (d.kpos[i] >= 0) { col[d.n + d.kpos[i]] += jv[k]; continue; }
-        // eliminated row i: its share J_i' (D_i + reg)^-1 J_i of column j (lower part)
+        if (!d.condense || d.kpos[i] >= 0) {     // a row that is in the matrix (placed after this variable?)
+            const int q = d.upos[d.n + (d.condense ? d.kpos[i] : i)];
+            if (q > p) col[q] += jv[k];
+            continue;
+        }
+        // eliminated row i: its share J_i' (D_i + reg)^-1 J_i of this column (entries at or below the diagonal)
         const double f = jv[k] / (Dd[i] + IPM_REG_D);
-        for (int t = d.jrowptr[i]; t < d.jrowptr[i + 1]; ++t)
-            if (d.jrcol[t] >= j) col[d.jrcol[t]] += f * jv[d.jrslot[t]];
+        for (int t = d.jrowptr[i]; t < d.jrowptr[i + 1]; ++t) {
+            const int q = d.upos[d.jrcol[t]];
+            if (q >= p) col[q] += f * jv[d.jrslot[t]];
+        }
     }
 }
 
@@ -391,21 +406,22 @@ __global__ __launch_bounds__(128) void k_kkt_assemble(DV d)
 // workgroup by the caller).  Full form: a copy.  Condensed form: g + J_I' (D_I + reg)^-1 b_I on top, b_E below.
 __device__ void load_solve_vector(const DV &d, int inst, const double *src, double *xv)
 {
-    if (!d.condense) {
-        for (int i = threadIdx.x; i < d.Fpad; i += TPB) xv[i] = i < d.N ? src[i] : 0.0;
-        return;
-    }
     const double *jv = d.jv + (long)inst * d.nnzjc, *Dd = d.Dd + (long)inst * d.m;
     const int *rt = d.rtype + (long)inst * d.m;
-    for (int j = threadIdx.x; j < d.n; j += TPB) {
-        double acc = 0.0;
-        for (int k = d.jcolptr[j]; k < d.jcolptr[j + 1]; ++k) {
-            const int i = d.jrowval[k];
-            if (rt[i] != ROW_FREE && d.kpos[i] < 0) acc += jv[k] * src[d.n + i] / (Dd[i] + IPM_REG_D);
+    for (int p = threadIdx.x; p < d.Fpad; p += TPB) {
+        const int u = d.uinv[p];
+        double v = 0.0;                                           // identity padding
+        if (u >= d.n) v = src[d.n + (d.condense ? d.krow[u - d.n] : u - d.n)];
+        else if (u >= 0) {
+            v = src[u];
+            if (d.condense)
+                for (int k = d.jcolptr[u]; k < d.jcolptr[u + 1]; ++k) {
+                    const int i = d.jrowval[k];
+                    if (rt[i] != ROW_FREE && d.kpos[i] < 0) v += jv[k] * src[d.n + i] / (Dd[i] + IPM_REG_D);
+                }
         }
-        xv[j] = src[j] + acc;
+        xv[p] = v;
     }
-    for (int k = threadIdx.x; k < d.Fpad - d.n; k += TPB) xv[d.n + k] = k < d.mk ? src[d.n + d.krow[k]] : 0.0;
 }
 
 // Newton right-hand side for centring target tgt (minus the second-order terms when soc), its working copy xv
@@ -463,7 +479,8 @@ __global__ __launch_bounds__(TPB) void k_inertia(DV d)
     IpmState &st = d.ist[inst];
     const double *dinv = d.dinv + (long)inst * d.Fpad;
     double np = 0, bad = 0;
-    for (int i = threadIdx.x; i < d.Nf; i += TPB) {
+    for (int i = threadIdx.x; i < d.Fpad; i += TPB) {
+        if (d.uinv[i] < 0) continue;             // identity padding
         const double v = dinv[i];
         if (!fin(v) || v == 0.0) bad += 1; else if (v > 0) np += 1;
     }
@@ -498,18 +515,18 @@ __global__ __launch_bounds__(TPB) void k_refine(DV d, int last, int want)
     double *xv = d.xv + (long)inst * d.Fpad;
     const int refine_it = st.refine_it;      // read before the first barrier, written by thread 0 at the end
     if (!d.condense) {
-        for (int i = threadIdx.x; i < d.N; i += TPB) sol[i] += xv[i];
+        for (int i = threadIdx.x; i < d.N; i += TPB) sol[i] += xv[d.upos[i]];
     } else {
         // the right-hand side this solve answered: the Newton rhs, or the residual of the first pass
         const double *cur = refine_it == 0 ? rhs : wN;
-        for (int j = threadIdx.x; j < d.n; j += TPB) sol[j] += xv[j];
+        for (int j = threadIdx.x; j < d.n; j += TPB) sol[j] += xv[d.upos[j]];
         for (int i = threadIdx.x; i < d.m; i += TPB) {
             double v;
-            if (d.kpos[i] >= 0) v = xv[d.n + d.kpos[i]];
+            if (d.kpos[i] >= 0) v = xv[d.upos[d.n + d.kpos[i]]];
             else if (rt[i] == ROW_FREE) v = -cur[d.n + i];
             else {      // eliminated row: q_i = (J_i dp - b_i) / (D_i + reg)
                 double acc = 0.0;
-                for (int t = d.jrowptr[i]; t < d.jrowptr[i + 1]; ++t) acc += jv[d.jrslot[t]] * xv[d.jrcol[t]];
+                for (int t = d.jrowptr[i]; t < d.jrowptr[i + 1]; ++t) acc += jv[d.jrslot[t]] * xv[d.upos[d.jrcol[t]]];
                 v = (acc - cur[d.n + i]) / (Dd[i] + IPM_REG_D);
             }
             sol[d.n + i] += v;

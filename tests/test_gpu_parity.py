@@ -381,6 +381,70 @@ def test_batched_sqp_on_networks_with_bus_shunts():
     c2.close(); ctx.close()
 
 
+def test_tile_ordered_kkt_matches_oracle():
+    """options.kkt_tile_order = 1: the variables of the condensed matrix are ordered into mutually independent
+    leading tiles (sqphip_kkt_order) and the factorisation treats them as such.  Same mathematics as the natural
+    order; the oracle factorises the matrix in the same order (O.set_kkt_order) so that both sides stay on one
+    trajectory: sub-problem modes and a batched SQP run at the usual tolerances."""
+    nb, ng, nl, seed = CASES["case14"]
+    net = acopf_synth(nb, ng, nl, seed); lay = acopf_layout(net)
+    P = O.problem_acopf(net, lay); S = P.structure()
+    pos, ts, nf = pkg.kkt_order(lay.n, lay.m, lay.jrow, lay.jcol, lay.hrow, lay.hcol, lay.gL, lay.gU)
+    assert ts >= 1 and nf >= lay.n + int((lay.gL == lay.gU).sum())
+    try:
+        O.set_kkt_order(pos)
+        ctx = pkg.Context(lay.n, lay.m, lay.num_linear, lay.jrow, lay.jcol, lay.hrow, lay.hcol, lay.xL, lay.xU,
+                          lay.gL, lay.gU, pkg.default_options(kkt_tile_order=1))
+        assert ctx.counters()["kkt_order"] == nf
+        osolve = _oracle_qp(P, S, O.default_options())
+        rng = np.random.default_rng(2)
+        xr = np.clip(lay.x0 + 0.02 * rng.standard_normal(lay.n), lay.xL, lay.xU)
+        for x, lam in ((lay.x0, np.zeros(lay.m)), (xr, 50 * rng.standard_normal(lay.m))):
+            df, E, jv, hv = P.eval_grad_f(x), P.eval_g(x), P.eval_jac_g(x), P.eval_h(x, 1.0, lam)
+            for mode, delta in ((O.MODE_LP, 10.0), (O.MODE_QP, 10.0), (O.MODE_QP, 0.2), (O.MODE_FR, 0.2),
+                                (O.MODE_SOC, 1.0), (O.MODE_L1QP, 1.0), (O.MODE_INFEAS, 1.0)):
+                _compare_qp(osolve(mode, x, delta, 3.0, df, E, jv, hv), ctx.qp_solve(mode, x, delta, 3.0, df, E, jv, hv),
+                            **_tols(mode, 1))
+        ctx.close()
+        base = net
+        nets = [base, contingency(base, 2, seed), contingency(base, 5, seed), _with_transformers(base, 3)]
+        lays = [acopf_layout(nt) for nt in nets]
+        for quirks in (0, 1):
+            kw = dict(max_iter=25, tol_infeas=1e-6, tol_residual=1e-4, literal_quirks=quirks, use_soc=1)
+            ctx = pkg.Context(lay.n, lay.m, lay.num_linear, lay.jrow, lay.jcol, lay.hrow, lay.hcol, lay.xL, lay.xU,
+                              lay.gL, lay.gU, pkg.default_options(kkt_tile_order=1, **kw), batch=len(nets))
+            ctx.acopf_attach(base, lay)
+            for b in range(len(nets)):
+                ctx.acopf_set_instance(b, nets[b], lays[b])
+            ctx.sqp_reset(); ctx.sqp_run(0)
+            for b in range(len(nets)):
+                ro = O.sqp_solve(O.problem_acopf(nets[b], lays[b]), O.default_options(**kw))
+                rg = ctx.sqp_get(b)
+                assert (rg["status"], rg["iter"]) == (ro["status"], ro["iter"])
+                tol = TOL if ro["status"] == 0 else TOL_TRAJ
+                assert rel(rg["x"], ro["x"]) < 100 * tol and abs(rg["obj_val"] - ro["obj_val"]) <= tol * abs(ro["obj_val"])
+            ctx.close()
+    finally:
+        O.set_kkt_order(None)
+    # tiny problems: everything fits one tile
+    for name in ("toy", "hs071"):
+        Pn = getattr(O, "problem_" + name)(); Sn = Pn.structure()
+        pos, ts, nf = pkg.kkt_order(Sn["n"], Sn["m"], Sn["jrow"], Sn["jcol"], Sn["hrow"], Sn["hcol"], Sn["gL"], Sn["gU"])
+        try:
+            O.set_kkt_order(pos)
+            ctx = pkg.Context(Sn["n"], Sn["m"], Sn["num_linear"], Sn["jrow"], Sn["jcol"], Sn["hrow"], Sn["hcol"], Sn["xL"],
+                              Sn["xU"], Sn["gL"], Sn["gU"], pkg.default_options(kkt_tile_order=1))
+            osolve = _oracle_qp(Pn, Sn, O.default_options())
+            x = Pn.x0
+            df, E, jv, hv = Pn.eval_grad_f(x), Pn.eval_g(x), Pn.eval_jac_g(x), Pn.eval_h(x, 1.0, np.zeros(Sn["m"]))
+            for mode in (O.MODE_QP, O.MODE_FR, O.MODE_LP, O.MODE_L1QP):
+                _compare_qp(osolve(mode, x, 10.0, 7.0, df, E, jv, hv), ctx.qp_solve(mode, x, 10.0, 7.0, df, E, jv, hv),
+                            **_tols(mode, 1))
+            ctx.close()
+        finally:
+            O.set_kkt_order(None)
+
+
 def test_condensed_kkt_fixes_the_kept_rows_at_creation():
     """The condensed order is n + #(gL == gU) of the creation bounds and is reported by the counters; per-instance
     bounds may move the equality values (contingency loads do) but may not create an equality among the
