@@ -65,6 +65,8 @@ def main():
                          "default keeps one group and a clean roofline measurement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--literal-quirks", type=int, default=1)
+    ap.add_argument("--kkt-tile-order", type=int, default=None,
+                    help="options.kkt_tile_order (default: the library default)")
     ap.add_argument("--kkt-condense", type=int, default=None,
                     help="options.kkt_condense (default: the library default)")
     ap.add_argument("--ipm-corrector", type=int, default=1,
@@ -112,6 +114,8 @@ def main():
     use_soc = 1 if args.sqp_options == "example" else 0
     sqp_kw = dict(tol_infeas=1e-6, tol_residual=1e-4, use_soc=1) if use_soc else {}
     lin_kw = {} if args.kkt_condense is None else {"kkt_condense": args.kkt_condense}
+    if args.kkt_tile_order is not None:
+        lin_kw["kkt_tile_order"] = args.kkt_tile_order
     opts = pkg.default_options(max_iter=3000, literal_quirks=args.literal_quirks, device=local_rank,
                                ipm_corrector=args.ipm_corrector, **lin_kw, **sqp_kw)
     import threading
@@ -182,12 +186,14 @@ def main():
     n_qp, n_ipm, n_fac = (float(v) for v in stats.tolist())
 
     # roofline of the dominant kernel (k_trailing, fp64 MFMA), rank-0 local measurement
-    N = int(c1["kkt_order"])            # order of the factorised matrices (n + m, or the condensed order)
+    cinfo = ctxs[0].counters()
+    N = int(cinfo["kkt_order"])         # order of the factorised matrices (n + m, or the condensed order)
     N_full = lay0.n + lay0.m
     loc_fac = c1["n_factor"] - c0["n_factor"]
     tr_sec = c1["trailing_seconds"] - c0["trailing_seconds"]
     tr_launch = c1["trailing_launches"] - c0["trailing_launches"]
-    achieved = loc_fac * trailing_alg_flops(N) / tr_sec / 1e12 if tr_sec > 0 else 0.0
+    # algorithmic flops of the k_trailing launches of one factorisation, as the library schedules them
+    achieved = loc_fac * float(cinfo["trailing_flops_per_factor"]) / tr_sec / 1e12 if tr_sec > 0 else 0.0
     probe = None
     if rank == 0:
         import ctypes as C
@@ -240,6 +246,7 @@ def main():
                        "groups_per_gpu": G,
                        "literal_quirks": args.literal_quirks, "ipm_corrector": args.ipm_corrector,
                        "kkt_condense": int(opts.kkt_condense), "kkt_order_full": N_full,
+                       "kkt_tile_order": int(opts.kkt_tile_order), "independent_lead_tiles": int(cinfo["lead_tiles"]),
                        "qp_solved": n_qp, "ipm_iterations": n_ipm, "kkt_factorisations": n_fac,
                        "ldlt_tflops_wall": n_fac * (N ** 3 / 3.0) / elapsed / 1e12 if elapsed > 0 else 0.0,
                        "instances_done": int(np.sum(g_done))},

@@ -199,6 +199,8 @@ typedef struct {
     double ldlt_flops, ldlt_seconds, trailing_seconds, solve_seconds, total_seconds;
     int64_t trailing_launches;
     int64_t kkt_order;       /* order of the matrices the LDL^T factorises (n + m, or the condensed order) */
+    int64_t lead_tiles;      /* leading 64-column tiles treated as mutually independent (options.kkt_tile_order) */
+    double trailing_flops_per_factor;   /* algorithmic flops of the k_trailing launches of one factorisation */
 } sqphip_counters;
 int sqphip_get_counters(sqphip_ctx *ctx, sqphip_counters *c);
 int sqphip_reset_counters(sqphip_ctx *ctx);

@@ -46,7 +46,8 @@ class Counters(C.Structure):
     _fields_ = [("n_qp", C.c_int64), ("n_ipm_iter", C.c_int64), ("n_factor", C.c_int64),
                 ("ldlt_flops", C.c_double), ("ldlt_seconds", C.c_double),
                 ("trailing_seconds", C.c_double), ("solve_seconds", C.c_double),
-                ("total_seconds", C.c_double), ("trailing_launches", C.c_int64), ("kkt_order", C.c_int64)]
+                ("total_seconds", C.c_double), ("trailing_launches", C.c_int64), ("kkt_order", C.c_int64),
+                ("lead_tiles", C.c_int64), ("trailing_flops_per_factor", C.c_double)]
 
 
 def lib():

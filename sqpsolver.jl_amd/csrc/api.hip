@@ -207,8 +207,9 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
         d.tol_infeas = opt->tol_infeas; d.init_mu = opt->init_mu; d.tr_size = opt->tr_size;
         d.max_iter = opt->max_iter; d.use_soc = opt->use_soc; d.literal_quirks = opt->literal_quirks;
         C.plan.N = d.Nf; C.plan.Npad = d.Fpad; C.plan.T = d.Fpad / 64; C.plan.ld = d.ld; C.plan.B = B;
+        C.plan.Ts = d.Ts;
         C.plan.stream = C.stream;
-        C.plan.Wbuf = C.dalloc<double>((size_t)2 * LdltPlan::MAX_R * B * d.Fpad * 64);
+        C.plan.Wbuf = C.dalloc<double>((size_t)std::max(2 * LdltPlan::MAX_R, d.Ts) * B * d.Fpad * 64);
         C.plan.init_lookahead();
         SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
         return SQPHIP_OK;
@@ -613,6 +614,8 @@ extern "C" int sqphip_get_counters(sqphip_ctx *h, sqphip_counters *c)
         c->n_qp = nqp; c->n_ipm_iter = nip; c->n_factor = nf;
         const double N = (double)C.d.Nf;
         c->kkt_order = C.d.Nf;
+        c->lead_tiles = C.d.Ts;
+        c->trailing_flops_per_factor = ldlt_trailing_flops(C.plan);
         c->ldlt_flops = (double)nf * N * N * N / 3.0;
         c->ldlt_seconds = C.tm.factor_seconds; c->trailing_seconds = C.tm.trailing_seconds;
         c->solve_seconds = C.tm.solve_seconds; c->total_seconds = C.total_seconds;

@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256) void k_diag_factor(double *__restrict__ K, lon
 {
     const int inst = blockIdx.x;
     if (phase && phase[inst] != want) return;
+    k += blockIdx.y;                 // grid (B, nk): the nk independent leading tile columns in one launch
     const int r = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double *A = K + (long)inst * strideK + (long)(k * 64) * ld + k * 64;   // tile origin
@@ -280,13 +281,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TB == 1 ? 4
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_panel_trsm_mfma(double *__restrict__ K, long strideK, int ld, const double *__restrict__ dinv,
                        double *__restrict__ Wbuf, int Npad, int k, int T, const int *__restrict__ phase, int want,
-                       double *__restrict__ bvec)
+                       double *__restrict__ bvec, int row0, long strideW)
 {
     const int inst = blockIdx.y;
     if (phase && phase[inst] != want) return;
+    // grid (., B, nk): nk independent leading tile columns in one launch, each with its own W slot; their row
+    // tiles start at row0 (the tiles between are structurally zero).  bvec must be null then: the fused
+    // elimination of different columns would race on the same rows (k_fwd_lead does it afterwards).
+    k += blockIdx.z; Wbuf += (long)blockIdx.z * strideW;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int l15 = lane & 15, l4 = lane >> 4;
-    const int i = k + 1 + blockIdx.x * 2 + (wave >> 1);   // this wave's row tile ...
+    const int i = row0 + blockIdx.x * 2 + (wave >> 1);    // this wave's row tile ...
     const int rh = (wave & 1) * 32;                       // ... and its half of the rows (2 x 16)
     double *Kb = K + (long)inst * strideK;
     const double *Lkk = Kb + (long)(k * 64) * ld + k * 64;
@@ -589,10 +594,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 __global__ __launch_bounds__(64) void k_fwd_step(const double *__restrict__ K, long strideK, int ld,
                                                 const double *__restrict__ dinv,
                                                 double *__restrict__ x, double *__restrict__ v,
-                                                int Npad, int k, const int *__restrict__ phase, int want)
+                                                int Npad, int k, const int *__restrict__ phase, int want, int lead)
 {
     const int inst = blockIdx.y;
     if (phase && phase[inst] != want) return;
+    // lead: grid (1, B, nk) -- the diagonal solves of the nk independent leading tile columns in one launch; y_k is
+    // also stored (into x) for k_fwd_lead; no other workgroup reads x_k in that launch
+    if (lead) k += blockIdx.z;
     const int i = k + blockIdx.x;
     const int r = threadIdx.x;
     const double *Kb = K + (long)inst * strideK;
@@ -610,6 +618,7 @@ __global__ __launch_bounds__(64) void k_fwd_step(const double *__restrict__ K, l
     }
     if (i == k) {
         v[(long)inst * Npad + k * 64 + r] = xr * dinv[(long)inst * Npad + k * 64 + r];
+        if (lead) xb[k * 64 + r] = xr;
         return;
     }
     ys[r] = xr;
@@ -621,6 +630,32 @@ __global__ __launch_bounds__(64) void k_fwd_step(const double *__restrict__ K, l
     xb[i * 64 + r] -= acc;
 }
 
+// forward elimination of the Ts independent leading tile columns on the rows below them, in one launch:
+// x_i -= sum_{k < Ts} L_ik y_k for tile row i >= Ts (y_k = x_k after the diagonal solves).  Wave w takes the tile
+// columns k = w (mod 4); lane r owns row r of the tile row.
+__global__ __launch_bounds__(256) void k_fwd_lead(const double *__restrict__ K, long strideK, int ld,
+                                                 double *__restrict__ x, int Npad, int Ts,
+                                                 const int *__restrict__ phase, int want)
+{
+    const int inst = blockIdx.y;
+    if (phase && phase[inst] != want) return;
+    const int i = Ts + blockIdx.x;
+    const int r = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const double *Kb = K + (long)inst * strideK;
+    double *xb = x + (long)inst * Npad;
+    __shared__ double part[4][64];
+    double acc = 0.0;
+    for (int k = w; k < Ts; k += 4) {
+        const double *Lik = Kb + (long)(k * 64) * ld + i * 64 + r;
+        const double *yk = xb + k * 64;
+#pragma unroll 8
+        for (int c = 0; c < 64; ++c) acc += Lik[(long)c * ld] * yk[c];
+    }
+    part[w][r] = acc;
+    __syncthreads();
+    if (w == 0) xb[i * 64 + r] -= (part[0][r] + part[1][r]) + (part[2][r] + part[3][r]);
+}
+
 // backward substitution L' x = v, step k (descending).  Workgroup j<=k re-solves the 64x64 unit-upper
 // system of tile (k,k)' (wave 0; the tile is staged transposed-readable in LDS by all four waves);
 // j==k publishes x_k, j<k updates v_j -= L_kj' x_k: tile (k,j) is fetched into registers during the
@@ -628,11 +663,13 @@ __global__ __launch_bounds__(64) void k_fwd_step(const double *__restrict__ K, l
 // the waves.
 __global__ __launch_bounds__(256) void k_bwd_step(const double *__restrict__ K, long strideK, int ld,
                                                  double *__restrict__ x, double *__restrict__ v,
-                                                 int Npad, int k, const int *__restrict__ phase, int want)
+                                                 int Npad, int k, const int *__restrict__ phase, int want, int lead)
 {
     const int inst = blockIdx.y;
     if (phase && phase[inst] != want) return;
-    const int j = blockIdx.x;
+    // lead: grid (1, B, nk) -- only the diagonal solves x_k = L_kk^-T v_k of the nk independent leading tile columns
+    if (lead) k += blockIdx.z;
+    const int j = lead ? k : blockIdx.x;
     const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
     const double *Kb = K + (long)inst * strideK;
     const double *Lkk = Kb + (long)(k * 64) * ld + k * 64;
@@ -724,7 +761,7 @@ static void launch_panel(const LdltPlan &P, hipStream_t s, double *K, double *di
     // longer steps of half as many workgroups hide less latency.
     if (P.trsm_mfma)
         hipLaunchKernelGGL(k_panel_trsm_mfma, dim3((rem + 1) / 2, P.B), dim3(256), 0, s, K, strideK, P.ld, dinv,
-                           P.Wbuf + (long)wslot * strideW, P.Npad, c, P.T, phase, want, b);
+                           P.Wbuf + (long)wslot * strideW, P.Npad, c, P.T, phase, want, b, c + 1, strideW);
     else
         hipLaunchKernelGGL(k_panel_trsm<1>, dim3(rem, P.B), dim3(256), 0, s, K, strideK, P.ld, dinv,
                            P.Wbuf + (long)wslot * strideW, P.Npad, c, P.T, phase, want, b);
@@ -740,12 +777,26 @@ static void launch_panel(const LdltPlan &P, hipStream_t s, double *K, double *di
 void ldlt_factor(const LdltPlan &P, double *K, double *dinv, const int *phase, int want, Timers *tm, double *b, double *v)
 {
     hipStream_t sA = P.stream, sB = P.aux ? P.aux : P.stream;
-    const int T = P.T, R = P.R;
-    const int nq = (T + R - 1) / R;
+    const int T = P.T, R = P.R, Ts = P.Ts;
+    const long strideK = (long)P.ld * P.Npad, strideW = (long)P.B * P.Npad * 64;
+    if (Ts > 0) {
+        // ---- the Ts leading tile columns are mutually independent (order.hip): the tiles between them are zero and
+        //      stay zero, so all diagonal tiles factor in one launch, all their panel solves (rows >= Ts only) in a
+        //      second, and one rank-64 Ts update brings the dense remainder up to date
+        hipLaunchKernelGGL(k_diag_factor, dim3(P.B, Ts), dim3(256), 0, sA, K, strideK, P.ld, dinv, P.Npad, 0, phase, want, b, v);
+        if (T > Ts) {
+            hipLaunchKernelGGL(k_panel_trsm_mfma, dim3((T - Ts + 1) / 2, P.B, Ts), dim3(256), 0, sA, K, strideK, P.ld,
+                               dinv, P.Wbuf, P.Npad, 0, T, phase, want, (double *)nullptr, Ts, strideW);
+            if (b)
+                hipLaunchKernelGGL(k_fwd_lead, dim3(T - Ts, P.B), dim3(256), 0, sA, K, strideK, P.ld, b, P.Npad, Ts, phase, want);
+            launch_update(P, sA, K, 0, Ts, 0, Ts, T, phase, want, tm, true);
+        }
+    }
+    const int nq = (T - Ts + R - 1) / R;
     hipEvent_t evStart = P.ev[0];
     if (sB != sA) { hipEventRecord(evStart, sA); hipStreamWaitEvent(sB, evStart, 0); }
     for (int q = 0; q < nq; ++q) {
-        const int c0 = R * q, slot = (q & 1) * LdltPlan::MAX_R;
+        const int c0 = Ts + R * q, slot = (q & 1) * LdltPlan::MAX_R;
         const int nsub = c0 + R <= T ? R : T - c0;
         hipEvent_t evPanel = P.ev[1 + (q & 1)], evHead = P.ev[3 + (q & 1)];
         // ---- stream B: factor the outer panel, sub-panel by sub-panel, left-looking inside the panel: tile
@@ -766,17 +817,48 @@ void ldlt_factor(const LdltPlan &P, double *K, double *dinv, const int *phase, i
     if (tm) tm->n_factor++;
 }
 
+// algorithmic flops of the k_trailing launches of one factorisation of one instance (what bench.py prices the
+// kernel's event time with): per launch the lower triangle (incl. diagonal) of the updated block -- r (r + 1) / 2
+// entries for r rows -- times 2 flops per multiply-add times the depth 64 nsub.  (The upper halves of the
+// diagonal tiles, which the kernel also computes, are not counted.)
+double ldlt_trailing_flops(const LdltPlan &P)
+{
+    const int T = P.T, R = P.R, Ts = P.Ts;
+    double f = 0.0;
+    auto tri = [](int tiles) { const double r = 64.0 * tiles; return r * (r + 1.0); };   // 2 * r (r + 1) / 2
+    if (Ts > 0 && T > Ts) f += tri(T - Ts) * 64.0 * Ts;
+    for (int c0 = Ts; c0 < T; c0 += R) {
+        const int nsub = c0 + R <= T ? R : T - c0;
+        if (c0 + nsub >= T) break;
+        f += tri(T - c0 - nsub) * 64.0 * nsub;
+    }
+    return f;
+}
+
 void ldlt_solve(const LdltPlan &P, const double *K, const double *dinv, double *x, double *v,
                 const int *phase, int want, bool skip_fwd)
 {
     const long strideK = (long)P.ld * P.Npad;
     hipStream_t s = P.stream;
-    for (int k = 0; k < P.T && !skip_fwd; ++k)
-        hipLaunchKernelGGL(k_fwd_step, dim3(P.T - k, P.B), dim3(64), 0, s, K, strideK, P.ld, dinv, x, v,
-                           P.Npad, k, phase, want);
-    for (int k = P.T - 1; k >= 0; --k)
+    const int Ts = P.Ts;
+    if (!skip_fwd) {
+        if (Ts > 0) {
+            hipLaunchKernelGGL(k_fwd_step, dim3(1, P.B, Ts), dim3(64), 0, s, K, strideK, P.ld, dinv, x, v, P.Npad, 0,
+                               phase, want, 1);
+            if (P.T > Ts)
+                hipLaunchKernelGGL(k_fwd_lead, dim3(P.T - Ts, P.B), dim3(256), 0, s, K, strideK, P.ld, x, P.Npad, Ts,
+                                   phase, want);
+        }
+        for (int k = Ts; k < P.T; ++k)
+            hipLaunchKernelGGL(k_fwd_step, dim3(P.T - k, P.B), dim3(64), 0, s, K, strideK, P.ld, dinv, x, v,
+                               P.Npad, k, phase, want, 0);
+    }
+    for (int k = P.T - 1; k >= Ts; --k)
         hipLaunchKernelGGL(k_bwd_step, dim3(k + 1, P.B), dim3(256), 0, s, K, strideK, P.ld, x, v, P.Npad, k,
-                           phase, want);
+                           phase, want, 0);
+    if (Ts > 0)
+        hipLaunchKernelGGL(k_bwd_step, dim3(1, P.B, Ts), dim3(256), 0, s, K, strideK, P.ld, x, v, P.Npad, 0,
+                           phase, want, 1);
 }
 
 }  // namespace sqphip

@@ -59,6 +59,7 @@ struct LdltPlan {
     hipEvent_t ev[6] = {};          // start, panel[2], head[2], join
     int trsm_mfma = 1;          // panel solve on the MFMA pipe, one wave per tile (SQPHIP_TRSM_MFMA=0: LDS substitution)
     int supertile = 8;          // tile columns per super-tile of the Schur-update schedule (SQPHIP_SUPERTILE; 1 = column-major)
+    int Ts = 0;                 // leading tile columns that are mutually independent (order.hip); 0 = plain dense
     int trail_pad = 0;          // extra dynamic LDS bytes per k_trailing workgroup (SQPHIP_TRAIL_PAD): caps its residency
     int kc = 16;                // k-columns per LDS stage of the Schur-update kernel (SQPHIP_KC = 16 | 32)
     int tpb_max = 1;            // longest run of tiles one Schur-update workgroup takes (SQPHIP_TPB): runs of 8
@@ -93,6 +94,7 @@ struct LdltPlan {
 // phase-filtered launches: kernels skip instances whose phase[inst] != want (phase may be null)
 void ldlt_factor(const LdltPlan &P, double *K, double *dinv, const int *phase, int want, Timers *tm,
                  double *b = nullptr, double *v = nullptr);
+double ldlt_trailing_flops(const LdltPlan &P);   // algorithmic flops of the k_trailing launches of one factorisation
 void ldlt_solve(const LdltPlan &P, const double *K, const double *dinv, double *x, double *v,
                 const int *phase, int want, bool skip_fwd = false);
 
