@@ -26,6 +26,7 @@ void ora_default_options(ora_options *o)
     o->num_threads = 1;
     o->ipm_corrector = 1;
     o->kkt_condense = 1;
+    o->kkt_tile_order = 1;
 }
 
 /* Julia's isapprox(a, b) with default rtol = sqrt(eps), atol = 0

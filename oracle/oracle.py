@@ -25,7 +25,7 @@ class Options(C.Structure):
                [("max_iter", C.c_int), ("use_soc", C.c_int), ("literal_quirks", C.c_int),
                 ("ipm_tol", C.c_double),
                 ("ipm_max_iter", C.c_int), ("ipm_phase1", C.c_int), ("num_threads", C.c_int),
-                ("ipm_corrector", C.c_int), ("kkt_condense", C.c_int)]
+                ("ipm_corrector", C.c_int), ("kkt_condense", C.c_int), ("kkt_tile_order", C.c_int)]
 
 
 class TraceRow(C.Structure):
@@ -137,6 +137,18 @@ def set_kkt_order(pos=None):
     L.ora_set_kkt_order(rank.ctypes.data_as(C.POINTER(C.c_int32)), len(rank))
 
 
+def _apply_order(opts, n, m, jrow1, jcol1, hrow1, hcol1, gL, gU):
+    """opts.kkt_tile_order: factorise in the product library's order.  The permutation comes from the library's
+    host-only, GPU-free `sqphip_kkt_order` (pure integer work on the sparsity pattern); every permutation gives the
+    same mathematics (tests/test_oracle_kat.py compares it with the natural order), following the product's one only
+    keeps the two implementations on one rounding trajectory."""
+    if not (opts.kkt_condense and opts.kkt_tile_order):
+        set_kkt_order(None); return
+    import sqpsolver_jl_amd as _pkg
+    pos, _, _ = _pkg.kkt_order(int(n), int(m), jrow1, jcol1, hrow1, hcol1, f64(gL), f64(gU))
+    set_kkt_order(pos)
+
+
 def default_options(**kw) -> Options:
     o = Options()
     lib().ora_default_options(C.byref(o))
@@ -241,6 +253,8 @@ def problem_acopf(net, lay):
 def sqp_solve(prob: Problem, opts: Options | None = None, x0=None, trace_cap: int = 4096):
     """Run the restated SqpTR.run! (sqp_trust_region.jl:98-223) and return everything."""
     opts = opts or default_options()
+    S = prob.structure()
+    _apply_order(opts, prob.n, prob.m, S["jrow"], S["jcol"], S["hrow"], S["hcol"], S["gL"], S["gU"])
     x = f64(prob.x0 if x0 is None else x0).copy()
     g = np.zeros(prob.m)
     mg = np.zeros(prob.m)
@@ -297,6 +311,8 @@ class QpSolver:
         self._keep = [np.ascontiguousarray(a, dtype=np.int64)
                       for a in (jcolptr, jrowval, hcolptr, hrowval)]
         jc, jr, hc, hr = self._keep
+        csc_cols = lambda ptr: np.repeat(np.arange(n, dtype=np.int64), np.diff(ptr))
+        _apply_order(self.opts, n, m, jr + 1, csc_cols(jc) + 1, hr + 1, csc_cols(hc) + 1, gL, gU)
         self.h = lib().ora_qp_create(n, m, num_linear, _l(jc), _l(jr), _l(hc), _l(hr),
                                      _d(f64(xL)), _d(f64(xU)), _d(f64(gL)), _d(f64(gU)),
                                      C.byref(self.opts))

@@ -65,6 +65,9 @@ typedef struct {
                           first inertia correction on; 0: monotone Fiacco-McCormick rule throughout */
     int kkt_condense;  /* 1: eliminate the rows with gL != gU (their block of the Newton matrix is the diagonal -D)
                           before factorising: dense LDL^T of order n + #equality rows instead of n + m */
+    int kkt_tile_order; /* 1: factorise the condensed matrix in the order the product library uses (its host-only
+                           sqphip_kkt_order), so that both sides stay on one trajectory; the permutation is handed in
+                           by oracle.py through ora_set_kkt_order -- the C code itself does not read this field */
 } ora_options;
 
 typedef double (*ora_eval_f_t)(void *ud, const double *x);

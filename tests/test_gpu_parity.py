@@ -300,9 +300,9 @@ def test_condensed_kkt_qp_modes_match_oracle():
     P = O.problem_acopf(net, lay); S = P.structure()
     for corrector in (1, 0):
         ctx = pkg.Context(lay.n, lay.m, lay.num_linear, lay.jrow, lay.jcol, lay.hrow, lay.hcol, lay.xL, lay.xU,
-                          lay.gL, lay.gU, pkg.default_options(ipm_corrector=corrector, kkt_condense=1))
+                          lay.gL, lay.gU, pkg.default_options(ipm_corrector=corrector, kkt_condense=1, kkt_tile_order=0))
         assert ctx.counters()["kkt_order"] == lay.n + int((lay.gL == lay.gU).sum()) < lay.n + lay.m
-        osolve = _oracle_qp(P, S, O.default_options(ipm_corrector=corrector, kkt_condense=1))
+        osolve = _oracle_qp(P, S, O.default_options(ipm_corrector=corrector, kkt_condense=1, kkt_tile_order=0))
         rng = np.random.default_rng(2)
         xr = np.clip(lay.x0 + 0.02 * rng.standard_normal(lay.n), lay.xL, lay.xU)
         for x, lam in ((lay.x0, np.zeros(lay.m)), (xr, 50 * rng.standard_normal(lay.m))):
@@ -454,7 +454,7 @@ def test_condensed_kkt_fixes_the_kept_rows_at_creation():
     mk = int((lay.gL == lay.gU).sum())
     for cond, order in ((1, lay.n + mk), (0, lay.n + lay.m)):
         ctx = pkg.Context(lay.n, lay.m, lay.num_linear, lay.jrow, lay.jcol, lay.hrow, lay.hcol, lay.xL, lay.xU,
-                          lay.gL, lay.gU, pkg.default_options(kkt_condense=cond), batch=2)
+                          lay.gL, lay.gU, pkg.default_options(kkt_condense=cond, kkt_tile_order=0), batch=2)
         assert ctx.counters()["kkt_order"] == order
         i = int(np.flatnonzero((lay.gL != lay.gU) & np.isfinite(lay.gU))[0])
         bad = dataclasses.replace(lay, gL=lay.gL.copy(), gU=lay.gU.copy())

@@ -334,3 +334,40 @@ def test_predictor_corrector_and_monotone_rule_agree_on_the_qp_solution():
                 if unique_p and r0["status"] == O.MOI_LOCALLY_SOLVED:
                     assert np.abs(r0["p"] - r1["p"]).max() <= 1e-7
     assert it[1] < 0.85 * it[0]
+
+
+def test_product_order_and_natural_order_of_the_condensed_matrix_agree():
+    """options.kkt_tile_order: the oracle factorises the condensed matrix in the order the product library reports
+    (independent leading tiles of variables, every kept row in the dense remainder).  Any symmetric permutation of a
+    quasi-definite matrix has an LDL^T and the same solution: whole SQP runs in both orders must coincide, and the
+    order itself must have the structure the factorisation relies on (no coupling between different leading tiles)."""
+    import sqpsolver_jl_amd as pkg
+    from sqpsolver_jl_amd.acopf_synth import acopf_synth, acopf_layout, CASES
+    nb, ng, nl, seed = CASES["case14"]
+    net = acopf_synth(nb, ng, nl, seed); lay = acopf_layout(net)
+    runs = [O.sqp_solve(O.problem_acopf(net, lay), O.default_options(max_iter=25, tol_infeas=1e-6, tol_residual=1e-4,
+                                                                     use_soc=1, literal_quirks=0, kkt_tile_order=t))
+            for t in (0, 1)]
+    assert runs[0]["status"] == runs[1]["status"] == 0 and runs[0]["iter"] == runs[1]["iter"]
+    assert runs[0]["n_factor"] == runs[1]["n_factor"]
+    assert np.abs(runs[0]["x"] - runs[1]["x"]).max() < 1e-10
+    for name in ("case14", "case118"):
+        nb, ng, nl, seed = CASES[name]
+        lay = acopf_layout(acopf_synth(nb, ng, nl, seed))
+        pos, ts, nf = pkg.kkt_order(lay.n, lay.m, lay.jrow, lay.jcol, lay.hrow, lay.hcol, lay.gL, lay.gU)
+        mk = int((lay.gL == lay.gU).sum())
+        assert len(pos) == lay.n + mk and len(set(pos.tolist())) == len(pos) and pos.max() == nf - 1
+        assert (pos[lay.n:] >= 64 * ts).all()                      # every kept row is in the dense remainder
+        tile = np.where(pos < 64 * ts, pos // 64, -1)              # leading tile of an unknown, -1 = remainder
+        # couplings between variables: Hessian entries and pairs of variables sharing an eliminated row
+        for r, c in zip(lay.hrow - 1, lay.hcol - 1):
+            assert tile[r] == tile[c] or tile[r] < 0 or tile[c] < 0
+        elim = np.flatnonzero(lay.gL != lay.gU)
+        rows = {}
+        for r, c in zip(lay.jrow - 1, lay.jcol - 1):
+            rows.setdefault(int(r), []).append(int(c))
+        for i in elim:
+            t = {int(tile[c]) for c in rows.get(int(i), [])} - {-1}
+            assert len(t) <= 1
+        if name == "case118":
+            assert ts == 17 and nf - 64 * ts == 1017               # 36 separator variables + 981 kept rows
