@@ -190,6 +190,8 @@ def main():
     cinfo = ctxs[0].counters()
     N = int(cinfo["kkt_order"])         # order of the factorised matrices (n + m, or the condensed order)
     N_full = lay0.n + lay0.m
+    N_c = lay0.n + int(np.sum(lay0.gL == lay0.gU))       # condensed order (before tile padding)
+    lead = int(cinfo["lead_tiles"])
     loc_fac = c1["n_factor"] - c0["n_factor"]
     tr_sec = c1["trailing_seconds"] - c0["trailing_seconds"]
     tr_launch = c1["trailing_launches"] - c0["trailing_launches"]
@@ -221,10 +223,12 @@ def main():
                                ipm_corrector=args.ipm_corrector, kkt_condense=int(opts.kkt_condense),
                                kkt_tile_order=int(opts.kkt_tile_order), **sqp_kw)
         ro = O.sqp_solve(O.problem_acopf(*nets[0]), oo)
+        N_cpu = lay0.n + (int(np.sum(lay0.gL == lay0.gU)) if int(opts.kkt_condense) else lay0.m)
         cpu = {"value": ro["n_qp"] / ro["qp_seconds"] if ro["qp_seconds"] > 0 else 0.0,
                "unit": "QP subproblems/s", "cores": cores, "kind": "port",
                "sample": f"{args.workload} scenario 0, first 6 SQP-TR iterations = {ro['n_qp']} sub-problems, "
-                         f"{ro['n_factor']} dense LDL^T of order {N}, {ro['qp_seconds']:.1f} s; CPU restatement "
+                         f"{ro['n_factor']} dense LDL^T of order {N_cpu} (plain dense, in the product's order), "
+                         f"{ro['qp_seconds']:.1f} s; CPU restatement "
                          f"(oracle/), not Julia/Ipopt"}
 
     if rank == 0:
@@ -243,14 +247,16 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{B} x IEEE-{nb}-bus-shaped ACOPF contingency scenarios per GPU "
                                    f"(BASELINE.json configs[3] shard), KKT order {N_full}"
-                                   + (f" condensed to {N}" if N != N_full else "") + ", dense fp64 LDL^T, SQP-TR outer iterations",
+                                   + (f" condensed to {N_c}" if int(opts.kkt_condense) else "")
+                                   + (f", ordered into {lead} independent leading tiles + a dense remainder of {N - 64 * lead}"
+                                      if lead else "") + ", fp64 LDL^T, SQP-TR outer iterations",
                        "instances_total": total, "kkt_order": N, "use_soc": use_soc, "sqp_options": args.sqp_options,
                        "groups_per_gpu": G,
                        "literal_quirks": args.literal_quirks, "ipm_corrector": args.ipm_corrector,
                        "kkt_condense": int(opts.kkt_condense), "kkt_order_full": N_full,
                        "kkt_tile_order": int(opts.kkt_tile_order), "independent_lead_tiles": int(cinfo["lead_tiles"]),
                        "qp_solved": n_qp, "ipm_iterations": n_ipm, "kkt_factorisations": n_fac,
-                       "ldlt_tflops_wall": n_fac * (N ** 3 / 3.0) / elapsed / 1e12 if elapsed > 0 else 0.0,
+                       "ldlt_dense_equivalent_tflops_wall": n_fac * ((N_c if int(opts.kkt_condense) else N_full) ** 3 / 3.0) / elapsed / 1e12 if elapsed > 0 else 0.0,
                        "instances_done": int(np.sum(g_done))},
             "roofline": {"bound": "mfma", "kernel": "k_trailing (v_mfma_f64_16x16x4_f64)",
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
