@@ -349,7 +349,15 @@ __global__ __launch_bounds__(128) void k_kkt_assemble(DV d)
     const int u = d.uinv[p];                     // unknown at this position: variable, kept row, or -1 = padding
     const IpmState &st = d.ist[inst];
     double *col = d.K + (long)inst * d.ld * d.Fpad + (long)p * d.ld;
-    for (int i = p + threadIdx.x; i < d.Fpad; i += 128) col[i] = 0.0;
+    // zero the column from the diagonal down; in a leading (independent) tile column the tiles between its own
+    // diagonal tile and the remainder are never written by anybody -- zeroed once at allocation, they stay zero
+    const int lead_end = 64 * d.Ts;
+    if (p < lead_end) {
+        for (int i = p + threadIdx.x; i < (p | 63) + 1; i += 128) col[i] = 0.0;
+        for (int i = lead_end + threadIdx.x; i < d.Fpad; i += 128) col[i] = 0.0;
+    } else {
+        for (int i = p + threadIdx.x; i < d.Fpad; i += 128) col[i] = 0.0;
+    }
     __syncthreads();
     if (threadIdx.x != 0) return;
     if (u < 0) { col[p] = 1.0; return; }
