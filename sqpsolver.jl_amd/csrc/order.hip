@@ -10,8 +10,9 @@
 // pivoting exists under every symmetric permutation (Vanderbei 1995) and the inertia test (n positive pivots) does
 // not depend on the order -- the quality of the heuristic only decides how much work is saved.
 //
-// Heuristic: while some component of the graph of S has more than 64 vertices, move its vertex of highest degree
-// (ties: lowest index) to R.  Components sorted by size (ties: lowest vertex) are packed first-fit into tiles;
+// Heuristic: while some component of the graph of S (variables only: rows_last) has more than 64 vertices, move its
+// vertex of highest degree (ties: lowest index) to R; then let every kept row whose variables all ended up in S
+// join their cluster if the merged cluster still fits a tile.  Components sorted by size (ties: lowest vertex) are packed first-fit into tiles;
 // inside a tile variables come before rows.
 #include "sqphip_internal.hpp"
 #include "../../include/sqphip.h"
@@ -55,6 +56,41 @@ KktOrder kkt_order_from_graph(int n, int nc, const std::vector<std::vector<int>>
             inS[best] = 0; changed = true;
         }
         if (!changed) break;
+    }
+    if (rows_last) {
+        // second pass: a kept row may follow its variables into their tile when ALL of them are in S and the
+        // clusters it ties together still fit one tile.  Inside a tile variables come before rows, so such a row is
+        // pivoted after every variable it couples to -- the property that makes the variables-first order safe --
+        // and it couples to nothing else but its own diagonal.
+        std::vector<int> root(comps.size()), csize(comps.size());
+        std::iota(root.begin(), root.end(), 0);
+        for (size_t c = 0; c < comps.size(); ++c) csize[c] = (int)comps[c].size();
+        auto find = [&](int a) { while (root[a] != a) { root[a] = root[root[a]]; a = root[a]; } return a; };
+        std::vector<int> rowroot(nc, -1), seen;
+        for (int u = n; u < nc; ++u) {
+            bool ok = !adj[u].empty();
+            seen.clear();
+            int tot = 1;
+            for (int v : adj[u]) {
+                if (!inS[v]) { ok = false; break; }
+                const int r = find(comp[v]);
+                if (std::find(seen.begin(), seen.end(), r) == seen.end()) { seen.push_back(r); tot += csize[r]; }
+            }
+            if (!ok || tot > 64) continue;
+            const int r0 = seen[0];
+            for (size_t k = 1; k < seen.size(); ++k) { root[seen[k]] = r0; }
+            csize[r0] = tot;
+            rowroot[u] = r0; inS[u] = 1;
+        }
+        // rebuild the component lists from the merged clusters
+        std::vector<std::vector<int>> merged(comps.size());
+        for (size_t c = 0; c < comps.size(); ++c) {
+            auto &dst = merged[find((int)c)];
+            dst.insert(dst.end(), comps[c].begin(), comps[c].end());
+        }
+        for (int u = n; u < nc; ++u) if (rowroot[u] >= 0) merged[find(rowroot[u])].push_back(u);
+        comps.clear();
+        for (auto &c : merged) if (!c.empty()) comps.push_back(std::move(c));
     }
     for (auto &c : comps) std::sort(c.begin(), c.end());
     std::sort(comps.begin(), comps.end(), [](const std::vector<int> &a, const std::vector<int> &b) {

@@ -357,7 +357,6 @@ def test_product_order_and_natural_order_of_the_condensed_matrix_agree():
         pos, ts, nf = pkg.kkt_order(lay.n, lay.m, lay.jrow, lay.jcol, lay.hrow, lay.hcol, lay.gL, lay.gU)
         mk = int((lay.gL == lay.gU).sum())
         assert len(pos) == lay.n + mk and len(set(pos.tolist())) == len(pos) and pos.max() == nf - 1
-        assert (pos[lay.n:] >= 64 * ts).all()                      # every kept row is in the dense remainder
         tile = np.where(pos < 64 * ts, pos // 64, -1)              # leading tile of an unknown, -1 = remainder
         # couplings between variables: Hessian entries and pairs of variables sharing an eliminated row
         for r, c in zip(lay.hrow - 1, lay.hcol - 1):
@@ -369,5 +368,16 @@ def test_product_order_and_natural_order_of_the_condensed_matrix_agree():
         for i in elim:
             t = {int(tile[c]) for c in rows.get(int(i), [])} - {-1}
             assert len(t) <= 1
+        # a kept row inside a leading tile has ALL its variables in that tile, at earlier positions (it is pivoted
+        # after everything it couples to, as in the variables-first order); the others are in the remainder
+        kept = np.flatnonzero(lay.gL == lay.gU)
+        inside = 0
+        for k, i in enumerate(kept):
+            u = lay.n + k
+            if tile[u] < 0:
+                continue
+            inside += 1
+            cols = rows.get(int(i), [])
+            assert cols and all(tile[c] == tile[u] and pos[c] < pos[u] for c in cols)
         if name == "case118":
-            assert ts == 17 and nf - 64 * ts == 1017               # 36 separator variables + 981 kept rows
+            assert inside == 292 and ts == 22 and nf - 64 * ts == 725   # 36 separator variables + 689 rows remain
