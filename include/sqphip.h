@@ -81,10 +81,13 @@ int sqphip_create(sqphip_ctx **ctx, int64_t n, int64_t m, int64_t num_linear,
                   const double *xL, const double *xU, const double *gL, const double *gU,
                   const sqphip_options *opt, int32_t batch);
 void sqphip_destroy(sqphip_ctx *ctx);
-/* Host-only (no GPU): the ordering options.kkt_order = 1 gives the condensed Newton matrix of this structure.
+/* Host-only (no GPU): the ordering options.kkt_tile_order = 1 gives the condensed Newton matrix of this structure.
  * pos[u], u < n + #(gL == gU): position of variable u (u < n) or of the (u - n)-th row with gL == gU in the
  * factorised matrix; the first n_lead_tiles 64-column tiles are mutually independent (block-diagonal leading block,
  * identity padding inside the tiles), the positions from 64 * n_lead_tiles to order - 1 are the dense remainder.
+ * rows_last = 1 is what the library uses: rows enter a leading tile only behind ALL the variables they couple to,
+ * everything else goes to the remainder.  rows_last = 0 lets rows and variables compete freely for the tiles
+ * (smaller remainder, but rows pivoted before their variables lose digits -- kept for experiments only).
  * Same COO conventions as sqphip_create. */
 int sqphip_kkt_order(int64_t n, int64_t m, int64_t nnzJ, const int64_t *jrow, const int64_t *jcol,
                      int64_t nnzH, const int64_t *hrow, const int64_t *hcol, const double *gL, const double *gU,
