@@ -26,6 +26,8 @@ namespace sqphip {
 KktOrder kkt_order_from_graph(int n, int nc, const std::vector<std::vector<int>> &adj, bool rows_last)
 {
     std::vector<char> inS(nc, 1);
+    // largest cluster of the first pass (experiment switch; rows joining in the second pass may fill it up to 64)
+    const int varcap = getenv("SQPHIP_ORDER_VARCAP") ? std::max(1, std::min(64, atoi(getenv("SQPHIP_ORDER_VARCAP")))) : 64;
     if (rows_last) for (int u = n; u < nc; ++u) inS[u] = 0;     // every kept row goes to the dense remainder
     std::vector<int> comp(nc), deg(nc), stack;
     std::vector<std::vector<int>> comps;
@@ -46,7 +48,7 @@ KktOrder kkt_order_from_graph(int n, int nc, const std::vector<std::vector<int>>
         }
         bool changed = false;
         for (auto &c : comps) {
-            if ((int)c.size() <= 64) continue;
+            if ((int)c.size() <= varcap) continue;
             int best = -1, bestdeg = -1;
             for (int u : c) {
                 int d = 0;
@@ -130,7 +132,8 @@ KktOrder kkt_order(int n, int m, const std::vector<int> &kpos, int mk, const std
     for (int i = 0; i < m; ++i) {
         const int s = jrowptr[i], e = jrowptr[i + 1];
         if (kpos[i] >= 0) { for (int t = s; t < e; ++t) edge(n + kpos[i], jrcol[t]); }
-        else for (int a = s; a < e; ++a) for (int b = a + 1; b < e; ++b) edge(jrcol[a], jrcol[b]);
+        else if (e - s <= 32) { for (int a = s; a < e; ++a) for (int b = a + 1; b < e; ++b) edge(jrcol[a], jrcol[b]); }
+        else for (int a = s; a + 1 < e; ++a) edge(jrcol[a], jrcol[a + 1]);   // long row: a chain ties the same cluster
     }
     for (auto &l : adj) { std::sort(l.begin(), l.end()); l.erase(std::unique(l.begin(), l.end()), l.end()); }
     return kkt_order_from_graph(n, nc, adj, rows_last);
