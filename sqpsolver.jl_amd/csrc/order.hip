@@ -10,7 +10,7 @@
 // pivoting exists under every symmetric permutation (Vanderbei 1995) and the inertia test (n positive pivots) does
 // not depend on the order -- the quality of the heuristic only decides how much work is saved.
 //
-// Heuristic: while some component of the graph of S (variables only: rows_last) has more than 64 vertices, move its
+// Heuristic: while some component of the graph of S (variables only: rows_last) has more than 32 vertices, move its
 // vertex of highest degree (ties: lowest index) to R; then let every kept row whose variables all ended up in S
 // join their cluster if the merged cluster still fits a tile.  Components sorted by size (ties: lowest vertex) are packed first-fit into tiles;
 // inside a tile variables come before rows.
@@ -26,8 +26,10 @@ namespace sqphip {
 KktOrder kkt_order_from_graph(int n, int nc, const std::vector<std::vector<int>> &adj, bool rows_last)
 {
     std::vector<char> inS(nc, 1);
-    // largest cluster of the first pass (experiment switch; rows joining in the second pass may fill it up to 64)
-    const int varcap = getenv("SQPHIP_ORDER_VARCAP") ? std::max(1, std::min(64, atoi(getenv("SQPHIP_ORDER_VARCAP")))) : 64;
+    // largest cluster of variables in the first pass: half a tile, so that the rows joining in the second pass (which
+    // may fill a cluster up to 64) find room.  Measured on the IEEE-118 shape: 64 / 40 / 32 / 24 / 16 -> dense
+    // remainder 725 / 685 / 673 / 652 / 671 and 478 / 511 / 532 / 502 / 505 QP/s (SQPHIP_ORDER_VARCAP overrides).
+    const int varcap = getenv("SQPHIP_ORDER_VARCAP") ? std::max(1, std::min(64, atoi(getenv("SQPHIP_ORDER_VARCAP")))) : 32;
     if (rows_last) for (int u = n; u < nc; ++u) inS[u] = 0;     // every kept row goes to the dense remainder
     std::vector<int> comp(nc), deg(nc), stack;
     std::vector<std::vector<int>> comps;
