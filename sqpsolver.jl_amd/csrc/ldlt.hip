@@ -26,6 +26,16 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 // group on disjoint bank halves
 __device__ __forceinline__ int swz(int k, int i) { return k * 64 + (i ^ ((k & 1) << 4)); }
 
+// value of lane `lane` (a compile-time constant after unrolling) in every lane: two v_readlane_b32 into scalar
+// registers -- no trip through the LDS crossbar as with __shfl / ds_bpermute.  For the substitution chains of the
+// triangular solves, where the broadcast IS the critical path.
+__device__ __forceinline__ double bcast_lane(double x, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
+
 // ---------------------------------------------------------------------------------------------
 // tile (k,k): unblocked right-looking LDL^T by one 256-thread workgroup.  Thread (r, W) = (tid & 63,
 // tid >> 6) owns row r of the tile restricted to the columns c = W (mod 4): 16 entries in registers.
@@ -613,7 +623,7 @@ __global__ __launch_bounds__(64) void k_fwd_step(const double *__restrict__ K, l
     double xr = xb[k * 64 + r];
 #pragma unroll
     for (int j = 0; j < 63; ++j) {
-        const double yj = __shfl(xr, j);
+        const double yj = bcast_lane(xr, j);
         if (r > j) xr -= lrow[j] * yj;
     }
     if (i == k) {
@@ -689,8 +699,9 @@ __global__ __launch_bounds__(256) void k_bwd_step(const double *__restrict__ K, 
     __syncthreads();
     if (w == 0) {
         double xc = vb[k * 64 + c];
+#pragma unroll
         for (int rr = 63; rr > 0; --rr) {
-            const double xr = __shfl(xc, rr);
+            const double xr = bcast_lane(xc, rr);
             if (c < rr) xc -= tile[c * 65 + rr] * xr;
         }
         if (j == k) x[(long)inst * Npad + k * 64 + c] = xc;
