@@ -226,6 +226,7 @@ extern "C" int sqphip_ldlt_stress(int32_t device, int32_t batch, int64_t N, int3
         std::vector<int> hp(batch);
         int bad_reps = 0;
         hipStream_t aux = S.P.aux;
+        S.P.lookahead_min = 0;         // this hook compares the two schedules whatever the matrix size
         for (int rep = 0; rep < reps; ++rep) {
             unsigned r = 12345u + 7919u * rep;
             for (int b = 0; b < batch; ++b) { r = r * 1664525u + 1013904223u; hp[b] = ((r >> 16) % 4) ? 1 : 0; }

@@ -787,8 +787,8 @@ static void launch_panel(const LdltPlan &P, hipStream_t s, double *K, double *di
 // so that the first solve after a factorisation is ldlt_solve(..., skip_fwd = true).
 void ldlt_factor(const LdltPlan &P, double *K, double *dinv, const int *phase, int want, Timers *tm, double *b, double *v)
 {
-    hipStream_t sA = P.stream, sB = P.aux ? P.aux : P.stream;
     const int T = P.T, R = P.R, Ts = P.Ts;
+    hipStream_t sA = P.stream, sB = (P.aux && T - Ts >= P.lookahead_min) ? P.aux : P.stream;
     const long strideK = (long)P.ld * P.Npad, strideW = (long)P.B * P.Npad * 64;
     if (Ts > 0) {
         // ---- the Ts leading tile columns are mutually independent (order.hip): the tiles between them are zero and

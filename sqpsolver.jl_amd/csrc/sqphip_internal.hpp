@@ -60,6 +60,9 @@ struct LdltPlan {
     int trsm_mfma = 1;          // panel solve on the MFMA pipe, one wave per tile (SQPHIP_TRSM_MFMA=0: LDS substitution)
     int supertile = 8;          // tile columns per super-tile of the Schur-update schedule (SQPHIP_SUPERTILE; 1 = column-major)
     int Ts = 0;                 // leading tile columns that are mutually independent (order.hip); 0 = plain dense
+    int lookahead_min = 24;     // the look-ahead stream is used when the dense chain has at least this many tile
+                                // columns (SQPHIP_LOOKAHEAD_MIN): +6 % QP/s at 44 columns, nothing at 33, -2.8 % at the
+                                // 11 of the tile-ordered IEEE-118 matrices (events and a second queue for nothing)
     int trail_pad = 0;          // extra dynamic LDS bytes per k_trailing workgroup (SQPHIP_TRAIL_PAD): caps its residency
     int kc = 16;                // k-columns per LDS stage of the Schur-update kernel (SQPHIP_KC = 16 | 32)
     int tpb_max = 1;            // longest run of tiles one Schur-update workgroup takes (SQPHIP_TPB): runs of 8
@@ -75,6 +78,7 @@ struct LdltPlan {
             if (getenv("SQPHIP_NO_PRIORITY")) greatest = least;
             hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, greatest);
         }
+        if (const char *e = getenv("SQPHIP_LOOKAHEAD_MIN")) lookahead_min = atoi(e);
         if (const char *e = getenv("SQPHIP_OUTER")) { R = atoi(e); if (R < 1) R = 1; if (R > MAX_R) R = MAX_R; }
         if (const char *e = getenv("SQPHIP_TRSM_MFMA")) trsm_mfma = atoi(e);
         if (const char *e = getenv("SQPHIP_SUPERTILE")) { supertile = atoi(e); if (supertile < 1) supertile = 1; }
