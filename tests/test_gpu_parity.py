@@ -445,6 +445,39 @@ def test_tile_ordered_kkt_matches_oracle():
             O.set_kkt_order(None)
 
 
+def test_case118_sqp_first_iterations_match_oracle():
+    """The bench workload itself (IEEE-118 shape, the example's SQP options, the reference's Hessian sign, every
+    default of the linear algebra: condensed, 22 independent leading tiles + dense remainder): the first three outer
+    iterations of the base case and of one contingency against the oracle -- every accept / reject / restoration
+    decision and sub-problem status equal, iterates at the truncated-trajectory tolerance, interior-point iteration
+    counts within two per sub-problem: at this size the last iterations of a solve sit within a factor of a few of
+    the tolerance and the acceptable-termination counters (8 iterates within 100 x tol) tip on rounding -- the
+    oracle run against itself with a refinement step after every solve (ORA_REFINE_TOL=0) moves the same counts
+    by one or two (20/21, 29/28, 14/16, 22/21; scripts/gpu_c118_compare.py)."""
+    nb, ng, nl, seed = CASES["case118"]
+    base = acopf_synth(nb, ng, nl, seed)
+    nets = [base, contingency(base, 7, seed)]
+    lays = [acopf_layout(nt) for nt in nets]
+    kw = dict(max_iter=3, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=1)
+    ctx = pkg.Context(lays[0].n, lays[0].m, lays[0].num_linear, lays[0].jrow, lays[0].jcol, lays[0].hrow, lays[0].hcol,
+                      lays[0].xL, lays[0].xU, lays[0].gL, lays[0].gU, pkg.default_options(**kw), batch=2)
+    c = ctx.counters()
+    assert c["lead_tiles"] == 22 and c["kkt_order"] == 2081
+    ctx.acopf_attach(base, lays[0])
+    for b in range(2):
+        ctx.acopf_set_instance(b, nets[b], lays[b])
+    ctx.sqp_reset(); ctx.sqp_run(0)
+    for b in range(2):
+        ro = O.sqp_solve(O.problem_acopf(nets[b], lays[b]), O.default_options(num_threads=host_threads(), **kw))
+        rg = ctx.sqp_get(b); tr = ctx.sqp_trace(b)
+        assert (rg["status"], rg["iter"]) == (ro["status"], ro["iter"])
+        assert [(a["iter"], a["accepted"], a["fr"], a["sub_status"]) for a in ro["trace"]] == \
+               [(t["iter"], t["accepted"], t["fr"], t["sub_status"]) for t in tr]
+        assert all(abs(a["ipm_iters"] - t["ipm_iters"]) <= 2 for a, t in zip(ro["trace"], tr))
+        assert rel(rg["x"], ro["x"]) < TOL_TRAJ and abs(rg["obj_val"] - ro["obj_val"]) <= TOL_TRAJ * abs(ro["obj_val"])
+    ctx.close()
+
+
 def test_condensed_kkt_fixes_the_kept_rows_at_creation():
     """The condensed order is n + #(gL == gU) of the creation bounds and is reported by the counters; per-instance
     bounds may move the equality values (contingency loads do) but may not create an equality among the
