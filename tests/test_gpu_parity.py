@@ -478,6 +478,24 @@ def test_case118_sqp_first_iterations_match_oracle():
     ctx.close()
 
 
+@pytest.mark.parametrize("name", ["hs035", "hs076"])
+def test_published_qp_optima_on_the_device(name):
+    """Hock & Schittkowski problems 35 and 76 (convex QPs, published optima) through `sqphip_qp_solve`: p = x*, the
+    optimal value and the multipliers in the JuMP sign, under every combination of the linear-algebra options."""
+    from hs_qps import HS_QPS, structure
+    q = HS_QPS[name]; S = structure(q)
+    n, m = S["n"], S["m"]
+    for kw in (dict(), dict(kkt_tile_order=0), dict(kkt_condense=0), dict(ipm_corrector=0)):
+        ctx = pkg.Context(n, m, m, S["jrow"], S["jcol"], S["hrow"], S["hcol"], q["xL"], q["xU"], q["gL"], q["gU"],
+                          pkg.default_options(**kw))
+        r = ctx.qp_solve(O.MODE_QP, np.zeros(n), 1e3, 1.0, q["c"], np.zeros(m), S["jval"], S["hval"])
+        assert r["status"] == O.MOI_LOCALLY_SOLVED
+        assert np.abs(r["p"] - q["x"]).max() < 1e-7
+        assert abs(q["f0"] + q["c"] @ r["p"] + 0.5 * r["p"] @ q["H"] @ r["p"] - q["f"]) < 1e-8
+        assert np.abs(r["lam"] - q["lam"]).max() < 1e-6
+        ctx.close()
+
+
 def test_condensed_kkt_fixes_the_kept_rows_at_creation():
     """The condensed order is n + #(gL == gU) of the creation bounds and is reported by the counters; per-instance
     bounds may move the equality values (contingency loads do) but may not create an equality among the

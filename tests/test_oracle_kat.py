@@ -381,3 +381,24 @@ def test_product_order_and_natural_order_of_the_condensed_matrix_agree():
             assert cols and all(tile[c] == tile[u] and pos[c] < pos[u] for c in cols)
         if name == "case118":
             assert inside == 354 and ts == 22 and nf - 64 * ts == 673   # 46 separator variables + 627 rows remain
+
+
+@pytest.mark.parametrize("name", ["hs035", "hs076"])
+def test_published_qp_optima_through_the_subproblem_seat(name):
+    """Hock & Schittkowski problems 35 and 76 are convex QPs with published optima: one MODE_QP solve at x_k = 0 with a
+    wide trust region must return p = x*, the optimal value and the row multipliers (JuMP sign) -- under every
+    combination of the linear-algebra options."""
+    from hs_qps import HS_QPS, structure
+    q = HS_QPS[name]; S = structure(q)
+    n, m = S["n"], S["m"]
+    jcp, jrv, jslot, _ = O.coo_to_csc(n, S["jrow"], S["jcol"])
+    hcp, hrv, hslot, hslot_t = O.coo_to_csc(n, S["hrow"], S["hcol"], sym=True)
+    jv = np.zeros(len(jrv)); np.add.at(jv, jslot, S["jval"])
+    hv = np.zeros(len(hrv)); np.add.at(hv, hslot, S["hval"]); ok = hslot_t >= 0; np.add.at(hv, hslot_t[ok], S["hval"][ok])
+    for kw in (dict(), dict(kkt_tile_order=0), dict(kkt_condense=0), dict(ipm_corrector=0)):
+        qs = O.QpSolver(n, m, m, jcp, jrv, hcp, hrv, q["xL"], q["xU"], q["gL"], q["gU"], O.default_options(**kw))
+        r = qs.solve(O.MODE_QP, np.zeros(n), 1e3, 1.0, q["c"], np.zeros(m), jv, hv)
+        assert r["status"] == O.MOI_LOCALLY_SOLVED
+        assert np.abs(r["p"] - q["x"]).max() < 1e-7
+        assert abs(q["f0"] + q["c"] @ r["p"] + 0.5 * r["p"] @ q["H"] @ r["p"] - q["f"]) < 1e-8
+        assert np.abs(r["lam"] - q["lam"]).max() < 1e-6
