@@ -29,28 +29,6 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet fp64 matrix peak; MI355X_MICRO
                                # register-resident MFMA probe (printed next to it) sustains 77.6 of it.
 
 
-def outer_width() -> int:
-    """Sub-panels per outer panel used by the library (LdltPlan::R, sqphip_internal.hpp)."""
-    return max(1, min(4, int(os.environ.get("SQPHIP_OUTER", "4"))))
-
-
-def trailing_alg_flops(N: int, R: int | None = None) -> float:
-    """Algorithmic flops of the k_trailing launches that bench.py times, for one LDL^T of order N:
-    outer panels of R 64-wide sub-panels (ldlt.hip, ldlt_factor); after an outer panel the lower
-    triangle (incl. diagonal) of the matrix right of the panel receives a rank-64R update, 2 flops per
-    multiply-add.  (The rank-64 updates inside an outer panel run on the look-ahead stream and are
-    neither timed nor counted.)  N = 2813: 6.46 (R = 4, the default) or 6.95 (R = 2) of the 7.42 GFLOP of N^3/3."""
-    R = R or outer_width()
-    T = (N + 63) // 64
-    tot = 0.0
-    for c0 in range(0, T, R):
-        nsub = min(R, T - c0)
-        r = (T - c0 - nsub) * 64
-        if r > 0:
-            tot += r * (r + 1) * 64.0 * nsub
-    return tot
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
