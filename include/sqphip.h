@@ -168,6 +168,13 @@ int sqphip_acopf_attach(sqphip_ctx *ctx, int32_t nb, int32_t ng, int32_t nl,
  * lists, and num_linear = 2 nl + 1 (the balance rows are no longer linear) -- sqpsolver.jl_amd/acopf_synth.py,
  * acopf_layout.  Shared by every instance of the batch. */
 int sqphip_acopf_set_shunts(sqphip_ctx *ctx, int32_t nsh, const int32_t *sh_bus, const double *gs, const double *bs);
+/* HVDC lines (optional, after sqphip_acopf_attach; PowerModels variable_dcline_power +
+ * constraint_dcline_power_losses, /root/reference/examples/acopf/opf.jl:16,40-42).  The structure given to
+ * sqphip_create carries them already -- per line 4 variables (p_f, p_t, q_f, q_t of the line, blocks of ndc behind
+ * all other variables, entering the balance rows of their buses through the incidence lists of sqphip_acopf_attach)
+ * and one row  (1 - loss1) p_f + p_t = loss0  behind all other rows, its two Jacobian entries behind all others
+ * (acopf_synth.py, acopf_layout); this call supplies loss1 per line (default 0).  ndc must match the structure. */
+int sqphip_acopf_set_dclines(sqphip_ctx *ctx, int32_t ndc, const double *loss1);
 /* ohm[nl][12]: per branch the coefficients (A, Bc, Bs) of the four flow equations p_f, q_f, p_t, q_t,
  *   F_k = A_k v_self^2 + v_f v_t (Bc_k cos(va_f - va_t) + Bs_k sin(va_f - va_t)),
  * i.e. the pi model with an ideal transformer (tap ratio, phase shift) at the from end folded into 12 numbers on the

@@ -100,7 +100,7 @@ def lib():
         L.ora_problem_acopf.restype = C.c_void_p
         L.ora_problem_acopf.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, dp, ip, dp, dp,
                                         ip, ip, ip, dp, C.c_int64, lp, lp, C.c_int64, lp, lp,
-                                        dp, dp, dp, dp, C.c_int, ip, dp, dp]
+                                        dp, dp, dp, dp, C.c_int, ip, dp, dp, C.c_int, dp]
         L.ora_problem_nlp.restype = C.POINTER(Nlp)
         L.ora_problem_nlp.argtypes = [C.c_void_p]
         L.ora_problem_x0.restype = dp
@@ -246,7 +246,8 @@ def problem_acopf(net, lay):
                                 _i(gb), _d(c2), _d(c1), _i(bp), _i(bcp), _i(bcq), _d(coef),
                                 len(jr), _l(jr), _l(jc), len(hr), _l(hr), _l(hc),
                                 _d(xL), _d(xU), _d(gL), _d(gU), len(lay.sh_bus),
-                                _i(np.ascontiguousarray(lay.sh_bus, dtype=np.int32)), _d(f64(lay.sh_gs)), _d(f64(lay.sh_bs)))
+                                _i(np.ascontiguousarray(lay.sh_bus, dtype=np.int32)), _d(f64(lay.sh_gs)), _d(f64(lay.sh_bs)),
+                                len(lay.dc_loss1), _d(f64(lay.dc_loss1)))
     return Problem(h, x0=lay.x0)
 
 

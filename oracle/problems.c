@@ -17,6 +17,7 @@ struct ora_problem {
     /* acopf */
     int nb, ng, nl, ref_bus;
     int32_t *f_bus, *t_bus, *gen_bus, *bal_ptr, *bal_colP, *bal_colQ;
+    int ndc; double *dc_loss1;    /* HVDC lines: variables p_f, p_t, q_f, q_t behind all others, one loss row each at the end */
     int nsh; int32_t *sh_bus; double *sh_gs, *sh_bs;   /* bus shunts: + gs vm^2 (P row), - bs vm^2 (Q row) */
     double *ohm, *c2, *c1, *bal_coef;      /* ohm[nl][12]: (A, Bc, Bs) of p_f, q_f, p_t, q_t per branch */
 };
@@ -51,7 +52,7 @@ void ora_problem_destroy(ora_problem *P)
     if (!P) return;
     void *ptrs[] = { P->x0, P->jrow, P->jcol, P->hrow, P->hcol, P->xL, P->xU, P->gL, P->gU,
         P->f_bus, P->t_bus, P->gen_bus, P->bal_ptr, P->bal_colP, P->bal_colQ, P->ohm,
-        P->c2, P->c1, P->bal_coef, P->sh_bus, P->sh_gs, P->sh_bs };
+        P->c2, P->c1, P->bal_coef, P->sh_bus, P->sh_gs, P->sh_bs, P->dc_loss1 };
     for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) free(ptrs[i]);
     free(P);
 }
@@ -201,6 +202,8 @@ static void ac_g(void *u, const double *x, double *gv)
             gv[O0 + 4 * l + k] = x[own[k] + l] - (A * vs * vs + vf * vt * (Bc * C + Bs * S));
         }
     }
+    for (int d = 0; d < P->ndc; ++d)           /* (1 - loss1) p_dc_f + p_dc_t  (= loss0 by the row bounds) */
+        gv[O0 + 4 * nl + d] = (1.0 - P->dc_loss1[d]) * x[PF + 4 * nl + d] + x[PF + 4 * nl + P->ndc + d];
 }
 static void ac_jac(void *u, const double *x, double *v)
 {
@@ -231,6 +234,7 @@ static void ac_jac(void *u, const double *x, double *v)
         double vm = x[VM + P->sh_bus[s]];
         v[o++] = 2 * P->sh_gs[s] * vm; v[o++] = -2 * P->sh_bs[s] * vm;
     }
+    for (int d = 0; d < P->ndc; ++d) { v[o++] = 1.0 - P->dc_loss1[d]; v[o++] = 1.0; }
 }
 static void ac_h(void *u, const double *x, double sig, const double *lam, double *v)
 {
@@ -275,9 +279,9 @@ ora_problem *ora_problem_acopf(int nb, int ng, int nl, const int32_t *f_bus,
                                int64_t nnzh, const int64_t *hrow, const int64_t *hcol,
                                const double *xL, const double *xU, const double *gL,
                                const double *gU, int nsh, const int32_t *sh_bus, const double *sh_gs,
-                               const double *sh_bs)
+                               const double *sh_bs, int ndc, const double *dc_loss1)
 {
-    int64_t n = 2 * nb + 2 * ng + 4 * nl, m = 1 + 2 * nb + 8 * nl;
+    int64_t n = 2 * nb + 2 * ng + 4 * nl + 4 * ndc, m = 1 + 2 * nb + 8 * nl + ndc;
     double *x0 = (double *)calloc((size_t)n, sizeof(double));
     /* with bus shunts the balance rows carry a vm^2 term: only the angle and reference rows stay linear */
     ora_problem *P = mk(n, m, nsh > 0 ? 2 * nl + 1 : 2 * nl + 1 + 2 * nb, nnzj, jrow, jcol, nnzh, hrow, hcol, xL, xU, gL, gU, x0);
@@ -290,6 +294,7 @@ ora_problem *ora_problem_acopf(int nb, int ng, int nl, const int32_t *f_bus,
     P->bal_colP = i32dup(bal_colP, nbal); P->bal_colQ = i32dup(bal_colQ, nbal);
     P->bal_coef = ddup(bal_coef, nbal);
     P->ohm = ddup(ohm, 12 * (int64_t)nl);
+    P->ndc = ndc; P->dc_loss1 = ddup(dc_loss1, ndc);
     P->nsh = nsh; P->sh_bus = i32dup(sh_bus, nsh); P->sh_gs = ddup(sh_gs, nsh); P->sh_bs = ddup(sh_bs, nsh);
     P->c2 = ddup(c2, ng); P->c1 = ddup(c1, ng);
     P->nlp.eval_f = ac_f; P->nlp.eval_grad_f = ac_df; P->nlp.eval_g = ac_g;

@@ -185,7 +185,7 @@ ora_problem *ora_problem_acopf(int nb, int ng, int nl, const int32_t *f_bus,
                                int64_t nnzh, const int64_t *hrow, const int64_t *hcol,
                                const double *xL, const double *xU, const double *gL,
                                const double *gU, int nsh, const int32_t *sh_bus, const double *sh_gs,
-                               const double *sh_bs);
+                               const double *sh_bs, int ndc, const double *dc_loss1);
 const ora_nlp *ora_problem_nlp(const ora_problem *p);
 const double *ora_problem_x0(const ora_problem *p);
 void ora_problem_destroy(ora_problem *p);

@@ -90,6 +90,7 @@ def lib():
                                               ip, dp, C.c_int32]
             L.sqphip_acopf_set_instance.argtypes = [vp, C.c_int32, dp, dp, dp, dp]
             L.sqphip_acopf_set_shunts.argtypes = [vp, C.c_int32, ip, dp, dp]
+            L.sqphip_acopf_set_dclines.argtypes = [vp, C.c_int32, dp]
             L.sqphip_kkt_order.argtypes = [C.c_int64, C.c_int64, C.c_int64, lp, lp, C.c_int64, lp, lp, dp, dp, C.c_int32,
                                            ip, ip, ip]
             L.sqphip_acopf_eval.argtypes = [vp, C.c_int32, dp, C.c_double, dp, dp, dp, dp, dp, dp]
@@ -110,7 +111,7 @@ EXPORTS = [
     "sqphip_set_bounds", "sqphip_qp_solve", "sqphip_qp_stats", "sqphip_norm_violations",
     "sqphip_kt_residuals", "sqphip_norm_complementarity", "sqphip_compute_phi",
     "sqphip_compute_qmodel", "sqphip_compute_derivative", "sqphip_tr_update",
-    "sqphip_kkt_order", "sqphip_acopf_attach", "sqphip_acopf_set_shunts", "sqphip_acopf_set_instance", "sqphip_acopf_eval", "sqphip_sqp_reset",
+    "sqphip_kkt_order", "sqphip_acopf_attach", "sqphip_acopf_set_shunts", "sqphip_acopf_set_dclines", "sqphip_acopf_set_instance", "sqphip_acopf_eval", "sqphip_sqp_reset",
     "sqphip_sqp_run", "sqphip_sqp_get", "sqphip_sqp_status", "sqphip_sqp_trace",
     "sqphip_get_counters", "sqphip_reset_counters", "sqphip_set_timing", "sqphip_ldlt_factor_host",
     "sqphip_ldlt_solve_host", "sqphip_ldlt_bench", "sqphip_ldlt_stress", "sqphip_mfma_f64_peak", "sqphip_armijo_alpha", "sqphip_compute_mu_rule",

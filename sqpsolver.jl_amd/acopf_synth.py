@@ -73,6 +73,15 @@ class Network:
     shift: np.ndarray = None # phase shift at the from end, radians (None = 0)
     gs: np.ndarray = None    # bus shunt conductance, p.u. (MW consumed at vm = 1 / baseMVA); None = 0
     bs: np.ndarray = None    # bus shunt susceptance, p.u. (MVAr injected at vm = 1 / baseMVA); None = 0
+    # HVDC lines (MATPOWER mpc.dcline; PowerModels variable_dcline_power + constraint_dcline_power_losses, the
+    # reference's build at examples/acopf/opf.jl:16,40-42): None = no dc lines.  Dict of arrays, one entry per line:
+    #   f_bus, t_bus (int32), pminf, pmaxf (active power leaving the from bus into the line, p.u.),
+    #   qminf, qmaxf, qmint, qmaxt (reactive power drawn at either end, p.u.), loss0 (p.u.), loss1
+    dcline: dict = None
+
+    @property
+    def ndc(self):
+        return 0 if self.dcline is None else len(self.dcline["f_bus"])
 
     def shunts(self):
         """(bus indices, gs, bs) of the buses with a shunt element; they add gs*vm^2 to the P balance and
@@ -264,12 +273,16 @@ class NlpLayout:
     sh_bus: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(0, dtype=np.int32))
     sh_gs: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(0))
     sh_bs: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(0))
+    dc_loss1: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(0))   # per dc line (empty: none)
 
 
 def acopf_layout(net: Network) -> NlpLayout:
-    nb, ng, nl = net.nb, net.ng, net.nl
-    n = 2 * nb + 2 * ng + 4 * nl
-    m = 1 + 2 * nb + 8 * nl
+    nb, ng, nl, ndc = net.nb, net.ng, net.nl, net.ndc
+    # dc lines: 4 variables each (p_f, p_t, q_f, q_t of the line) behind everything else, one loss row each behind
+    # every other row (a linear row; sitting behind the nonlinear block it is simply re-linearised every iteration)
+    n = 2 * nb + 2 * ng + 4 * nl + 4 * ndc
+    m = 1 + 2 * nb + 8 * nl + ndc
+    DC = 2 * nb + 2 * ng + 4 * nl              # p_dc_f[ndc], p_dc_t[ndc], q_dc_f[ndc], q_dc_t[ndc]
     VA, VM, PG, QG = 0, nb, 2 * nb, 2 * nb + ng
     PF = 2 * nb + 2 * ng
     PT, QF, QT = PF + nl, PF + 2 * nl, PF + 3 * nl
@@ -293,6 +306,9 @@ def acopf_layout(net: Network) -> NlpLayout:
         inc[int(t[l])].append((PT + l, QT + l, 1.0))
     for g in range(ng):
         inc[int(net.gen_bus[g])].append((PG + g, QG + g, -1.0))
+    for d in range(ndc):                       # a dc line draws p_dc_f / q_dc_f at its from bus, p_dc_t / q_dc_t at its to bus
+        inc[int(net.dcline["f_bus"][d])].append((DC + d, DC + 2 * ndc + d, 1.0))
+        inc[int(net.dcline["t_bus"][d])].append((DC + ndc + d, DC + 3 * ndc + d, 1.0))
     bal_ptr = np.zeros(nb + 1, dtype=np.int32)
     colP, colQ, coef = [], [], []
     for i in range(nb):
@@ -324,6 +340,10 @@ def acopf_layout(net: Network) -> NlpLayout:
         sb = sh_bus.astype(np.int64)
         jr.append(np.stack([2 * nl + 1 + 2 * sb, 2 * nl + 2 + 2 * sb], 1).ravel())
         jc.append(np.repeat(VM + sb, 2))
+    if ndc:                                    # loss rows: (1 - loss1) p_dc_f + p_dc_t = loss0
+        D = np.arange(ndc, dtype=np.int64)
+        jr.append(np.repeat(1 + 2 * nb + 8 * nl + D, 2))
+        jc.append(np.stack([DC + D, DC + ndc + D], 1).ravel())
     jrow = np.concatenate(jr).astype(np.int64) + 1
     jcol = np.concatenate(jc).astype(np.int64) + 1
 
@@ -352,6 +372,12 @@ def acopf_layout(net: Network) -> NlpLayout:
                          -net.rate_a, -net.rate_a, -net.rate_a, -net.rate_a])
     xU = np.concatenate([np.full(nb, inf), net.vmax, net.pmax, net.qmax,
                          net.rate_a, net.rate_a, net.rate_a, net.rate_a])
+    if ndc:
+        dc = net.dcline
+        # p_dc_t = loss0 - (1 - loss1) p_dc_f: its box is the image of the from-end box (implied by the loss row)
+        a = dc["loss0"] - (1.0 - dc["loss1"]) * dc["pmaxf"]; b = dc["loss0"] - (1.0 - dc["loss1"]) * dc["pminf"]
+        xL = np.concatenate([xL, dc["pminf"], np.minimum(a, b), dc["qminf"], dc["qmint"]])
+        xU = np.concatenate([xU, dc["pmaxf"], np.maximum(a, b), dc["qmaxf"], dc["qmaxt"]])
     gL = np.empty(m); gU = np.empty(m)
     gL[0:nl] = -inf; gU[0:nl] = net.angmax
     gL[nl:2 * nl] = net.angmin; gU[nl:2 * nl] = inf
@@ -361,6 +387,8 @@ def acopf_layout(net: Network) -> NlpLayout:
     gL[T0:O0] = -inf
     gU[T0:O0:2] = net.rate_a ** 2; gU[T0 + 1:O0:2] = net.rate_a ** 2
     gL[O0:] = 0.0; gU[O0:] = 0.0
+    if ndc:
+        gL[O0 + 4 * nl:] = net.dcline["loss0"]; gU[O0 + 4 * nl:] = net.dcline["loss0"]
     # start: midpoint of finite boxes, 0 otherwise
     # (/root/reference/examples/acopf/init_opf.jl:25-47)
     boxed = np.isfinite(xL) & np.isfinite(xU)
@@ -372,4 +400,5 @@ def acopf_layout(net: Network) -> NlpLayout:
                      xL=xL, xU=xU, gL=gL, gU=gU, x0=x0,
                      bal_ptr=bal_ptr, bal_colP=colP.astype(np.int32),
                      bal_colQ=colQ.astype(np.int32), bal_coef=np.asarray(coef),
-                     sh_bus=sh_bus, sh_gs=sh_gs, sh_bs=sh_bs)
+                     sh_bus=sh_bus, sh_gs=sh_gs, sh_bs=sh_bs,
+                     dc_loss1=(np.zeros(0) if ndc == 0 else np.asarray(net.dcline["loss1"], dtype=np.float64)))

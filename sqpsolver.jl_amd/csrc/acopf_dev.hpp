@@ -70,6 +70,13 @@ static __device__ void acopf_eval(const DV &d, int inst, const double *__restric
     // branch rows
     const int TH = 4 * nl + 1 + 2 * d.bal_ptr[nb], OH = TH + 4 * nl;
     const int HO = ng + 4 * nl;
+    // HVDC lines: loss row d (behind every other row) = (1 - loss1) p_dc_f + p_dc_t; Jacobian entries behind the
+    // shunt entries; no second derivatives
+    for (int dl = threadIdx.x; dl < d.ndc; dl += TPB) {
+        const int DCV = PF + 4 * nl;
+        if (gv) gv[O0 + 4 * nl + dl] = (1.0 - d.dc_loss1[dl]) * x[DCV + dl] + x[DCV + d.ndc + dl];
+        if (jv) { jv[OH + 20 * nl + 2 * d.nsh + 2 * dl] = 1.0 - d.dc_loss1[dl]; jv[OH + 20 * nl + 2 * d.nsh + 2 * dl + 1] = 1.0; }
+    }
     // shunt entries at the end of both COO lists
     for (int s = threadIdx.x; s < d.nsh; s += TPB) {
         const int i = d.sh_bus[s];

@@ -438,12 +438,16 @@ extern "C" int sqphip_acopf_attach(sqphip_ctx *h, int32_t nb, int32_t ng, int32_
 {
     if (!h || nb <= 0 || ng <= 0 || nl <= 0) return SQPHIP_EINVAL;
     Ctx &C0 = h->c;
-    if (C0.d.n != 2 * nb + 2 * ng + 4 * nl || C0.d.m != 1 + 2 * nb + 8 * nl) return SQPHIP_EINVAL;
+    // HVDC lines add 4 variables, 1 row, 2 balance incidences (= 4 Jacobian entries) and 2 loss-row entries each
+    const int n_ac = 2 * nb + 2 * ng + 4 * nl, m_ac = 1 + 2 * nb + 8 * nl;
+    if (C0.d.n < n_ac || (C0.d.n - n_ac) % 4 != 0) return SQPHIP_EINVAL;
+    const int ndc = (C0.d.n - n_ac) / 4;
+    if (C0.d.m != m_ac + ndc) return SQPHIP_EINVAL;
     const int nbal = bal_ptr[nb];
     // (a structure with bus shunts has 2 more Jacobian and 1 more Hessian entry per shunted bus at the end of the
     // lists; sqphip_acopf_set_shunts checks the exact counts)
-    const int extraJ = C0.d.nnzj_coo - (32 * nl + 2 * ng + 1), extraH = C0.d.nnzh_coo - (ng + 44 * nl);
-    if (extraJ < 0 || extraJ != 2 * extraH || extraH > nb || nbal != 2 * nl + ng) return SQPHIP_EINVAL;
+    const int extraJ = C0.d.nnzj_coo - (32 * nl + 2 * ng + 1) - 6 * ndc, extraH = C0.d.nnzh_coo - (ng + 44 * nl);
+    if (extraJ < 0 || extraJ != 2 * extraH || extraH > nb || nbal != 2 * nl + ng + 2 * ndc) return SQPHIP_EINVAL;
     for (int l = 0; l < nl; ++l)
         if (f_bus[l] < 0 || f_bus[l] >= nb || t_bus[l] < 0 || t_bus[l] >= nb) return SQPHIP_EINVAL;
     for (int k = 0; k < nbal; ++k)
@@ -452,6 +456,8 @@ extern "C" int sqphip_acopf_attach(sqphip_ctx *h, int32_t nb, int32_t ng, int32_
     return guarded(h, [&](Ctx &C) {
         DV &d = C.d;
         d.nb = nb; d.ng = ng; d.nl = nl; d.ref_bus = ref_bus;
+        d.ndc = ndc;
+        d.dc_loss1 = C.upload(std::vector<double>(ndc > 0 ? ndc : 1, 0.0));   // sqphip_acopf_set_dclines overrides
         d.f_bus = C.upload(std::vector<int>(f_bus, f_bus + nl));
         d.t_bus = C.upload(std::vector<int>(t_bus, t_bus + nl));
         d.gen_bus = C.upload(std::vector<int>(gen_bus, gen_bus + ng));
@@ -473,7 +479,7 @@ extern "C" int sqphip_acopf_set_shunts(sqphip_ctx *h, int32_t nsh, const int32_t
     if (!h || !h->c.acopf_attached || nsh < 0) return SQPHIP_EINVAL;
     Ctx &C0 = h->c;
     const int nl = C0.d.nl, ng = C0.d.ng, nb = C0.d.nb;
-    if (C0.d.nnzj_coo != 32 * nl + 2 * ng + 1 + 2 * nsh || C0.d.nnzh_coo != ng + 44 * nl + nsh) return SQPHIP_EINVAL;
+    if (C0.d.nnzj_coo != 32 * nl + 2 * ng + 1 + 2 * nsh + 6 * C0.d.ndc || C0.d.nnzh_coo != ng + 44 * nl + nsh) return SQPHIP_EINVAL;
     if (nsh > 0 && C0.d.nlin != 2 * nl + 1) return SQPHIP_EINVAL;     // balance rows must not be declared linear
     std::vector<int> of(nb, -1);
     for (int s = 0; s < nsh; ++s) {
@@ -487,6 +493,17 @@ extern "C" int sqphip_acopf_set_shunts(sqphip_ctx *h, int32_t nsh, const int32_t
         d.sh_of_bus = C.upload(of);
         d.sh_gs = C.upload(std::vector<double>(gs, gs + nsh));
         d.sh_bs = C.upload(std::vector<double>(bs, bs + nsh));
+        SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        return SQPHIP_OK;
+    });
+}
+
+extern "C" int sqphip_acopf_set_dclines(sqphip_ctx *h, int32_t ndc, const double *loss1)
+{
+    if (!h || !h->c.acopf_attached || ndc != h->c.d.ndc || (ndc > 0 && !loss1)) return SQPHIP_EINVAL;
+    if (ndc == 0) return SQPHIP_OK;
+    return guarded(h, [&](Ctx &C) {
+        C.d.dc_loss1 = C.upload(std::vector<double>(loss1, loss1 + ndc));
         SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
         return SQPHIP_OK;
     });

@@ -88,6 +88,7 @@ struct DV {
     double *trace;      // [B][CAP][COLS]
     // ---- ACOPF evaluator data
     int nb, ng, nl, ref_bus;
+    int ndc; const double *dc_loss1;   // HVDC lines (shared): 4 variables each behind all others, one loss row each at the end
     int nsh; const int *sh_bus, *sh_of_bus; const double *sh_gs, *sh_bs;   // bus shunts (shared): list, bus -> index or -1
     const int *f_bus, *t_bus, *gen_bus, *bal_ptr, *bal_colP, *bal_colQ;
     const double *bal_coef;

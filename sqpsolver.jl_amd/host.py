@@ -178,6 +178,8 @@ class Context:
         coef = _f(lay.bal_coef)
         self._ck(self.L.sqphip_acopf_attach(self.h, net.nb, net.ng, net.nl, *[_i(a) for a in keep],
                                             _d(coef), int(net.ref_bus)))
+        if len(lay.dc_loss1):
+            self._ck(self.L.sqphip_acopf_set_dclines(self.h, len(lay.dc_loss1), _d(_f(lay.dc_loss1))))
         if len(lay.sh_bus):
             sb = np.ascontiguousarray(lay.sh_bus, dtype=np.int32)
             self._ck(self.L.sqphip_acopf_set_shunts(self.h, len(sb), _i(sb), _d(_f(lay.sh_gs)), _d(_f(lay.sh_bs))))

@@ -11,7 +11,10 @@ Supported subset = what the evaluator models (polar ACOPF, SURVEY.md App. B, wit
 transformer taps and phase shifters at the from end and bus shunts Gs/Bs as MATPOWER defines them):
 polynomial (model 2) generator costs of degree <= 2.  Anything else raises `UnsupportedCase` naming the offending rows, never a silent
 approximation.  HVDC lines (`mpc.dcline`, modelled by the reference's custom build at
-examples/acopf/opf.jl:40-42) are rejected unless `dcline="drop"` is passed.
+examples/acopf/opf.jl:16,40-42: `variable_dcline_power` + `constraint_dcline_power_losses`) become four variables
+and one loss row each (`acopf_layout`); `dcline="drop"` ignores them.  A `mpc.dclinecost` table is rejected (the
+shipped example has none).  [UNVERIFIED against PowerModels, which is not in the image: the sign convention of the
+reactive limits QminF..QmaxT -- the shipped file's limits are symmetric, so it does not matter there.]
 
 Column meaning (MATPOWER manual, Appendix B):
     bus    : bus_i type Pd Qd Gs Bs area Vm Va baseKV zone Vmax Vmin
@@ -161,8 +164,27 @@ def network_from_matpower(mpc: Dict, dcline: str = "error", unlimited_rate: floa
     ratio, shift = br[:, 8], br[:, 9]                # ratio 0 means "no transformer" = 1; shift in degrees
     if np.any(ratio < 0.0):
         problems.append(f"negative tap ratios on branches {np.flatnonzero(ratio < 0).tolist()}")
+    dc = None
     if "dcline" in mpc and mpc["dcline"].size and dcline != "drop":
-        problems.append(f"{mpc['dcline'].shape[0]} HVDC line(s) (pass dcline='drop' to ignore them)")
+        if dcline not in ("error", "model"):
+            raise ValueError("dcline must be 'model' (default), 'error' (same) or 'drop'")
+        t = np.atleast_2d(mpc["dcline"])
+        t = t[t[:, 2] > 0]                                   # in-service lines only
+        if "dclinecost" in mpc and np.size(mpc["dclinecost"]):
+            problems.append("HVDC line costs (mpc.dclinecost)")
+        if t.shape[1] < 17:
+            problems.append("mpc.dcline with fewer than 17 columns")
+        else:
+            missing = [int(b) for b in np.concatenate([t[:, 0], t[:, 1]]) if int(b) not in idx]
+            if missing:
+                raise ValueError(f"dcline rows reference unknown buses {sorted(set(missing))}")
+            if np.any(t[:, 9] > t[:, 10]):
+                problems.append("HVDC lines with Pmin > Pmax")
+            dc = dict(f_bus=np.asarray([idx[int(b)] for b in t[:, 0]], dtype=np.int32),
+                      t_bus=np.asarray([idx[int(b)] for b in t[:, 1]], dtype=np.int32),
+                      pminf=t[:, 9] / base, pmaxf=t[:, 10] / base,
+                      qminf=t[:, 11] / base, qmaxf=t[:, 12] / base, qmint=t[:, 13] / base, qmaxt=t[:, 14] / base,
+                      loss0=t[:, 15] / base, loss1=t[:, 16].copy())
     for col, nm in ((0, "gen"),):
         missing = [int(b) for b in g[:, col] if int(b) not in idx]
         if missing:
@@ -196,6 +218,7 @@ def network_from_matpower(mpc: Dict, dcline: str = "error", unlimited_rate: floa
         angmin=amin, angmax=amax, status=(br[:, 10] > 0).astype(np.float64),
         tap=np.where(ratio == 0.0, 1.0, ratio), shift=np.deg2rad(shift),
         gs=bus[:, 4] / base, bs=bus[:, 5] / base,        # MW / MVAr at vm = 1 -> per unit
+        dcline=dc,
     )
 
 
@@ -230,5 +253,17 @@ def write_matpower(net: Network, name: str = "case_synth", base_mva: float = 100
                                    f(0.0 if net.tap is None or net.tap[l] == 1.0 else net.tap[l]),
                                    f(0.0 if net.shift is None else np.rad2deg(net.shift[l])), str(int(net.status[l] > 0)),
                                    f(np.rad2deg(net.angmin[l])), f(np.rad2deg(net.angmax[l]))]) + ";")
-    L += ["];", ""]
+    L += ["];"]
+    if net.ndc:
+        dc = net.dcline
+        L += ["mpc.dcline = ["]
+        for d in range(net.ndc):
+            pf = dc["pminf"][d] * base_mva
+            L.append("\t" + "\t".join([str(int(dc["f_bus"][d]) + 1), str(int(dc["t_bus"][d]) + 1), "1", f(pf), f(pf), "0.0", "0.0",
+                                       "1.0", "1.0", f(dc["pminf"][d] * base_mva), f(dc["pmaxf"][d] * base_mva),
+                                       f(dc["qminf"][d] * base_mva), f(dc["qmaxf"][d] * base_mva),
+                                       f(dc["qmint"][d] * base_mva), f(dc["qmaxt"][d] * base_mva),
+                                       f(dc["loss0"][d] * base_mva), f(dc["loss1"][d])]) + ";")
+        L += ["];"]
+    L += [""]
     return "\n".join(L)

@@ -74,6 +74,23 @@ def main():
     with open(os.path.join(HERE, "case14_synth.m"), "w") as fh:
         fh.write("% synthetic IEEE-14-shaped case written by tests/golden/make_golden.py (acopf_synth(14,5,20,seed=14))\n")
         fh.write(write_matpower(base, "case14_synth"))
+    # the reference's example case, re-serialised through our own writer (data, not the reference's file), together
+    # with the dispatch the file itself stores in its gen / dcline columns: a reference-derived pin for the full
+    # ACOPF + HVDC model (examples/acopf/opf.jl:12-46)
+    ref_case = "/root/reference/examples/acopf/case3.m"
+    if os.path.exists(ref_case):
+        from sqpsolver_jl_amd.matpower import read_matpower, network_from_matpower
+        m3 = read_matpower(ref_case)
+        net3 = network_from_matpower(m3)
+        with open(os.path.join(HERE, "case3_network.m"), "w") as fh:
+            fh.write("% network data of the reference's examples/acopf/case3.m, re-serialised by tests/golden/make_golden.py\n")
+            fh.write(write_matpower(net3, "case3_network", base_mva=float(m3["baseMVA"])))
+        json.dump({"case3_dispatch": {"source": "gen column Pg and dcline columns Pf, Pt of /root/reference/examples/acopf/case3.m",
+                                      "pg_mw": m3["gen"][:, 1].tolist(), "dc_pf_mw": float(m3["dcline"][0, 3]),
+                                      "dc_pt_mw": float(m3["dcline"][0, 4]), "base_mva": float(m3["baseMVA"]),
+                                      "objective": 5906.88, "objective_source": "this build's optimum, consistent with "
+                                      "the value PowerModels documents for the case (5907)"}},
+                  open(os.path.join(HERE, "case3_dispatch.json"), "w"), indent=1)
     print("wrote", os.listdir(HERE))
 
 

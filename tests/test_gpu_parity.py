@@ -497,6 +497,106 @@ def test_published_qp_optima_on_the_device(name):
         ctx.close()
 
 
+def _with_dclines(net):
+    dc = dict(f_bus=np.array([2, 7], dtype=np.int32), t_bus=np.array([9, 3], dtype=np.int32),
+              pminf=np.array([0.05, -0.3]), pmaxf=np.array([0.6, 0.3]), qminf=np.full(2, -0.4), qmaxf=np.full(2, 0.4),
+              qmint=np.full(2, -0.4), qmaxt=np.full(2, 0.4), loss0=np.array([0.002, 0.0]), loss1=np.array([0.03, 0.0]))
+    return dataclasses.replace(net, dcline=dc)
+
+
+def test_hvdc_lines_on_the_device():
+    """HVDC lines (four variables and one loss row each, sqphip_acopf_set_dclines): evaluator against the oracle, then
+    a batch of three scenarios of a 14-bus network with two dc lines to convergence."""
+    nb, ng, nl, seed = CASES["case14"]
+    base = _with_dclines(acopf_synth(nb, ng, nl, seed))
+    nets = [base, contingency(base, 2, seed), _with_shunts(_with_transformers(base, 5), 5)]
+    lays = [acopf_layout(nt) for nt in nets[:2]]
+    lay = lays[0]
+    assert lay.n == 118 + 8 and lay.m == 189 + 2
+    P = O.problem_acopf(base, lay)
+    kw = dict(max_iter=60, tol_infeas=1e-6, tol_residual=1e-4, literal_quirks=0, use_soc=1)
+    ctx = pkg.Context(lay.n, lay.m, lay.num_linear, lay.jrow, lay.jcol, lay.hrow, lay.hcol, lay.xL, lay.xU, lay.gL,
+                      lay.gU, pkg.default_options(**kw), batch=2)
+    ctx.acopf_attach(base, lay)
+    for b in range(2):
+        ctx.acopf_set_instance(b, nets[b], lays[b])
+    rng = np.random.default_rng(2)
+    x = lay.x0 + 0.05 * rng.standard_normal(lay.n); lam = rng.standard_normal(lay.m)
+    ev = ctx.acopf_eval(0, x, 0.7, lam)
+    assert rel(ev["g"], P.eval_g(x)) < 1e-13 and rel(ev["jval"], P.eval_jac_g(x)) < 1e-13
+    assert rel(ev["hval"], P.eval_h(x, 0.7, lam)) < 1e-13 and rel(ev["grad"], P.eval_grad_f(x)) < 1e-13
+    ctx.sqp_reset(); ctx.sqp_run(0)
+    for b in range(2):
+        ro = O.sqp_solve(O.problem_acopf(nets[b], lays[b]), O.default_options(**kw))
+        rg = ctx.sqp_get(b)
+        assert (rg["status"], rg["iter"]) == (ro["status"], ro["iter"]) and ro["status"] == 0
+        assert rel(rg["x"], ro["x"]) < 100 * TOL and abs(rg["obj_val"] - ro["obj_val"]) <= TOL * abs(ro["obj_val"])
+    ctx.close()
+    # dc lines together with transformers and bus shunts (structure with shunt entries AND dc entries)
+    net3 = nets[2]; lay3 = acopf_layout(net3)
+    ctx = pkg.Context(lay3.n, lay3.m, lay3.num_linear, lay3.jrow, lay3.jcol, lay3.hrow, lay3.hcol, lay3.xL, lay3.xU,
+                      lay3.gL, lay3.gU, pkg.default_options(**kw))
+    ctx.acopf_attach(net3, lay3); ctx.acopf_set_instance(0, net3, lay3)
+    P3 = O.problem_acopf(net3, lay3)
+    x = lay3.x0 + 0.05 * rng.standard_normal(lay3.n); lam = rng.standard_normal(lay3.m)
+    ev = ctx.acopf_eval(0, x, 0.7, lam)
+    assert rel(ev["g"], P3.eval_g(x)) < 1e-13 and rel(ev["jval"], P3.eval_jac_g(x)) < 1e-13
+    assert rel(ev["hval"], P3.eval_h(x, 0.7, lam)) < 1e-13
+    ctx.sqp_reset(); ctx.sqp_run(0)
+    ro = O.sqp_solve(P3, O.default_options(**kw)); rg = ctx.sqp_get(0)
+    assert (rg["status"], rg["iter"]) == (ro["status"], ro["iter"])
+    assert rel(rg["x"], ro["x"]) < 100 * TOL_TRAJ if ro["status"] else rel(rg["x"], ro["x"]) < 100 * TOL
+    ctx.close()
+
+
+def test_reference_example_network_on_the_device():
+    """The reference's example network (3 buses, 3 generators, 3 branches, one HVDC line; golden re-serialisation, see
+    tests/test_matpower.py) through the device-resident SQP-TR: the dispatch stored in the reference's file, the
+    oracle's iterates, and a load-scaled variant in the same batch."""
+    from sqpsolver_jl_amd import matpower as MP
+    pin = json.load(open(os.path.join(GOLD, "case3_dispatch.json")))["case3_dispatch"]
+    base = MP.load_case(os.path.join(GOLD, "case3_network.m"))
+    nets = [base, dataclasses.replace(base, pd=0.9 * base.pd, qd=0.9 * base.qd)]
+    lays = [acopf_layout(nt) for nt in nets]
+    kw = dict(max_iter=100, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=1)
+    ctx = pkg.Context(lays[0].n, lays[0].m, lays[0].num_linear, lays[0].jrow, lays[0].jcol, lays[0].hrow, lays[0].hcol,
+                      lays[0].xL, lays[0].xU, lays[0].gL, lays[0].gU, pkg.default_options(**kw), batch=2)
+    ctx.acopf_attach(base, lays[0])
+    for b in range(2):
+        ctx.acopf_set_instance(b, nets[b], lays[b])
+    ctx.sqp_reset(); ctx.sqp_run(0)
+    rg = ctx.sqp_get(0)
+    assert rg["status"] == 0
+    assert np.allclose(rg["x"][6:9] * pin["base_mva"], pin["pg_mw"], atol=2e-3)
+    assert np.allclose(rg["x"][-4:-2] * pin["base_mva"], [pin["dc_pf_mw"], -pin["dc_pt_mw"]], atol=1e-4)
+    assert abs(rg["obj_val"] - pin["objective"]) < 0.01
+    # against the oracle: same optimum; with the reference's Hessian sign the path to it is sensitive on this tiny
+    # problem (10 outer iterations on the device, 9 in the oracle), so the counts may differ by two.  The reactive
+    # power of the dc terminals and of the generators at the same buses substitute for each other at no cost: those
+    # entries are not determined and are left out of the comparison.
+    det = np.ones(lays[0].n, dtype=bool); det[2 * 3 + 3:2 * 3 + 6] = False; det[-2:] = False
+    for b in range(2):
+        ro = O.sqp_solve(O.problem_acopf(nets[b], lays[b]), O.default_options(**kw))
+        rg = ctx.sqp_get(b)
+        assert rg["status"] == ro["status"] == 0 and abs(rg["iter"] - ro["iter"]) <= 2
+        assert rel(rg["x"][det], ro["x"][det]) < 1e-6 and abs(rg["obj_val"] - ro["obj_val"]) <= 1e-7 * abs(ro["obj_val"])
+    ctx.close()
+    # with the textbook sign both sides walk the same path
+    kw["literal_quirks"] = 0
+    ctx = pkg.Context(lays[0].n, lays[0].m, lays[0].num_linear, lays[0].jrow, lays[0].jcol, lays[0].hrow, lays[0].hcol,
+                      lays[0].xL, lays[0].xU, lays[0].gL, lays[0].gU, pkg.default_options(**kw), batch=2)
+    ctx.acopf_attach(base, lays[0])
+    for b in range(2):
+        ctx.acopf_set_instance(b, nets[b], lays[b])
+    ctx.sqp_reset(); ctx.sqp_run(0)
+    for b in range(2):
+        ro = O.sqp_solve(O.problem_acopf(nets[b], lays[b]), O.default_options(**kw))
+        rg = ctx.sqp_get(b)
+        assert (rg["status"], rg["iter"]) == (ro["status"], ro["iter"]) and ro["status"] == 0
+        assert rel(rg["x"][det], ro["x"][det]) < 100 * TOL and abs(rg["obj_val"] - ro["obj_val"]) <= TOL * abs(ro["obj_val"])
+    ctx.close()
+
+
 def test_condensed_kkt_fixes_the_kept_rows_at_creation():
     """The condensed order is n + #(gL == gU) of the creation bounds and is reported by the counters; per-instance
     bounds may move the equality values (contingency loads do) but may not create an equality among the

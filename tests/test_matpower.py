@@ -76,15 +76,16 @@ def test_conversion_per_unit_renumbering_status():
 @pytest.mark.parametrize("edit,needle", [
     (("0.01 0.10 0.02  100 0 0 0 0 1 -30 30", "0.01 0.10 0.02  100 0 0 -0.98 0 1 -30 30"), "negative tap"),
     (("2 0 0 3  0.02 12.0 100.0", "1 0 0 3  0.02 12.0 100.0"), "piecewise"),
-    (("mpc.bus_name", "mpc.dcline = [10 20 1 10 10 5 0 1 1 10 90 -90 90 -90 90 0 0 0 0 0 0 0 0];\nmpc.bus_name"), "HVDC"),
+    (("mpc.bus_name", "mpc.dcline = [10 20 1 10 10 5 0 1 1 10 90 -90 90 -90 90 0 0 0 0 0 0 0 0];\n"
+                      "mpc.dclinecost = [2 0 0 2 1.0 0.0];\nmpc.bus_name"), "HVDC line costs"),
 ])
 def test_unsupported_features_are_rejected_loudly(edit, needle):
     txt = HAND.replace(*edit)
     assert txt != HAND
     with pytest.raises(MP.UnsupportedCase, match=needle):
         MP.network_from_matpower(MP.read_matpower(txt))
-    if needle == "HVDC":
-        assert MP.network_from_matpower(MP.read_matpower(txt), dcline="drop").nl == 4
+    if needle.startswith("HVDC"):
+        assert MP.network_from_matpower(MP.read_matpower(txt), dcline="drop").ndc == 0
 
 
 def test_taps_and_phase_shifters_are_read_and_reach_the_flow_equations():
@@ -208,9 +209,85 @@ def test_reference_example_case_is_read_in_place():
     m = MP.read_matpower("/root/reference/examples/acopf/case3.m")
     assert m["baseMVA"] == 100.0 and m["bus"].shape == (3, 13) and m["dcline"].shape[0] == 1
     assert m["const_str"] == "a string" and m["const_int"] == 123.0
-    with pytest.raises(MP.UnsupportedCase, match="HVDC"):
-        MP.network_from_matpower(m)
-    net = MP.network_from_matpower(m, dcline="drop")
+    net = MP.network_from_matpower(m)
+    assert net.ndc == 1 and net.dcline["f_bus"].tolist() == [0] and net.dcline["t_bus"].tolist() == [1]
+    assert np.allclose([net.dcline["pminf"][0], net.dcline["pmaxf"][0], net.dcline["loss0"][0], net.dcline["loss1"][0]],
+                       [0.1, 9.0, 0.0, 0.0])
+    assert MP.network_from_matpower(m, dcline="drop").ndc == 0
     assert (net.nb, net.ng, net.nl) == (3, 3, 3) and net.ref_bus == 0     # no type-3 bus in the file: largest generator's bus
     assert np.allclose(net.pd, [1.1, 1.1, 0.95]) and np.allclose(net.rate_a, [90.0, 0.5, 90.0])
     assert np.allclose(net.c2, [1100.0, 850.0, 0.0]) and np.allclose(net.c1, [500.0, 120.0, 0.0])
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/examples/acopf/case3.m"), reason="reference not mounted")
+def test_reference_example_case_solves_to_the_dispatch_stored_in_the_file():
+    """The reference's example file carries the solved ACOPF in its columns (gen Pg = 158.067, 160.006, 0 MW; dcline
+    Pf = Pmin = 10 MW; PowerModels' documented objective for this case is 5907).  The full model -- AC branches plus
+    the HVDC line with its loss row, examples/acopf/opf.jl:12-46 -- solved by the restated SQP-TR from a flat start
+    must land on that dispatch, under both Hessian sign conventions."""
+    from oracle import oracle as O
+    m = MP.read_matpower("/root/reference/examples/acopf/case3.m")
+    net = MP.network_from_matpower(m)
+    lay = acopf_layout(net)
+    assert lay.n == 2 * 3 + 2 * 3 + 4 * 3 + 4 and lay.m == 1 + 2 * 3 + 8 * 3 + 1
+    for quirks in (0, 1):
+        r = O.sqp_solve(O.problem_acopf(net, lay), O.default_options(max_iter=100, tol_infeas=1e-6, tol_residual=1e-4,
+                                                                     use_soc=1, literal_quirks=quirks))
+        assert r["status"] == 0
+        pg = r["x"][2 * net.nb:2 * net.nb + net.ng] * m["baseMVA"]
+        assert np.allclose(pg, m["gen"][:, 1], atol=2e-3)               # stored with 3 decimals (MW)
+        assert abs(r["obj_val"] - 5906.88) < 0.01
+        p_dc = r["x"][-4:-2] * m["baseMVA"]
+        assert np.allclose(p_dc, [m["dcline"][0, 3], -m["dcline"][0, 4]], atol=1e-4)   # Pf = 10 MW in, Pt = 10 MW out
+
+
+def test_dcline_loss_rows_and_balance_terms_match_finite_differences():
+    from oracle import oracle as O
+    import dataclasses
+    import scipy.sparse as sp
+    net = acopf_synth(14, 5, 20, 14)
+    dc = dict(f_bus=np.array([2, 7], dtype=np.int32), t_bus=np.array([9, 3], dtype=np.int32),
+              pminf=np.array([0.05, -0.3]), pmaxf=np.array([0.6, 0.3]), qminf=np.full(2, -0.4), qmaxf=np.full(2, 0.4),
+              qmint=np.full(2, -0.4), qmaxt=np.full(2, 0.4), loss0=np.array([0.002, 0.0]), loss1=np.array([0.03, 0.0]))
+    net = dataclasses.replace(net, dcline=dc)
+    lay = acopf_layout(net)
+    assert lay.n == 118 + 8 and lay.m == 189 + 2 and len(lay.jrow) == 651 + 2 * 6
+    P = O.problem_acopf(net, lay)
+    rng = np.random.default_rng(4)
+    x = np.clip(lay.x0 + 0.05 * rng.standard_normal(lay.n), lay.xL, lay.xU)
+    J = sp.coo_matrix((P.eval_jac_g(x), (lay.jrow - 1, lay.jcol - 1)), shape=(lay.m, lay.n)).toarray()
+    h = 1e-6
+    for j in range(lay.n):
+        e = np.zeros(lay.n); e[j] = h
+        assert np.abs((P.eval_g(x + e) - P.eval_g(x - e)) / (2 * h) - J[:, j]).max() < 1e-7 * max(1.0, np.abs(J).max())
+    g = P.eval_g(x)
+    DC = lay.n - 8
+    assert np.allclose(g[-2:], [(1 - 0.03) * x[DC] + x[DC + 2], x[DC + 1] + x[DC + 3]])
+    plain = acopf_synth(14, 5, 20, 14)
+    g0 = O.problem_acopf(plain, acopf_layout(plain)).eval_g(x[:118])
+    d = g[:189] - g0                                              # the dc terminals load the balance rows of their buses
+    rowP = lambda b: 2 * 20 + 1 + 2 * b
+    assert np.isclose(d[rowP(2)], x[DC]) and np.isclose(d[rowP(9)], x[DC + 2]) and np.isclose(d[rowP(2) + 1], x[DC + 4])
+    assert np.count_nonzero(np.abs(d) > 1e-15) == 8
+    # the whole thing solves
+    r = O.sqp_solve(P, O.default_options(max_iter=60, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=0))
+    assert r["status"] == 0
+
+
+def test_golden_copy_of_the_reference_case_reproduces_its_stored_dispatch():
+    """tests/golden/case3_network.m is the reference's example network re-serialised by make_golden.py (our writer's
+    text, not the reference's file); case3_dispatch.json holds the dispatch that file stores.  Runs where
+    /root/reference does not exist (the GPU box)."""
+    import json
+    from oracle import oracle as O
+    here = os.path.dirname(os.path.abspath(__file__))
+    pin = json.load(open(os.path.join(here, "golden", "case3_dispatch.json")))["case3_dispatch"]
+    net = MP.load_case(os.path.join(here, "golden", "case3_network.m"))
+    assert (net.nb, net.ng, net.nl, net.ndc) == (3, 3, 3, 1)
+    lay = acopf_layout(net)
+    r = O.sqp_solve(O.problem_acopf(net, lay), O.default_options(max_iter=100, tol_infeas=1e-6, tol_residual=1e-4,
+                                                                 use_soc=1, literal_quirks=1))
+    assert r["status"] == 0
+    assert np.allclose(r["x"][2 * net.nb:2 * net.nb + net.ng] * pin["base_mva"], pin["pg_mw"], atol=2e-3)
+    assert np.allclose(r["x"][-4:-2] * pin["base_mva"], [pin["dc_pf_mw"], -pin["dc_pt_mw"]], atol=1e-4)
+    assert abs(r["obj_val"] - pin["objective"]) < 0.01
