@@ -236,7 +236,7 @@ def main():
                        "qp_solved": n_qp, "ipm_iterations": n_ipm, "kkt_factorisations": n_fac,
                        "ldlt_dense_equivalent_tflops_wall": n_fac * ((N_c if int(opts.kkt_condense) else N_full) ** 3 / 3.0) / elapsed / 1e12 if elapsed > 0 else 0.0,
                        "instances_done": int(np.sum(g_done))},
-            "roofline": {"bound": "mfma", "kernel": "k_trailing (v_mfma_f64_16x16x4_f64)",
+            "roofline": {"bound": "mfma", "kernel": "k_trailing + k_trailing_list (v_mfma_f64_16x16x4_f64)",
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "launches": tr_launch, "avg_launch_ms": 1e3 * tr_sec / tr_launch if tr_launch else None,

@@ -23,9 +23,15 @@ for k in sorted(set(fe) | set(wr)):
               "fetch_bytes_per_launch_corrected": 2.0 * 1024.0 * f / max(1, nf),
               "write_bytes_per_launch": 1024.0 * w / max(1, nw)}
 json.dump(out, open(os.path.join(root, f"{tag}_pmc_traffic_batch64.json"), "w"), indent=1)
-tr = next((v for k, v in out.items() if "k_trailing" in k), None)
+# the timed update launches are k_trailing<16> and, behind the independent leading tiles, k_trailing_list<16>
+trk = [v for k, v in out.items() if "k_trailing" in k]
+tr = None
+if trk:
+    nd = sum(v["dispatches"] for v in trk)
+    tr = {"fetch_bytes_per_launch_corrected": sum(v["fetch_bytes_per_launch_corrected"] * v["dispatches"] for v in trk) / max(1, nd),
+          "write_bytes_per_launch": sum(v["write_bytes_per_launch"] * v["dispatches"] for v in trk) / max(1, nd)}
 if tr:
-    json.dump({"kernel": "k_trailing<16>", "hbm_bytes_per_launch": tr["fetch_bytes_per_launch_corrected"] + tr["write_bytes_per_launch"],
+    json.dump({"kernel": "k_trailing<16> + k_trailing_list<16>", "hbm_bytes_per_launch": tr["fetch_bytes_per_launch_corrected"] + tr["write_bytes_per_launch"],
                "fetch_bytes_per_launch": tr["fetch_bytes_per_launch_corrected"], "write_bytes_per_launch": tr["write_bytes_per_launch"],
                "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, bench.py --steps 1 --warmup 0 (64 instances, one group); "
                       "KiB -> bytes; FETCH_SIZE doubled (gfx950 wide-read correction, MI355X_MICROARCH.md HBM section); average over the "

@@ -162,6 +162,17 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
             if (d.condense && opt->kkt_tile_order) {
                 KktOrder o = kkt_order(d.n, (int)m, kpos, d.mk, PH.colptr, PH.rowval, rptr, rcol, /*rows_last=*/true);
                 upos = o.pos; d.Ts = o.Ts; d.Nf = o.Nf;
+                if (o.Ts > 0 && o.Tr > 0 && !getenv("SQPHIP_NO_TILE_MASK")) {
+                    C.plan.tmask = C.upload(o.tmask);
+                    C.plan.pair_ptr = C.upload(o.pair_ptr);
+                    C.plan.pair_k = C.upload(o.pair_k.empty() ? std::vector<int>(1, 0) : o.pair_k);
+                    // per tile pair: (entries of the lower triangle in the tile) x 2 x 64 x (sub-panels in its list)
+                    double fl = 0.0;
+                    for (int ti = 0, pi = 0; ti < o.Tr; ++ti)
+                        for (int tj = 0; tj <= ti; ++tj, ++pi)
+                            fl += (ti == tj ? 64.0 * 65.0 / 2.0 : 64.0 * 64.0) * 2.0 * 64.0 * (o.pair_ptr[pi + 1] - o.pair_ptr[pi]);
+                    C.plan.lead_update_flops = fl;
+                }
             } else {
                 for (int u = 0; u < nu; ++u) upos[u] = u;
             }

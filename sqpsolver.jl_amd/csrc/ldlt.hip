@@ -291,7 +291,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TB == 1 ? 4
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_panel_trsm_mfma(double *__restrict__ K, long strideK, int ld, const double *__restrict__ dinv,
                        double *__restrict__ Wbuf, int Npad, int k, int T, const int *__restrict__ phase, int want,
-                       double *__restrict__ bvec, int row0, long strideW)
+                       double *__restrict__ bvec, int row0, long strideW, const unsigned char *__restrict__ tmask,
+                       int Ts)
 {
     const int inst = blockIdx.y;
     if (phase && phase[inst] != want) return;
@@ -316,6 +317,9 @@ void k_panel_trsm_mfma(double *__restrict__ K, long strideK, int ld, const doubl
     }
     __syncthreads();
     if (i >= T) return;                                   // no further barriers below
+    // batched leading columns: a (remainder tile, leading tile) block that is structurally zero stays zero -- L is
+    // already zero there (k_kkt_assemble) and the update skips it, so nothing to compute or store
+    if (tmask && !tmask[(i - Ts) * Ts + k]) return;
     double *A = Kb + (long)(k * 64) * ld + i * 64 + rh;
     double *Wout = Wbuf + (long)inst * Npad * 64 + i * 64 + rh;   // Wbuf already points at this sub-panel's slot
     const double *di = dinv + (long)inst * Npad + k * 64;
@@ -464,11 +468,13 @@ __device__ __forceinline__ void tile_decode(int t, int jlo, int jhi, int T, int 
 }
 
 // KC = k-columns per LDS stage (two stages): 32 -> 64 KB of LDS, two workgroups per CU; 16 -> 32 KB, up to four.
-template <int KC>
+template <int KC, bool LIST = false>
 __device__ __forceinline__ void schur_update_run(double *__restrict__ K, long strideK, int ld,
                                                  const double *__restrict__ Wbuf, long strideW, int Npad,
                                                  int T, int kp, int nsub, int wslot, int jlo, int jhi, int S, int ntl,
-                                                 int tpb, int nrun, int B, const int *__restrict__ phase, int want)
+                                                 int tpb, int nrun, int B, const int *__restrict__ phase, int want,
+                                                 const int *__restrict__ pair_ptr = nullptr,
+                                                 const int *__restrict__ pair_k = nullptr)
 {
     constexpr int SPS = 64 / KC;            // stages per 64-wide sub-panel
     constexpr int NP = KC / 8;              // staging passes: 8 columns per pass
@@ -501,8 +507,16 @@ __device__ __forceinline__ void schur_update_run(double *__restrict__ K, long st
     // operand staging: thread moves 2 doubles per column, 32 threads cover a column, 8 columns per pass
     const int ii = (tid & 31) * 2, kk0 = tid >> 5;
     d2 lv[NP], wv[NP];
+    // LIST: only the sub-panels both tiles couple to (pair list of the tile order; one tile per run)
+    const int *kl = nullptr;
+    if (LIST) {
+        const int pi = (ti - jlo) * (ti - jlo + 1) / 2 + (tj - jlo);
+        kl = pair_k + pair_ptr[pi];
+        nsub = pair_ptr[pi + 1] - pair_ptr[pi];
+        if (nsub == 0) return;               // uniform over the workgroup, before any barrier
+    }
     auto fetch = [&](int ftj, int fti, int step) {
-        const int sub = step / SPS, off = (step % SPS) * KC;
+        const int sub = LIST ? kl[step / SPS] : step / SPS, off = (step % SPS) * KC;
         const double *Lg = Kb + (long)((kp + sub) * 64 + off) * ld + ftj * 64;              // L[tj][kp+sub]
         const double *Wg = Wb + (long)sub * strideW + (long)off * Npad + fti * 64;          // W_sub[ti]
 #pragma unroll
@@ -586,6 +600,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                     int tpb, int nrun, int B, const int *__restrict__ phase, int want)
 {
     schur_update_run<KC>(K, strideK, ld, Wbuf, strideW, Npad, T, kp, nsub, wslot, jlo, jhi, S, ntl, tpb, nrun, B, phase, want);
+}
+
+// the rank-64 Ts update behind the independent leading tile columns, restricted per tile pair to the leading tiles
+// both of them couple to (order.hip: pair lists); timed and counted with k_trailing
+template <int KC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_trailing_list(double *__restrict__ K, long strideK, int ld,
+                                                    const double *__restrict__ Wbuf, long strideW, int Npad,
+                                                    int T, int kp, int nsub, int wslot, int jlo, int jhi, int S, int ntl,
+                                                    int tpb, int nrun, int B, const int *__restrict__ phase, int want,
+                                                    const int *__restrict__ pair_ptr, const int *__restrict__ pair_k)
+{
+    schur_update_run<KC, true>(K, strideK, ld, Wbuf, strideW, Npad, T, kp, nsub, wslot, jlo, jhi, S, ntl, tpb, nrun, B, phase, want,
+                               pair_ptr, pair_k);
 }
 
 // the left-looking updates inside an outer panel (look-ahead stream, not timed)
@@ -730,7 +757,7 @@ static int tiles_in_cols(int T, int jlo, int jhi)
 }
 
 static void launch_update(const LdltPlan &P, hipStream_t s, double *K, int kp, int nsub, int wslot, int jlo,
-                          int jhi, const int *phase, int want, Timers *tm, bool count)
+                          int jhi, const int *phase, int want, Timers *tm, bool count, bool use_list = false)
 {
     if (jhi > P.T) jhi = P.T;
     if (jlo >= jhi) return;
@@ -744,7 +771,13 @@ static void launch_update(const LdltPlan &P, hipStream_t s, double *K, int kp, i
     std::pair<hipEvent_t, hipEvent_t> ev;
     const bool timed = tm && tm->enabled && count;
     if (timed) { ev = tm->get(); hipEventRecord(ev.first, s); }
-    if (count && P.kc == 16)
+    if (use_list && P.pair_ptr) {
+        // one tile per workgroup (the pair list belongs to the tile), plain column-major tile order (S = 1): the
+        // pair index in the kernel is computed from (ti, tj) directly
+        hipLaunchKernelGGL(k_trailing_list<16>, dim3(ntl * P.B), dim3(256), P.trail_pad, s, K, strideK, P.ld, P.Wbuf, strideW,
+                           P.Npad, P.T, kp, nsub, wslot, jlo, jhi, P.supertile, ntl, 1, ntl, P.B, phase, want, P.pair_ptr,
+                           P.pair_k);
+    } else if (count && P.kc == 16)
         hipLaunchKernelGGL(k_trailing<16>, dim3(nrun * P.B), dim3(256), P.trail_pad, s, K, strideK, P.ld, P.Wbuf, strideW, P.Npad,
                            P.T, kp, nsub, wslot, jlo, jhi, P.supertile, ntl, tpb, nrun, P.B, phase, want);
     else if (count)
@@ -772,7 +805,8 @@ static void launch_panel(const LdltPlan &P, hipStream_t s, double *K, double *di
     // longer steps of half as many workgroups hide less latency.
     if (P.trsm_mfma)
         hipLaunchKernelGGL(k_panel_trsm_mfma, dim3((rem + 1) / 2, P.B), dim3(256), 0, s, K, strideK, P.ld, dinv,
-                           P.Wbuf + (long)wslot * strideW, P.Npad, c, P.T, phase, want, b, c + 1, strideW);
+                           P.Wbuf + (long)wslot * strideW, P.Npad, c, P.T, phase, want, b, c + 1, strideW,
+                           (const unsigned char *)nullptr, 0);
     else
         hipLaunchKernelGGL(k_panel_trsm<1>, dim3(rem, P.B), dim3(256), 0, s, K, strideK, P.ld, dinv,
                            P.Wbuf + (long)wslot * strideW, P.Npad, c, P.T, phase, want, b);
@@ -797,10 +831,10 @@ void ldlt_factor(const LdltPlan &P, double *K, double *dinv, const int *phase, i
         hipLaunchKernelGGL(k_diag_factor, dim3(P.B, Ts), dim3(256), 0, sA, K, strideK, P.ld, dinv, P.Npad, 0, phase, want, b, v);
         if (T > Ts) {
             hipLaunchKernelGGL(k_panel_trsm_mfma, dim3((T - Ts + 1) / 2, P.B, Ts), dim3(256), 0, sA, K, strideK, P.ld,
-                               dinv, P.Wbuf, P.Npad, 0, T, phase, want, (double *)nullptr, Ts, strideW);
+                               dinv, P.Wbuf, P.Npad, 0, T, phase, want, (double *)nullptr, Ts, strideW, P.tmask, Ts);
             if (b)
                 hipLaunchKernelGGL(k_fwd_lead, dim3(T - Ts, P.B), dim3(256), 0, sA, K, strideK, P.ld, b, P.Npad, Ts, phase, want);
-            launch_update(P, sA, K, 0, Ts, 0, Ts, T, phase, want, tm, true);
+            launch_update(P, sA, K, 0, Ts, 0, Ts, T, phase, want, tm, true, /*use_list=*/true);
         }
     }
     const int nq = (T - Ts + R - 1) / R;
@@ -837,7 +871,7 @@ double ldlt_trailing_flops(const LdltPlan &P)
     const int T = P.T, R = P.R, Ts = P.Ts;
     double f = 0.0;
     auto tri = [](int tiles) { const double r = 64.0 * tiles; return r * (r + 1.0); };   // 2 * r (r + 1) / 2
-    if (Ts > 0 && T > Ts) f += tri(T - Ts) * 64.0 * Ts;
+    if (Ts > 0 && T > Ts) f += P.pair_ptr ? P.lead_update_flops : tri(T - Ts) * 64.0 * Ts;
     for (int c0 = Ts; c0 < T; c0 += R) {
         const int nsub = c0 + R <= T ? R : T - c0;
         if (c0 + nsub >= T) break;

@@ -23,7 +23,9 @@
 namespace sqphip {
 
 // unknown u: variable j (u = j < n) or kept row (u = n + kpos).  adj: symmetric adjacency lists (sorted, unique)
-KktOrder kkt_order_from_graph(int n, int nc, const std::vector<std::vector<int>> &adj, bool rows_last)
+// long_rows: variable lists of the eliminated rows whose cliques were only chained in adj (see kkt_order)
+KktOrder kkt_order_from_graph(int n, int nc, const std::vector<std::vector<int>> &adj, bool rows_last,
+                              const std::vector<std::vector<int>> &long_rows)
 {
     std::vector<char> inS(nc, 1);
     // largest cluster of variables in the first pass: half a tile, so that the rows joining in the second pass (which
@@ -114,9 +116,47 @@ KktOrder kkt_order_from_graph(int n, int nc, const std::vector<std::vector<int>>
         std::sort(bins[b].begin(), bins[b].end());        // variables (u < n) first, then rows
         for (size_t k = 0; k < bins[b].size(); ++k) o.pos[bins[b][k]] = (int)(64 * b + k);
     }
+    // remainder: separator variables first (a row must stay behind every variable it couples to), then the rows
+    // sorted by the leading tiles they touch, so that a 64-row tile of the remainder couples to few leading tiles and
+    // most (remainder tile, leading tile) blocks of the panel are structurally zero.  tmask / pair lists: what the
+    // panel solve and the rank-64 Ts update of ldlt_factor may skip (exact: a zero block of K_c stays zero through
+    // the elimination of the independent leading tiles).
+    std::vector<int> rem;
+    for (int u = 0; u < nc; ++u) if (!inS[u]) rem.push_back(u);
+    std::vector<std::vector<int>> touch(nc);
+    for (const auto &lr : long_rows) {           // a chained clique: every pair of its variables is an entry of K_c
+        std::vector<int> tiles;
+        for (int v : lr) if (inS[v]) tiles.push_back(o.pos[v] / 64);
+        for (int u : lr) if (!inS[u]) touch[u].insert(touch[u].end(), tiles.begin(), tiles.end());
+    }
+    for (int u : rem) {
+        for (int v : adj[u]) if (inS[v]) touch[u].push_back(o.pos[v] / 64);
+        std::sort(touch[u].begin(), touch[u].end());
+        touch[u].erase(std::unique(touch[u].begin(), touch[u].end()), touch[u].end());
+    }
+    if (rows_last && !getenv("SQPHIP_ORDER_NO_SORT"))
+        std::stable_sort(rem.begin(), rem.end(), [&](int a, int b) {
+            const bool va = a < n, vb = b < n;
+            if (va != vb) return va;                       // variables before rows
+            if (va) return a < b;
+            const bool ea = touch[a].empty(), eb = touch[b].empty();
+            if (ea != eb) return eb;                       // rows touching no leading tile last
+            return touch[a] < touch[b] || (touch[a] == touch[b] && a < b);
+        });
     int p = 64 * o.Ts;
-    for (int u = 0; u < nc; ++u) if (!inS[u]) o.pos[u] = p++;
+    for (int u : rem) o.pos[u] = p++;
     o.Nf = p;
+    o.Tr = ((int)rem.size() + 63) / 64;
+    o.tmask.assign((size_t)o.Tr * std::max(1, o.Ts), 0);
+    for (size_t k = 0; k < rem.size(); ++k)
+        for (int t : touch[rem[k]]) o.tmask[(k / 64) * o.Ts + t] = 1;
+    o.pair_ptr.assign(1, 0);
+    for (int ti = 0; ti < o.Tr; ++ti)
+        for (int tj = 0; tj <= ti; ++tj) {
+            for (int k = 0; k < o.Ts; ++k)
+                if (o.tmask[(size_t)ti * o.Ts + k] && o.tmask[(size_t)tj * o.Ts + k]) o.pair_k.push_back(k);
+            o.pair_ptr.push_back((int)o.pair_k.size());
+        }
     return o;
 }
 
@@ -127,7 +167,7 @@ KktOrder kkt_order(int n, int m, const std::vector<int> &kpos, int mk, const std
                    bool rows_last)
 {
     const int nc = n + mk;
-    std::vector<std::vector<int>> adj(nc);
+    std::vector<std::vector<int>> adj(nc), long_rows;
     auto edge = [&](int a, int b) { if (a != b) { adj[a].push_back(b); adj[b].push_back(a); } };
     for (int j = 0; j < n; ++j)
         for (int k = hcolptr[j]; k < hcolptr[j + 1]; ++k) if (hrowval[k] > j) edge(hrowval[k], j);
@@ -135,10 +175,13 @@ KktOrder kkt_order(int n, int m, const std::vector<int> &kpos, int mk, const std
         const int s = jrowptr[i], e = jrowptr[i + 1];
         if (kpos[i] >= 0) { for (int t = s; t < e; ++t) edge(n + kpos[i], jrcol[t]); }
         else if (e - s <= 32) { for (int a = s; a < e; ++a) for (int b = a + 1; b < e; ++b) edge(jrcol[a], jrcol[b]); }
-        else for (int a = s; a + 1 < e; ++a) edge(jrcol[a], jrcol[a + 1]);   // long row: a chain ties the same cluster
+        else {                                             // long row: a chain ties the same cluster
+            for (int a = s; a + 1 < e; ++a) edge(jrcol[a], jrcol[a + 1]);
+            long_rows.emplace_back(jrcol.begin() + s, jrcol.begin() + e);
+        }
     }
     for (auto &l : adj) { std::sort(l.begin(), l.end()); l.erase(std::unique(l.begin(), l.end()), l.end()); }
-    return kkt_order_from_graph(n, nc, adj, rows_last);
+    return kkt_order_from_graph(n, nc, adj, rows_last, long_rows);
 }
 
 }  // namespace sqphip

@@ -60,6 +60,9 @@ struct LdltPlan {
     int trsm_mfma = 1;          // panel solve on the MFMA pipe, one wave per tile (SQPHIP_TRSM_MFMA=0: LDS substitution)
     int supertile = 8;          // tile columns per super-tile of the Schur-update schedule (SQPHIP_SUPERTILE; 1 = column-major)
     int Ts = 0;                 // leading tile columns that are mutually independent (order.hip); 0 = plain dense
+    const unsigned char *tmask = nullptr;       // device copies of KktOrder::tmask / pair lists (null: no skipping)
+    const int *pair_ptr = nullptr, *pair_k = nullptr;
+    double lead_update_flops = 0.0;             // algorithmic flops of the list-restricted update behind the leading tiles
     int lookahead_min = 24;     // the look-ahead stream is used when the dense chain has at least this many tile
                                 // columns (SQPHIP_LOOKAHEAD_MIN): +6 % QP/s at 44 columns, nothing at 33, -2.8 % at the
                                 // 11 of the tile-ordered IEEE-118 matrices (events and a second queue for nothing)
@@ -118,6 +121,10 @@ struct KktOrder {
     std::vector<int> pos;   // unknown (variable j, or n + kept-row position) -> position in the factorised matrix
     int Ts = 0;             // leading tile columns, mutually independent (block-diagonal leading Ts x Ts tile block)
     int Nf = 0;             // positions used: 64 * Ts for the tiles (identity padding inside) + the dense remainder
+    int Tr = 0;             // tiles of the remainder
+    std::vector<unsigned char> tmask;   // [Tr][Ts]: remainder tile r couples to leading tile k
+    std::vector<int> pair_ptr, pair_k;  // per remainder tile pair (ti >= tj, index ti (ti + 1) / 2 + tj): the leading
+                                        // tiles both couple to = the sub-panels of the rank-64 Ts update that matter
 };
 KktOrder kkt_order(int n, int m, const std::vector<int> &kpos, int mk, const std::vector<int> &hcolptr,
                    const std::vector<int> &hrowval, const std::vector<int> &jrowptr, const std::vector<int> &jrcol,
