@@ -672,7 +672,8 @@ __global__ __launch_bounds__(64) void k_fwd_step(const double *__restrict__ K, l
 // columns k = w (mod 4); lane r owns row r of the tile row.
 __global__ __launch_bounds__(256) void k_fwd_lead(const double *__restrict__ K, long strideK, int ld,
                                                  double *__restrict__ x, int Npad, int Ts,
-                                                 const int *__restrict__ phase, int want)
+                                                 const int *__restrict__ phase, int want,
+                                                 const unsigned char *__restrict__ tmask)
 {
     const int inst = blockIdx.y;
     if (phase && phase[inst] != want) return;
@@ -683,6 +684,7 @@ __global__ __launch_bounds__(256) void k_fwd_lead(const double *__restrict__ K, 
     __shared__ double part[4][64];
     double acc = 0.0;
     for (int k = w; k < Ts; k += 4) {
+        if (tmask && !tmask[(i - Ts) * Ts + k]) continue;      // structurally zero block (wave-uniform test)
         const double *Lik = Kb + (long)(k * 64) * ld + i * 64 + r;
         const double *yk = xb + k * 64;
 #pragma unroll 8
@@ -700,13 +702,16 @@ __global__ __launch_bounds__(256) void k_fwd_lead(const double *__restrict__ K, 
 // the waves.
 __global__ __launch_bounds__(256) void k_bwd_step(const double *__restrict__ K, long strideK, int ld,
                                                  double *__restrict__ x, double *__restrict__ v,
-                                                 int Npad, int k, const int *__restrict__ phase, int want, int lead)
+                                                 int Npad, int k, const int *__restrict__ phase, int want, int lead,
+                                                 const unsigned char *__restrict__ tmask, int Ts)
 {
     const int inst = blockIdx.y;
     if (phase && phase[inst] != want) return;
     // lead: grid (1, B, nk) -- only the diagonal solves x_k = L_kk^-T v_k of the nk independent leading tile columns
     if (lead) k += blockIdx.z;
     const int j = lead ? k : blockIdx.x;
+    // a leading tile row that does not couple to tile row k of the remainder: tile (k, j) is structurally zero
+    if (tmask && !lead && j < Ts && k >= Ts && !tmask[(k - Ts) * Ts + j]) return;
     const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
     const double *Kb = K + (long)inst * strideK;
     const double *Lkk = Kb + (long)(k * 64) * ld + k * 64;
@@ -833,7 +838,8 @@ void ldlt_factor(const LdltPlan &P, double *K, double *dinv, const int *phase, i
             hipLaunchKernelGGL(k_panel_trsm_mfma, dim3((T - Ts + 1) / 2, P.B, Ts), dim3(256), 0, sA, K, strideK, P.ld,
                                dinv, P.Wbuf, P.Npad, 0, T, phase, want, (double *)nullptr, Ts, strideW, P.tmask, Ts);
             if (b)
-                hipLaunchKernelGGL(k_fwd_lead, dim3(T - Ts, P.B), dim3(256), 0, sA, K, strideK, P.ld, b, P.Npad, Ts, phase, want);
+                hipLaunchKernelGGL(k_fwd_lead, dim3(T - Ts, P.B), dim3(256), 0, sA, K, strideK, P.ld, b, P.Npad, Ts, phase, want,
+                                   P.tmask);
             launch_update(P, sA, K, 0, Ts, 0, Ts, T, phase, want, tm, true, /*use_list=*/true);
         }
     }
@@ -892,7 +898,7 @@ void ldlt_solve(const LdltPlan &P, const double *K, const double *dinv, double *
                                phase, want, 1);
             if (P.T > Ts)
                 hipLaunchKernelGGL(k_fwd_lead, dim3(P.T - Ts, P.B), dim3(256), 0, s, K, strideK, P.ld, x, P.Npad, Ts,
-                                   phase, want);
+                                   phase, want, P.tmask);
         }
         for (int k = Ts; k < P.T; ++k)
             hipLaunchKernelGGL(k_fwd_step, dim3(P.T - k, P.B), dim3(64), 0, s, K, strideK, P.ld, dinv, x, v,
@@ -900,10 +906,10 @@ void ldlt_solve(const LdltPlan &P, const double *K, const double *dinv, double *
     }
     for (int k = P.T - 1; k >= Ts; --k)
         hipLaunchKernelGGL(k_bwd_step, dim3(k + 1, P.B), dim3(256), 0, s, K, strideK, P.ld, x, v, P.Npad, k,
-                           phase, want, 0);
+                           phase, want, 0, P.tmask, Ts);
     if (Ts > 0)
         hipLaunchKernelGGL(k_bwd_step, dim3(1, P.B, Ts), dim3(256), 0, s, K, strideK, P.ld, x, v, P.Npad, 0,
-                           phase, want, 1);
+                           phase, want, 1, (const unsigned char *)nullptr, 0);
 }
 
 }  // namespace sqphip
