@@ -164,6 +164,7 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
                 upos = o.pos; d.Ts = o.Ts; d.Nf = o.Nf;
                 if (o.Ts > 0 && o.Tr > 0 && !getenv("SQPHIP_NO_TILE_MASK")) {
                     C.plan.tmask = C.upload(o.tmask);
+                    d.tmask = C.plan.tmask;
                     C.plan.pair_ptr = C.upload(o.pair_ptr);
                     C.plan.pair_k = C.upload(o.pair_k.empty() ? std::vector<int>(1, 0) : o.pair_k);
                     // per tile pair: (entries of the lower triangle in the tile) x 2 x 64 x (sub-panels in its list)

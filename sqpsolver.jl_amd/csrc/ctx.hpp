@@ -54,6 +54,7 @@ struct DV {
     // columns that are mutually independent
     const int *upos, *uinv;
     int Ts;
+    const unsigned char *tmask;           // [remainder tile][leading tile] coupling mask (null: none), order.hip
     int nnzj_coo, nnzh_coo, nnzjc, nnzhc;
     // shared structure
     const int *jcolptr, *jrowval, *jrowptr, *jrcol, *jrslot;

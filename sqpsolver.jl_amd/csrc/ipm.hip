@@ -354,7 +354,15 @@ __global__ __launch_bounds__(128) void k_kkt_assemble(DV d)
     const int lead_end = 64 * d.Ts;
     if (p < lead_end) {
         for (int i = p + threadIdx.x; i < (p | 63) + 1; i += 128) col[i] = 0.0;
-        for (int i = lead_end + threadIdx.x; i < d.Fpad; i += 128) col[i] = 0.0;
+        if (d.tmask) {
+            // ... and of the panel below only the blocks that couple to this leading tile: the others are never
+            // written either (the scatter below puts entries into coupled blocks only, the panel solve skips the rest)
+            const int k = p >> 6;
+            for (int r = 0; r < (d.Fpad - lead_end) / 64; ++r)
+                if (d.tmask[r * d.Ts + k] && threadIdx.x < 64) col[lead_end + 64 * r + threadIdx.x] = 0.0;
+        } else {
+            for (int i = lead_end + threadIdx.x; i < d.Fpad; i += 128) col[i] = 0.0;
+        }
     } else {
         for (int i = p + threadIdx.x; i < d.Fpad; i += 128) col[i] = 0.0;
     }
