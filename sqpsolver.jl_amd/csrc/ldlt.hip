@@ -304,6 +304,11 @@ void k_panel_trsm_mfma(double *__restrict__ K, long strideK, int ld, const doubl
     const int l15 = lane & 15, l4 = lane >> 4;
     const int i = row0 + blockIdx.x * 2 + (wave >> 1);    // this wave's row tile ...
     const int rh = (wave & 1) * 32;                       // ... and its half of the rows (2 x 16)
+    if (tmask) {                                          // both row tiles of this workgroup structurally zero: nothing to do
+        const int i0 = row0 + blockIdx.x * 2;
+        const bool a = i0 < T && tmask[(i0 - Ts) * Ts + k], b = i0 + 1 < T && tmask[(i0 + 1 - Ts) * Ts + k];
+        if (!a && !b) return;                             // workgroup-uniform, before any barrier
+    }
     double *Kb = K + (long)inst * strideK;
     const double *Lkk = Kb + (long)(k * 64) * ld + k * 64;
     __shared__ double Ls[64 * 64];                        // Ls[swz(kcol, c)] = L_kk[c][kcol]  (k-major image)
