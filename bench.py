@@ -7,7 +7,7 @@ One "step" = one SQP-TR outer iteration of every instance of the rank's batch: d
 evaluation, the trust-region QP (or feasibility-restoration / second-order-correction) sub-problem
 solved by the on-device interior-point method, merit + ratio test.  Workload at N = 1: the per-GPU
 shard of BASELINE.json configs[3] -- 64 IEEE-118-shaped ACOPF contingency scenarios (512 over 8 GPUs,
-weak scaling: 64 per rank), KKT order 2813 condensed to 2069 (options.kkt_condense) and ordered into 22 independent
+weak scaling: 64 per rank), KKT order 2813 condensed to 2069 (options.kkt_condense) and ordered into 23 independent
 leading tiles + a dense remainder of 673 (options.kkt_tile_order), fp64 LDL^T, synthetic
 data of that shape, SQP options of
 /root/reference/examples/acopf/opf.jl:76-79.  Inputs are resident in HBM before the timed region.

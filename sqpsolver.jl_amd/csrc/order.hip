@@ -102,13 +102,28 @@ KktOrder kkt_order_from_graph(int n, int nc, const std::vector<std::vector<int>>
     std::sort(comps.begin(), comps.end(), [](const std::vector<int> &a, const std::vector<int> &b) {
         return a.size() != b.size() ? a.size() > b.size() : a[0] < b[0]; });
     // first-fit packing into 64-slot tiles
+    // packing: clusters in index order (neighbours in the numbering are neighbours in the network, so a row of the
+    // remainder finds the clusters it touches in few tiles and the tile mask gets sparse), first-fit among the last
+    // `window` tiles.  Measured on the IEEE-118 shape: window 1 / 3 / 5 / all -> 25 / 24 / 23 / 23 tiles, 192 / 186 /
+    // 196 / 211 (pair, leading tile) products, 736 / 755 / 771 / 763 QP/s; largest-first first-fit (SQPHIP_ORDER_PACK=0)
+    // packs 22 tiles but leaves 336 products: 731 QP/s.
     std::vector<std::vector<int>> bins;
-    for (auto &c : comps) {
-        size_t b = 0;
-        while (b < bins.size() && bins[b].size() + c.size() > 64) ++b;
-        if (b == bins.size()) bins.emplace_back();
-        bins[b].insert(bins[b].end(), c.begin(), c.end());
-    }
+    const int window = getenv("SQPHIP_ORDER_PACK") ? atoi(getenv("SQPHIP_ORDER_PACK")) : 5;
+    if (window > 0) {
+        std::sort(comps.begin(), comps.end(), [](const std::vector<int> &a, const std::vector<int> &b) { return a[0] < b[0]; });
+        for (auto &c : comps) {
+            size_t b = bins.size() > (size_t)window ? bins.size() - window : 0;
+            while (b < bins.size() && bins[b].size() + c.size() > 64) ++b;
+            if (b == bins.size()) bins.emplace_back();
+            bins[b].insert(bins[b].end(), c.begin(), c.end());
+        }
+    } else
+        for (auto &c : comps) {
+            size_t b = 0;
+            while (b < bins.size() && bins[b].size() + c.size() > 64) ++b;
+            if (b == bins.size()) bins.emplace_back();
+            bins[b].insert(bins[b].end(), c.begin(), c.end());
+        }
     KktOrder o;
     o.pos.assign(nc, -1);
     o.Ts = (int)bins.size();

@@ -380,7 +380,7 @@ def test_product_order_and_natural_order_of_the_condensed_matrix_agree():
             cols = rows.get(int(i), [])
             assert cols and all(tile[c] == tile[u] and pos[c] < pos[u] for c in cols)
         if name == "case118":
-            assert inside == 354 and ts == 22 and nf - 64 * ts == 673   # 46 separator variables + 627 rows remain
+            assert inside == 354 and ts == 23 and nf - 64 * ts == 673   # 46 separator variables + 627 rows remain
 
 
 @pytest.mark.parametrize("name", ["hs035", "hs076"])
