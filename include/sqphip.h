@@ -64,6 +64,10 @@ typedef struct {
                               * the condensed matrix are mutually independent (sqphip_kkt_order, rows_last = 1) and
                               * the factorisation treats them as such: one launch per kernel for all of them, the
                               * dense chain only on the remainder */
+    int32_t kkt_mode;        /* linear solver of the Newton systems.  1: batched dense LDL^T on the MFMA pipe (ldlt.hip);
+                              * 2: multifrontal LDL^T of the sparse matrix (mfront.hip: symbolic analysis once per
+                              * structure, dense fronts in LDS); 0 (default): the sparse one when it does at most a
+                              * quarter of the dense flops and no front exceeds 512 rows, else the dense one */
 } sqphip_options;
 
 void sqphip_default_options(sqphip_options *o);
@@ -92,7 +96,45 @@ void sqphip_destroy(sqphip_ctx *ctx);
 int sqphip_kkt_order(int64_t n, int64_t m, int64_t nnzJ, const int64_t *jrow, const int64_t *jcol,
                      int64_t nnzH, const int64_t *hrow, const int64_t *hcol, const double *gL, const double *gU,
                      int32_t rows_last, int32_t *pos, int32_t *n_lead_tiles, int32_t *order);
+/* Host-only (no GPU): symbolic analysis of the sparse Newton matrix of this structure -- what the analysis phase of
+ * Ipopt's linear solver does for the reference (/root/reference/examples/acopf/opf.jl:59-64).  condense = 1: rows with
+ * gL != gU (and at most 32 entries) are eliminated first, as options.kkt_condense does.  rows_after_vars = 1 is what
+ * the library uses: a row is ordered behind every variable it couples to.  small_front / zero_frac: amalgamation
+ * thresholds (<= 0 / < 0: library defaults).  pos[u], u < order: position of variable u (u < n) or of the (u - n)-th
+ * kept row in the elimination order; any output may be NULL. */
+typedef struct {
+    int64_t order;            /* unknowns of the factorised matrix */
+    int64_t nnz_k_lower;      /* structural entries of its lower triangle, diagonal included */
+    int64_t n_supernodes, n_levels, max_front, max_cols;
+    int64_t nnz_l;            /* entries of L below the diagonal as the dense fronts hold them (explicit zeros included) */
+    int64_t nnz_l_exact;      /* ... of the exact sparse factor under the same order */
+    double flops, flops_exact;/* 2 x multiply-adds of one numeric factorisation: dense fronts / exact sparse */
+    int64_t front_doubles;    /* doubles of front storage per instance */
+} sqphip_symbolic_stats;
+int sqphip_kkt_symbolic(int64_t n, int64_t m, int64_t nnzJ, const int64_t *jrow, const int64_t *jcol,
+                        int64_t nnzH, const int64_t *hrow, const int64_t *hcol, const double *gL, const double *gU,
+                        int32_t condense, int32_t rows_after_vars, int32_t small_front, double zero_frac,
+                        int32_t *pos, sqphip_symbolic_stats *out);
+/* Host-only test hook (no GPU, never on the product path): builds the multifrontal plan of the structure and runs a
+ * plain host reference of its numeric phase -- assembly from the item lists, front-by-front partial LDL^T with the
+ * right-hand side carried along, backward substitution -- on the Newton matrix
+ *     [ hsc H + diag(hd + sigp + dw + 1e-8) + J_I' (D_I + 1e-8)^-1 J_I    J_K' ;  J_K   -(D_K + 1e-8) ]
+ * (rows with rtype 0 are free: diagonal -1, no coupling).  Jval / Hval in the COO order of the structure; Dd, rtype
+ * per row; sigp, hd per variable; rhs / sol / dinv_by_unknown in unknown order (variables, then kept rows);
+ * npos = positive pivots.  CPU tests compare it with a dense solve to validate the plan the kernels run. */
+int sqphip_mf_host_solve(int64_t n, int64_t m, int64_t nnzJ, const int64_t *jrow, const int64_t *jcol,
+                         int64_t nnzH, const int64_t *hrow, const int64_t *hcol, const double *gL, const double *gU,
+                         int32_t condense, const double *Jval, const double *Hval, const double *Dd,
+                         const double *sigp, const double *hd, const int32_t *rtype, double hsc, double dw,
+                         const double *rhs, double *sol, double *dinv_by_unknown, int32_t *npos);
 const char *sqphip_last_error(const sqphip_ctx *ctx);
+/* Device twin of sqphip_mf_host_solve (kernel-level parity tests): the same Newton matrix, assembled, factorised and
+ * solved by the multifrontal kernels in instance `inst` of a context that uses the sparse solver (kkt_mode 2, or 0
+ * where it selects it).  sol_fused: right-hand side carried through the factorisation; sol_standalone: the
+ * stand-alone forward / backward kernels on the same factors.  Leaves the instance idle. */
+int sqphip_mf_solve_test(sqphip_ctx *ctx, int32_t inst, const double *Jval, const double *Hval, const double *Dd,
+                         const double *sigp, const double *hd, const int32_t *rtype, double hsc, double dw,
+                         const double *rhs, double *sol_fused, double *sol_standalone, double *dinv_by_unknown);
 int sqphip_set_bounds(sqphip_ctx *ctx, int32_t inst, const double *xL, const double *xU,
                       const double *gL, const double *gU);
 
@@ -211,6 +253,15 @@ typedef struct {
     int64_t kkt_order;       /* order of the matrices the LDL^T factorises (n + m, or the condensed order) */
     int64_t lead_tiles;      /* leading 64-column tiles treated as mutually independent (options.kkt_tile_order) */
     double trailing_flops_per_factor;   /* algorithmic flops of the k_trailing launches of one factorisation */
+    /* sparse (multifrontal) solver; all zero when the dense one is in use */
+    int64_t sparse;          /* 1: the Newton systems go through mfront.hip */
+    int64_t nnz_k;           /* structural entries of the lower triangle of the factorised matrix, diagonal included */
+    int64_t nnz_l;           /* entries of L below the diagonal as the fronts hold them (deterministic order of the library) */
+    int64_t n_supernodes, n_levels, max_front;
+    double factor_flops;     /* flops of one numeric factorisation of one instance (dense partial factorisations of the fronts) */
+    int64_t front_doubles;   /* doubles of front storage per instance (L + contribution blocks + right-hand-side rows) */
+    int64_t cb_doubles;      /* ... of which contribution blocks (written once by the child, read once by the parent) */
+    int64_t factor_launches, solve_launches;   /* kernel launches of one factorisation / of one forward + backward solve */
 } sqphip_counters;
 int sqphip_get_counters(sqphip_ctx *ctx, sqphip_counters *c);
 int sqphip_reset_counters(sqphip_ctx *ctx);

@@ -7,4 +7,4 @@ from . import acopf_synth  # noqa: F401
 from . import _lib  # noqa: F401
 from . import host  # noqa: F401
 from .host import (Context, QpData, QpHip, Model, Parameters, SqpTR, optimize,  # noqa: F401
-                   default_options, SqpHipError, kkt_order)
+                   default_options, SqpHipError, kkt_order, kkt_symbolic, mf_host_solve)

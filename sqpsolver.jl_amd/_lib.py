@@ -8,8 +8,9 @@ import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 SO_PATH = os.path.join(_CSRC, "libsqphip.so")
-SOURCES = ["ldlt.hip", "kernel_api.hip", "ipm.hip", "acopf.hip", "sqp.hip", "api.hip", "order.hip"]
-HEADERS = ["sqphip_internal.hpp", "ctx.hpp", os.path.join("..", "..", "include", "sqphip.h")]
+SOURCES = ["ldlt.hip", "kernel_api.hip", "ipm.hip", "acopf.hip", "sqp.hip", "api.hip", "order.hip", "symbolic.hip",
+           "mfplan.hip", "mfront.hip"]
+HEADERS = ["sqphip_internal.hpp", "ctx.hpp", "sparse.hpp", "dev_util.hpp", "acopf_dev.hpp", os.path.join("..", "..", "include", "sqphip.h")]
 
 _lib = None
 
@@ -39,7 +40,7 @@ class Options(C.Structure):
                [("max_iter", C.c_int32), ("use_soc", C.c_int32), ("literal_quirks", C.c_int32),
                 ("ipm_tol", C.c_double), ("ipm_max_iter", C.c_int32), ("ipm_phase1", C.c_int32),
                 ("device", C.c_int32), ("ipm_corrector", C.c_int32),
-                ("kkt_condense", C.c_int32), ("kkt_tile_order", C.c_int32)]
+                ("kkt_condense", C.c_int32), ("kkt_tile_order", C.c_int32), ("kkt_mode", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -47,7 +48,17 @@ class Counters(C.Structure):
                 ("ldlt_flops", C.c_double), ("ldlt_seconds", C.c_double),
                 ("trailing_seconds", C.c_double), ("solve_seconds", C.c_double),
                 ("total_seconds", C.c_double), ("trailing_launches", C.c_int64), ("kkt_order", C.c_int64),
-                ("lead_tiles", C.c_int64), ("trailing_flops_per_factor", C.c_double)]
+                ("lead_tiles", C.c_int64), ("trailing_flops_per_factor", C.c_double),
+                ("sparse", C.c_int64), ("nnz_k", C.c_int64), ("nnz_l", C.c_int64), ("n_supernodes", C.c_int64),
+                ("n_levels", C.c_int64), ("max_front", C.c_int64), ("factor_flops", C.c_double),
+                ("front_doubles", C.c_int64), ("cb_doubles", C.c_int64), ("factor_launches", C.c_int64),
+                ("solve_launches", C.c_int64)]
+
+
+class SymbolicStats(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in ("order", "nnz_k_lower", "n_supernodes", "n_levels", "max_front", "max_cols",
+                                         "nnz_l", "nnz_l_exact")] + \
+               [("flops", C.c_double), ("flops_exact", C.c_double), ("front_doubles", C.c_int64)]
 
 
 def lib():
@@ -93,6 +104,11 @@ def lib():
             L.sqphip_acopf_set_dclines.argtypes = [vp, C.c_int32, dp]
             L.sqphip_kkt_order.argtypes = [C.c_int64, C.c_int64, C.c_int64, lp, lp, C.c_int64, lp, lp, dp, dp, C.c_int32,
                                            ip, ip, ip]
+            L.sqphip_kkt_symbolic.argtypes = [C.c_int64, C.c_int64, C.c_int64, lp, lp, C.c_int64, lp, lp, dp, dp, C.c_int32,
+                                              C.c_int32, C.c_int32, C.c_double, ip, C.POINTER(SymbolicStats)]
+            L.sqphip_mf_host_solve.argtypes = [C.c_int64, C.c_int64, C.c_int64, lp, lp, C.c_int64, lp, lp, dp, dp, C.c_int32,
+                                               dp, dp, dp, dp, dp, ip, C.c_double, C.c_double, dp, dp, dp, ip]
+            L.sqphip_mf_solve_test.argtypes = [vp, C.c_int32, dp, dp, dp, dp, dp, ip, C.c_double, C.c_double, dp, dp, dp, dp]
             L.sqphip_acopf_eval.argtypes = [vp, C.c_int32, dp, C.c_double, dp, dp, dp, dp, dp, dp]
             L.sqphip_sqp_reset.argtypes = [vp]
             L.sqphip_sqp_run.argtypes = [vp, C.c_int32]
@@ -111,7 +127,7 @@ EXPORTS = [
     "sqphip_set_bounds", "sqphip_qp_solve", "sqphip_qp_stats", "sqphip_norm_violations",
     "sqphip_kt_residuals", "sqphip_norm_complementarity", "sqphip_compute_phi",
     "sqphip_compute_qmodel", "sqphip_compute_derivative", "sqphip_tr_update",
-    "sqphip_kkt_order", "sqphip_acopf_attach", "sqphip_acopf_set_shunts", "sqphip_acopf_set_dclines", "sqphip_acopf_set_instance", "sqphip_acopf_eval", "sqphip_sqp_reset",
+    "sqphip_kkt_order", "sqphip_kkt_symbolic", "sqphip_mf_host_solve", "sqphip_mf_solve_test", "sqphip_acopf_attach", "sqphip_acopf_set_shunts", "sqphip_acopf_set_dclines", "sqphip_acopf_set_instance", "sqphip_acopf_eval", "sqphip_sqp_reset",
     "sqphip_sqp_run", "sqphip_sqp_get", "sqphip_sqp_status", "sqphip_sqp_trace",
     "sqphip_get_counters", "sqphip_reset_counters", "sqphip_set_timing", "sqphip_ldlt_factor_host",
     "sqphip_ldlt_solve_host", "sqphip_ldlt_bench", "sqphip_ldlt_stress", "sqphip_mfma_f64_peak", "sqphip_armijo_alpha", "sqphip_compute_mu_rule",

@@ -90,6 +90,14 @@ __global__ void k_qp_request(DV d, int inst, int mode, double delta, double mu_p
     }
 }
 
+// test hook (sqphip_mf_solve_test): instance `inst` alone enters phase `ph` with the given Hessian scale / delta_w
+__global__ void k_mf_test_setup(DV d, int inst, double hsc, double dw, int ph)
+{
+    for (int i = threadIdx.x; i < d.B; i += blockDim.x) { d.phase[i] = PH_IDLE; d.ist[i].start = 0; }
+    __syncthreads();
+    if (threadIdx.x == 0) { d.ist[inst].hsc = hsc; d.ist[inst].dw = dw; d.ist[inst].stage = 0; d.phase[inst] = ph; }
+}
+
 }  // namespace
 
 extern "C" void sqphip_default_options(sqphip_options *o)
@@ -100,6 +108,7 @@ extern "C" void sqphip_default_options(sqphip_options *o)
     o->rho = 0.8; o->eta = 0.4; o->tau = 0.9; o->min_alpha = 1e-6;
     o->max_iter = 3000; o->use_soc = 0; o->literal_quirks = 1;
     o->ipm_tol = 1e-9; o->ipm_max_iter = 200; o->ipm_phase1 = 0; o->device = 0; o->ipm_corrector = 1; o->kkt_condense = 1; o->kkt_tile_order = 1;
+    o->kkt_mode = 0;
 }
 
 extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num_linear, int64_t nnzJ,
@@ -128,14 +137,6 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
         const int B = batch;
         d.n = (int)n; d.m = (int)m; d.nlin = (int)num_linear; d.N = (int)(n + m);
         d.Npad = (d.N + 63) / 64 * 64; d.B = B;
-        {   // condensed form: rows with gL == gU stay in the factorised matrix, all others are eliminated
-            std::vector<int> kpos(m > 0 ? m : 1, -1), krow;
-            for (int64_t i = 0; i < m; ++i) if (gL[i] == gU[i]) { kpos[i] = (int)krow.size(); krow.push_back((int)i); }
-            d.condense = opt->kkt_condense != 0; d.mk = (int)krow.size();
-            if (krow.empty()) krow.push_back(0);
-            d.kpos = C.upload(kpos); d.krow = C.upload(krow);
-            C.h_kpos = kpos;
-        }
         d.nnzj_coo = (int)nnzJ; d.nnzh_coo = (int)nnzH;
         Pattern PJ = build_pattern(n, nnzJ, jrow, jcol, false);
         Pattern PH = build_pattern(n, nnzH, hrow, hcol, true);
@@ -154,12 +155,53 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
         }
         d.jcolptr = C.upload(PJ.colptr); d.jrowval = C.upload(PJ.rowval);
         d.jrowptr = C.upload(rptr); d.jrcol = C.upload(rcol); d.jrslot = C.upload(rslot);
-        {   // order of the factorised matrix
+        {   // condensed form: the equality rows (and rows too long to eliminate, sparse.hpp) stay in the factorised
+            // matrix, all others are eliminated
+            std::vector<int> kpos(m > 0 ? m : 1, -1), krow;
+            for (int64_t i = 0; i < m; ++i)
+                if (kkt_row_is_kept(gL[i], gU[i], rptr[i + 1] - rptr[i])) { kpos[i] = (int)krow.size(); krow.push_back((int)i); }
+            d.condense = opt->kkt_condense != 0; d.mk = (int)krow.size();
+            if (krow.empty()) krow.push_back(0);
+            d.kpos = C.upload(kpos); d.krow = C.upload(krow);
+            C.h_kpos = kpos;
+        }
+        {   // linear solver and order of the factorised matrix
             const std::vector<int> &kpos = C.h_kpos;
             const int nu = d.condense ? d.n + d.mk : d.N;       // unknowns of the factorised system
             std::vector<int> upos(nu);
-            d.Ts = 0; d.Nf = nu;
-            if (d.condense && opt->kkt_tile_order) {
+            d.Ts = 0; d.Nf = nu; d.sparse = 0;
+            if (opt->kkt_mode != 1) {
+                // multifrontal plan of the sparse matrix (full form: every row is its own unknown)
+                std::vector<int> kp(kpos);
+                if (!d.condense) for (int64_t i = 0; i < m; ++i) kp[i] = (int)i;
+                SymOptions so;
+                if (const char *e = getenv("SQPHIP_MF_SMALL_FRONT")) so.small_front = atoi(e);
+                if (const char *e = getenv("SQPHIP_MF_ZERO_FRAC")) so.zero_frac = atof(e);
+                if (const char *e = getenv("SQPHIP_MF_ROWS_AFTER")) so.rows_after_vars = atoi(e);
+                C.mfp = mf_build_plan(d.n, (int)m, kp, d.condense ? d.mk : (int)m, PH.colptr, PH.rowval, rptr, rcol, rslot, so);
+                const SparseSym &S = C.mfp.S;
+                // auto: the sparse factorisation when it does a quarter of the dense work or less and no front
+                // outgrows what one workgroup eliminates in reasonable time; a dense Hessian goes to the MFMA path
+                const double dense_flops = (double)nu * nu * nu / 3.0;
+                const bool fits = S.max_front <= 1024;
+                if (opt->kkt_mode == 2 && !fits) throw std::string("kkt_mode = 2: a front of " + std::to_string(S.max_front) + " rows exceeds the multifrontal kernels' limit (1024)");
+                d.sparse = opt->kkt_mode == 2 || (fits && S.max_front <= 512 && S.flops <= 0.25 * dense_flops);
+            }
+            if (d.sparse) {
+                const MfPlan &P = C.mfp;
+                const SparseSym &S = P.S;
+                upos = S.pos;
+                MfDev &M = d.mf;
+                M.ns = S.ns; M.stride = P.stride;
+                M.first = C.upload(S.sn_first); M.nc = C.upload(S.sn_nc); M.nr = C.upload(S.sn_nr);
+                M.rowptr = C.upload(S.sn_rowptr); M.rows = C.upload(S.sn_rows.empty() ? std::vector<int>(1, 0) : S.sn_rows);
+                M.rel = C.upload(S.rel.empty() ? std::vector<int>(1, 0) : S.rel);
+                M.child_ptr = C.upload(S.child_ptr); M.child = C.upload(S.child.empty() ? std::vector<int>(1, 0) : S.child);
+                M.off = C.upload(P.off);
+                M.asm_ptr = C.upload(P.asm_ptr); M.dest_loc = C.upload(P.dest_loc); M.item_ptr = C.upload(P.item_ptr);
+                M.items = C.upload(P.items); M.sched = C.upload(P.sched);
+                M.fronts = C.dalloc<double>((size_t)B * P.stride);
+            } else if (d.condense && opt->kkt_tile_order) {
                 KktOrder o = kkt_order(d.n, (int)m, kpos, d.mk, PH.colptr, PH.rowval, rptr, rcol, /*rows_last=*/true);
                 upos = o.pos; d.Ts = o.Ts; d.Nf = o.Nf;
                 if (o.Ts > 0 && o.Tr > 0 && !getenv("SQPHIP_NO_TILE_MASK")) {
@@ -209,7 +251,7 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
         d.rhs = C.dalloc<double>(BN); d.sol = C.dalloc<double>(BN); d.wN = C.dalloc<double>(BN);
         const size_t BF = (size_t)B * d.Fpad;          // solve vectors and pivots live in the factorised order
         d.xv = C.dalloc<double>(BF); d.vv = C.dalloc<double>(BF); d.dinv = C.dalloc<double>(BF);
-        d.K = C.dalloc<double>((size_t)B * d.ld * d.Fpad);
+        d.K = C.dalloc<double>(d.sparse ? 1 : (size_t)B * d.ld * d.Fpad);
         d.ist = C.dalloc<IpmState>(B); d.sst = C.dalloc<SqpState>(B);
         d.phase = C.dalloc<int>(B); d.counters = C.dalloc<int>(8);
         d.trace = C.dalloc<double>((size_t)B * SQPHIP_TRACE_CAP * SQPHIP_TRACE_COLS);
@@ -221,8 +263,10 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
         C.plan.N = d.Nf; C.plan.Npad = d.Fpad; C.plan.T = d.Fpad / 64; C.plan.ld = d.ld; C.plan.B = B;
         C.plan.Ts = d.Ts;
         C.plan.stream = C.stream;
-        C.plan.Wbuf = C.dalloc<double>((size_t)std::max(2 * LdltPlan::MAX_R, d.Ts) * B * d.Fpad * 64);
-        C.plan.init_lookahead();
+        if (!d.sparse) {
+            C.plan.Wbuf = C.dalloc<double>((size_t)std::max(2 * LdltPlan::MAX_R, d.Ts) * B * d.Fpad * 64);
+            C.plan.init_lookahead();
+        }
         SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
         return SQPHIP_OK;
     });
@@ -296,6 +340,52 @@ extern "C" int sqphip_qp_solve(sqphip_ctx *h, int32_t mode, const double *x_k, d
         C.last_ipm_iters = st.ipm_iters; C.last_n_factor = st.n_factor;
         C.n_qp += 1; C.n_ipm_iter += st.ipm_iters; C.n_factor += st.n_factor;
         C.total_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return SQPHIP_OK;
+    });
+}
+
+// Kernel-level test hook of the multifrontal path (mfront.hip) -- the device twin of sqphip_mf_host_solve: Newton
+// matrix from the given values in instance `inst` of a context created with the sparse solver, factorised with the
+// right-hand side fused in (sol_fused), then solved again through the stand-alone forward / backward kernels
+// (sol_standalone).  Vectors in unknown order (variables, then kept rows).
+extern "C" int sqphip_mf_solve_test(sqphip_ctx *h, int32_t inst, const double *Jval, const double *Hval,
+                                    const double *Dd, const double *sigp, const double *hd, const int32_t *rtype,
+                                    double hsc, double dw, const double *rhs, double *sol_fused,
+                                    double *sol_standalone, double *dinv_by_unknown)
+{
+    if (!h || inst < 0 || inst >= h->c.d.B || !Jval || !Dd || !sigp || !hd || !rtype || !rhs) return SQPHIP_EINVAL;
+    if (!h->c.d.sparse) { h->c.err = "sqphip_mf_solve_test: the context does not use the sparse solver"; return SQPHIP_ESTATE; }
+    return guarded(h, [&](Ctx &C) {
+        DV &d = C.d;
+        const SparseSym &S = C.mfp.S;
+        const size_t on = (size_t)inst * d.n, om = (size_t)inst * d.m;
+        h2d(C, d.jcoo + (size_t)inst * d.nnzj_coo, Jval, d.nnzj_coo);
+        if (Hval) h2d(C, d.hcoo + (size_t)inst * d.nnzh_coo, Hval, d.nnzh_coo);
+        else SQPHIP_HIP_OK(hipMemsetAsync(d.hcoo + (size_t)inst * d.nnzh_coo, 0, sizeof(double) * (size_t)d.nnzh_coo, C.stream));
+        hipLaunchKernelGGL(k_qp_request, dim3(1), dim3(64), 0, C.stream, d, (int)inst, 0, 1.0, 1.0);
+        launch_qp_gather(C);                       // COO -> CSC values of the instance (start flag set, stage 0)
+        hipLaunchKernelGGL(k_mf_test_setup, dim3(1), dim3(64), 0, C.stream, d, (int)inst, hsc, dw, (int)PH_FACTOR);
+        h2d(C, d.Dd + om, Dd, d.m); h2d(C, d.sigp + on, sigp, d.n); h2d(C, d.hd + on, hd, d.n);
+        SQPHIP_HIP_OK(hipMemcpyAsync(d.rtype + om, rtype, sizeof(int) * (size_t)d.m, hipMemcpyHostToDevice, C.stream));
+        std::vector<double> xp(d.Fpad, 0.0), out(d.Fpad), dv(d.Fpad);
+        for (int u = 0; u < S.nu; ++u) xp[S.pos[u]] = rhs[u];
+        double *xv = d.xv + (size_t)inst * d.Fpad;
+        h2d(C, xv, xp.data(), d.Fpad);
+        mf_factor(C, PH_FACTOR, true);
+        mf_solve(C, PH_FACTOR, true);
+        d2h(C, out.data(), xv, d.Fpad); d2h(C, dv.data(), d.dinv + (size_t)inst * d.Fpad, d.Fpad);
+        SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        for (int u = 0; u < S.nu; ++u) {
+            if (sol_fused) sol_fused[u] = out[S.pos[u]];
+            if (dinv_by_unknown) dinv_by_unknown[u] = dv[S.pos[u]];
+        }
+        h2d(C, xv, xp.data(), d.Fpad);
+        mf_solve(C, PH_FACTOR, false);
+        d2h(C, out.data(), xv, d.Fpad);
+        hipLaunchKernelGGL(k_mf_test_setup, dim3(1), dim3(64), 0, C.stream, d, (int)inst, 0.0, 0.0, (int)PH_IDLE);
+        SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        SQPHIP_HIP_OK(hipGetLastError());
+        if (sol_standalone) for (int u = 0; u < S.nu; ++u) sol_standalone[u] = out[S.pos[u]];
         return SQPHIP_OK;
     });
 }
@@ -649,6 +739,19 @@ extern "C" int sqphip_get_counters(sqphip_ctx *h, sqphip_counters *c)
         c->ldlt_seconds = C.tm.factor_seconds; c->trailing_seconds = C.tm.trailing_seconds;
         c->solve_seconds = C.tm.solve_seconds; c->total_seconds = C.total_seconds;
         c->trailing_launches = C.tm.trailing_launches;
+        c->sparse = C.d.sparse; c->nnz_k = 0; c->nnz_l = 0; c->n_supernodes = 0; c->n_levels = 0; c->max_front = 0;
+        c->factor_flops = 0; c->front_doubles = 0; c->cb_doubles = 0; c->factor_launches = 0; c->solve_launches = 0;
+        if (C.d.sparse) {
+            const SparseSym &Y = C.mfp.S;
+            c->nnz_k = C.mfp.nnzK; c->nnz_l = Y.nnzL; c->n_supernodes = Y.ns; c->n_levels = Y.nlevels;
+            c->max_front = Y.max_front; c->factor_flops = Y.flops; c->front_doubles = C.mfp.stride;
+            long cb = 0;
+            for (int q = 0; q < Y.ns; ++q) cb += (long)(Y.sn_nr[q] + 1) * Y.sn_nr[q] - (long)Y.sn_nr[q] * (Y.sn_nr[q] - 1) / 2;
+            c->cb_doubles = cb;
+            c->factor_launches = (int64_t)C.mfp.fac.size();
+            c->solve_launches = (int64_t)(C.mfp.fwd.size() + C.mfp.bwd.size());
+            c->ldlt_flops = (double)nf * Y.flops;
+        }
         return SQPHIP_OK;
     });
 }

@@ -5,6 +5,7 @@
 #include <vector>
 #include "../../include/sqphip.h"
 #include "sqphip_internal.hpp"
+#include "sparse.hpp"
 
 namespace sqphip {
 
@@ -42,6 +43,18 @@ struct SqpState {
 #define SQPHIP_TRACE_COLS 12
 #define SQPHIP_TRACE_CAP 4096
 
+// device view of the multifrontal plan (sparse.hpp, MfPlan) and of the front arena
+struct MfDev {
+    int ns;
+    const int *first, *nc, *nr, *rowptr, *rows, *rel, *child_ptr, *child;
+    const long *off;
+    long stride;                          // doubles of front storage per instance
+    double *fronts;                       // [B][stride]
+    const int *asm_ptr, *dest_loc, *item_ptr;
+    const MfItem *items;
+    const int *sched;
+};
+
 // everything kernels need, by value
 struct DV {
     int n, m, nlin, N, Npad, ld, B;       // N = n + m, Npad = stride of the full-length vectors rhs / sol / wN
@@ -55,6 +68,8 @@ struct DV {
     const int *upos, *uinv;
     int Ts;
     const unsigned char *tmask;           // [remainder tile][leading tile] coupling mask (null: none), order.hip
+    int sparse;                           // 1: multifrontal LDL^T of the sparse matrix (mfront.hip); K is not allocated
+    MfDev mf;
     int nnzj_coo, nnzh_coo, nnzjc, nnzhc;
     // shared structure
     const int *jcolptr, *jrowval, *jrowptr, *jrcol, *jrslot;
@@ -103,6 +118,8 @@ struct Ctx {
     sqphip_options opt;
     DV d;                       // device view (pointers into the arenas below)
     LdltPlan plan;
+    MfPlan mfp;                 // multifrontal plan (d.sparse)
+    long mf_factor_launches = 0;
     Timers tm;
     std::vector<void *> allocs;
     std::string err;
@@ -140,6 +157,9 @@ void ipm_run_all(Ctx &C);            // runs every instance whose IpmState.start
 void ipm_sweep(Ctx &C, bool sqp_level);
 void sqp_stage_kernels(Ctx &C);      // sqp.hip: SQP-level kernels of a sweep
 void launch_qp_gather(Ctx &C);       // COO -> CSC for instances with start set (stage 0)
+// mfront.hip
+void mf_factor(Ctx &C, int want, bool with_rhs);
+void mf_solve(Ctx &C, int want, bool skip_fwd);
 // acopf.hip
 void launch_acopf_eval_point(Ctx &C, int inst, const double *x_dev, double sigma, const double *lam_dev,
                              double *f_dev, double *grad_dev, double *g_dev, double *jcoo_dev,

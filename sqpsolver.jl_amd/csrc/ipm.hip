@@ -825,18 +825,24 @@ void ipm_sweep(Ctx &C, bool sqp_level)
     hipLaunchKernelGGL(k_qp_gather, gB, bT, 0, s, d);
     hipLaunchKernelGGL(k_ipm_start, gB, bT, 0, s, d);
     hipLaunchKernelGGL(k_ipm_prepare, gB, bT, 0, s, d);
-    hipLaunchKernelGGL(k_kkt_assemble, dim3(d.Fpad, d.B), dim3(128), 0, s, d);
+    if (!d.sparse) hipLaunchKernelGGL(k_kkt_assemble, dim3(d.Fpad, d.B), dim3(128), 0, s, d);
     hipLaunchKernelGGL(k_build_rhs, gB, bT, 0, s, d);
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (C.tm.enabled) { ev = C.tm.get(); hipEventRecord(ev.first, s); }
-    ldlt_factor(C.plan, d.K, d.dinv, d.phase, PH_FACTOR, &C.tm, d.xv, d.vv);   // + fused forward elimination of xv
+    // assembly + factorisation, with the forward elimination of xv fused in
+    if (d.sparse) { mf_factor(C, PH_FACTOR, true); C.tm.n_factor++; }
+    else ldlt_factor(C.plan, d.K, d.dinv, d.phase, PH_FACTOR, &C.tm, d.xv, d.vv);
     if (C.tm.enabled) { hipEventRecord(ev.second, s); C.tm.pending_factor.push_back(ev); }
+    auto lin_solve = [&](int want, bool skip_fwd) {
+        if (d.sparse) mf_solve(C, want, skip_fwd);
+        else ldlt_solve(C.plan, d.K, d.dinv, d.xv, d.vv, d.phase, want, skip_fwd);
+    };
     hipLaunchKernelGGL(k_inertia, gB, bT, 0, s, d);
     if (C.tm.enabled) { ev = C.tm.get(); hipEventRecord(ev.first, s); }
     // backward half of the solve (the forward half happened inside the factorisation), then the residual against
     // the sparse operator.  No iterative refinement: one step of it (the policy until late in round 1, two more
     // launch chains per sweep) changed no iteration count on any test problem -- see oracle/qp_ipm.c, kkt_solve.
-    ldlt_solve(C.plan, d.K, d.dinv, d.xv, d.vv, d.phase, PH_SOLVE, true);
+    lin_solve(PH_SOLVE, true);
     // condensed form: one conditional refinement step per direction.  Whether any instance wants it is read back
     // (4 bytes + a stream synchronise, the sweep loop synchronises once per sweep anyway): on most sweeps none
     // does, and 2 x 33 gated-off launches per skipped pass cost more than the round trip.
@@ -851,7 +857,7 @@ void ipm_sweep(Ctx &C, bool sqp_level)
             SQPHIP_HIP_OK(hipStreamSynchronize(s));
             if (C.h_counters[4] == 0) return;
         }
-        ldlt_solve(C.plan, d.K, d.dinv, d.xv, d.vv, d.phase, want, false);
+        lin_solve(want, false);
         hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, 1, want);
     };
     refine_pass((int)PH_SOLVE);
@@ -859,7 +865,7 @@ void ipm_sweep(Ctx &C, bool sqp_level)
         // predictor-corrector mode: centring parameter + second-order terms, then the corrector's right-hand side
         // through the same factors (full forward + backward solve)
         hipLaunchKernelGGL(k_mpc, gB, bT, 0, s, d);
-        ldlt_solve(C.plan, d.K, d.dinv, d.xv, d.vv, d.phase, PH_SOLVE2, false);
+        lin_solve(PH_SOLVE2, false);
         refine_pass((int)PH_SOLVE2);
     }
     if (C.tm.enabled) { hipEventRecord(ev.second, s); C.tm.pending_solve.push_back(ev); }

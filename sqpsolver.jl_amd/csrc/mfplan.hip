@@ -1,0 +1,239 @@
+// mfplan.hip -- host-only: the multifrontal plan of the sparse Newton matrix (assembly lists, front layout, launch
+// schedule) and a host reference of the numeric phase that the CPU tests use to validate the plan.
+//
+// Seat in the reference: Ipopt's linear-solver interface (symbolic + numeric factorisation, MUMPS / MA57;
+// /root/reference/examples/acopf/opf.jl:59-64), reached through /root/reference/src/algorithms/subproblem_JuMP.jl:178.
+// The matrix is the (condensed) Newton matrix of ipm.hip:
+//     [ W + J_I' (D_I + reg)^-1 J_I    J_K' ]     W = hsc H + hd + sigp + (delta_w + reg) I,  K = rows kept in the matrix
+//     [ J_K                       -(D_K + reg) ]
+#include "sparse.hpp"
+#include "../../include/sqphip.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <tuple>
+
+namespace sqphip {
+
+MfPlan mf_build_plan(int n, int m, const std::vector<int> &kpos, int mk, const std::vector<int> &hcolptr,
+                     const std::vector<int> &hrowval, const std::vector<int> &jrowptr, const std::vector<int> &jrcol,
+                     const std::vector<int> &jrslot, const SymOptions &opt)
+{
+    MfPlan P;
+    std::vector<std::vector<int>> adj, before;
+    kkt_graph(n, m, kpos, mk, hcolptr, hrowval, jrowptr, jrcol, adj, before);
+    P.S = sparse_symbolic(n + mk, adj, before, opt);
+    const SparseSym &S = P.S;
+    // front layout: (fs + 1) x fs, 16-byte aligned
+    P.off.resize(S.ns);
+    for (int s = 0; s < S.ns; ++s) {
+        const long fs = S.sn_nc[s] + S.sn_nr[s];
+        P.off[s] = P.stride;
+        P.stride += ((fs + 1) * fs + 1) / 2 * 2;
+    }
+    // assembly lists.  Entry (unknown a, unknown b) of the lower triangle lives in the front of the supernode that
+    // owns the earlier of the two positions.
+    struct Rec { int sn, loc, seq; MfItem it; };
+    std::vector<Rec> recs;
+    auto add = [&](int ua, int ub, MfItem it) {
+        int pa = S.pos[ua], pb = S.pos[ub];
+        if (pa < pb) std::swap(pa, pb);              // pa = row position, pb = column position
+        const int s = S.col2sn[pb], f = S.sn_first[s], nc = S.sn_nc[s], fs = nc + S.sn_nr[s];
+        int li;
+        if (pa < f + nc) li = pa - f;
+        else {
+            const int *R = S.sn_rows.data() + S.sn_rowptr[s];
+            const int *q = std::lower_bound(R, R + S.sn_nr[s], pa);
+            if (q == R + S.sn_nr[s] || *q != pa) { fprintf(stderr, "sqphip: mf_build_plan: entry outside its front\n"); abort(); }
+            li = nc + (int)(q - R);
+        }
+        recs.push_back({s, (pb - f) * (fs + 1) + li, (int)recs.size(), it});
+    };
+    for (int j = 0; j < n; ++j) {
+        add(j, j, {MF_ITEM_VDIAG, -1, j, 0});
+        for (int k = hcolptr[j]; k < hcolptr[j + 1]; ++k) {
+            const int i = hrowval[k];
+            if (i >= j) add(i, j, {MF_ITEM_H, -1, k, 0});      // the mirrored slot (j, i) of the full pattern holds the same value
+        }
+    }
+    for (int i = 0; i < m; ++i) {
+        const int s = jrowptr[i], e = jrowptr[i + 1];
+        if (kpos[i] >= 0) {
+            add(n + kpos[i], n + kpos[i], {MF_ITEM_RDIAG, i, 0, 0});
+            for (int t = s; t < e; ++t) add(n + kpos[i], jrcol[t], {MF_ITEM_JKEPT, i, jrslot[t], 0});
+        } else {
+            for (int a = s; a < e; ++a)
+                for (int b = s; b <= a; ++b) add(jrcol[a], jrcol[b], {MF_ITEM_PAIR, i, jrslot[a], jrslot[b]});
+        }
+    }
+    std::sort(recs.begin(), recs.end(), [](const Rec &x, const Rec &y) {
+        return std::tie(x.sn, x.loc, x.seq) < std::tie(y.sn, y.loc, y.seq); });
+    P.asm_ptr.assign(S.ns + 1, 0);
+    for (size_t r = 0; r < recs.size(); ++r) {
+        const bool fresh = r == 0 || recs[r].sn != recs[r - 1].sn || recs[r].loc != recs[r - 1].loc;
+        if (fresh) {
+            P.dest_loc.push_back(recs[r].loc);
+            P.item_ptr.push_back((int)P.items.size());
+            P.asm_ptr[recs[r].sn + 1]++;
+        }
+        P.items.push_back(recs[r].it);
+    }
+    P.item_ptr.push_back((int)P.items.size());
+    for (int s = 0; s < S.ns; ++s) P.asm_ptr[s + 1] += P.asm_ptr[s];
+    P.nnzK = (long)P.dest_loc.size();
+    // launch schedule: level by level (leaves first); inside a level the fronts are split by size class
+    //   class 0: fs + 1 <= 32      one wave per front, front in LDS
+    //   class 1: fs + 1 <= 90      256 threads per front, front in LDS (<= 64 KB)
+    //   class 2: larger            256 threads per front, in place in the front arena (L2 / HBM)
+    auto cls = [&](int s) { const int r = S.sn_nc[s] + S.sn_nr[s] + 1; return r <= 32 ? 0 : (r <= 90 ? 1 : 2); };
+    for (int l = 0; l < S.nlevels; ++l) {
+        for (int c = 0; c < 3; ++c) {
+            MfLaunch L{(int)P.sched.size(), 0, c == 0 ? 64 : 256, 0};
+            for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; ++q) {
+                const int s = S.level_sn[q];
+                if (cls(s) != c) continue;
+                P.sched.push_back(s);
+                L.count++;
+                const int fs = S.sn_nc[s] + S.sn_nr[s];
+                if (c < 2) L.lds_bytes = std::max(L.lds_bytes, (fs + 1) * fs * 8);
+            }
+            if (L.count) P.fac.push_back(L);
+        }
+    }
+    // solves: one launch per level, one wave per front (the fronts of a level in one block of `sched`)
+    for (int l = 0; l < S.nlevels; ++l) {
+        MfLaunch L{(int)P.sched.size(), S.level_ptr[l + 1] - S.level_ptr[l], 64, 0};
+        for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; ++q) {
+            const int s = S.level_sn[q];
+            P.sched.push_back(s);
+            L.lds_bytes = std::max(L.lds_bytes, (S.sn_nc[s] + S.sn_nr[s]) * 8);     // one vector of the front's height
+        }
+        P.fwd.push_back(L);
+    }
+    P.bwd.assign(P.fwd.rbegin(), P.fwd.rend());
+    return P;
+}
+
+// value of one assembly item (the device twin is mf_item_value in mfront.hip)
+static inline double item_value(const MfItem &it, const MfValues &V)
+{
+    const double reg_p = 1e-8, reg_d = 1e-8;           // IPM_REG_P / IPM_REG_D of ipm.hip
+    switch (it.type) {
+    case MF_ITEM_H: return V.hsc * V.hv[it.a];
+    case MF_ITEM_JKEPT: return V.rtype[it.row] != 0 ? V.jv[it.a] : 0.0;
+    case MF_ITEM_PAIR: return V.rtype[it.row] != 0 ? V.jv[it.a] * V.jv[it.b] / (V.Dd[it.row] + reg_d) : 0.0;
+    case MF_ITEM_VDIAG: return V.hd[it.a] + V.sigp[it.a] + V.dw + reg_p;
+    default: return V.rtype[it.row] != 0 ? -(V.Dd[it.row] + reg_d) : -1.0;
+    }
+}
+
+void mf_host_factor_solve(const MfPlan &P, const MfValues &V, const double *rhs, double *sol, double *dinv)
+{
+    const SparseSym &S = P.S;
+    std::vector<double> F(P.stride, 0.0), x(S.nu), v(S.nu);
+    for (int u = 0; u < S.nu; ++u) x[S.pos[u]] = rhs[u];
+    for (int s = 0; s < S.ns; ++s) {
+        const int nc = S.sn_nc[s], nr = S.sn_nr[s], fs = nc + nr, ld = fs + 1, f0 = S.sn_first[s];
+        double *A = F.data() + P.off[s];
+        for (int e = P.asm_ptr[s]; e < P.asm_ptr[s + 1]; ++e) {
+            double a = 0.0;
+            for (int k = P.item_ptr[e]; k < P.item_ptr[e + 1]; ++k) a += item_value(P.items[k], V);
+            A[P.dest_loc[e]] = a;
+        }
+        for (int j = 0; j < nc; ++j) A[j * ld + fs] = x[f0 + j];
+        for (int q = S.child_ptr[s]; q < S.child_ptr[s + 1]; ++q) {
+            const int c = S.child[q], cnc = S.sn_nc[c], cnr = S.sn_nr[c], cfs = cnc + cnr, cld = cfs + 1;
+            const double *C = F.data() + P.off[c];
+            const int *rel = S.rel.data() + S.sn_rowptr[c];
+            for (int jj = 0; jj < cnr; ++jj)
+                for (int ii = jj; ii <= cnr; ++ii)
+                    A[rel[jj] * ld + (ii < cnr ? rel[ii] : fs)] += C[(cnc + jj) * cld + cnc + ii];
+        }
+        for (int k = 0; k < nc; ++k) {
+            const double d = A[k * ld + k], di = 1.0 / d;
+            dinv[f0 + k] = di;
+            for (int j = k + 1; j < fs; ++j) {
+                const double lj = A[k * ld + j] * di;
+                for (int i = j; i <= fs; ++i) A[j * ld + i] -= A[k * ld + i] * lj;
+            }
+            for (int i = k + 1; i <= fs; ++i) A[k * ld + i] *= di;      // L, and z = D^-1 L^-1 b in the last row
+            v[f0 + k] = A[k * ld + fs];
+        }
+    }
+    // backward: x_cols = L11^-T (z - L21' x_rows), roots first
+    for (int s = S.ns - 1; s >= 0; --s) {
+        const int nc = S.sn_nc[s], nr = S.sn_nr[s], fs = nc + nr, ld = fs + 1, f0 = S.sn_first[s];
+        const double *A = F.data() + P.off[s];
+        const int *R = S.sn_rows.data() + S.sn_rowptr[s];
+        for (int k = nc - 1; k >= 0; --k) {
+            double a = v[f0 + k];
+            for (int i = k + 1; i < nc; ++i) a -= A[k * ld + i] * x[f0 + i];
+            for (int r = 0; r < nr; ++r) a -= A[k * ld + nc + r] * x[R[r]];
+            x[f0 + k] = a;
+        }
+    }
+    for (int u = 0; u < S.nu; ++u) sol[u] = x[S.pos[u]];
+}
+
+}  // namespace sqphip
+
+// C-ABI test hook (host only, no GPU): plan + host reference of the numeric phase for the NLP structure given as in
+// sqphip_create; values in the library's internal layouts (see include/sqphip.h).
+extern "C" int sqphip_mf_host_solve(int64_t n, int64_t m, int64_t nnzJ, const int64_t *jrow, const int64_t *jcol,
+                                    int64_t nnzH, const int64_t *hrow, const int64_t *hcol, const double *gL,
+                                    const double *gU, int32_t condense, const double *Jval, const double *Hval,
+                                    const double *Dd, const double *sigp, const double *hd, const int32_t *rtype,
+                                    double hsc, double dw, const double *rhs, double *sol, double *dinv_by_unknown,
+                                    int32_t *npos)
+{
+    if (n <= 0 || m < 0 || !rhs || !sol) return SQPHIP_EINVAL;
+    using namespace sqphip;
+    // CSC of J with duplicate summation and the full symmetric CSC of H, as sqphip_create builds them
+    struct Ent { int c, r; double v; };
+    auto build = [](int64_t ncols, int64_t nnz, const int64_t *row, const int64_t *col, const double *val, bool sym,
+                    std::vector<int> &colptr, std::vector<int> &rowval, std::vector<double> &vals) {
+        std::vector<Ent> e;
+        for (int64_t k = 0; k < nnz; ++k) {
+            e.push_back({(int)col[k] - 1, (int)row[k] - 1, val[k]});
+            if (sym && row[k] != col[k]) e.push_back({(int)row[k] - 1, (int)col[k] - 1, val[k]});
+        }
+        std::stable_sort(e.begin(), e.end(), [](const Ent &a, const Ent &b) { return std::tie(a.c, a.r) < std::tie(b.c, b.r); });
+        colptr.assign(ncols + 1, 0);
+        for (size_t i = 0; i < e.size(); ++i) {
+            if (i && e[i].c == e[i - 1].c && e[i].r == e[i - 1].r) { vals.back() += e[i].v; continue; }
+            rowval.push_back(e[i].r); vals.push_back(e[i].v); colptr[e[i].c + 1]++;
+        }
+        for (int64_t j = 0; j < ncols; ++j) colptr[j + 1] += colptr[j];
+    };
+    std::vector<int> jcp, jrv, hcp, hrv;
+    std::vector<double> jv, hv;
+    build(n, nnzJ, jrow, jcol, Jval, false, jcp, jrv, jv);
+    build(n, nnzH, hrow, hcol, Hval, true, hcp, hrv, hv);
+    std::vector<int> rptr(m + 1, 0), rcol(jrv.size()), rslot(jrv.size());
+    for (int r : jrv) rptr[r + 1]++;
+    for (int64_t i = 0; i < m; ++i) rptr[i + 1] += rptr[i];
+    {
+        std::vector<int> fill(rptr.begin(), rptr.end() - 1);
+        for (int j = 0; j < (int)n; ++j)
+            for (int s = jcp[j]; s < jcp[j + 1]; ++s) { const int i = jrv[s]; rcol[fill[i]] = j; rslot[fill[i]] = s; fill[i]++; }
+    }
+    std::vector<int> kpos(m > 0 ? m : 1, -1);
+    int mk = 0;
+    for (int64_t i = 0; i < m; ++i)
+        if (!condense || kkt_row_is_kept(gL[i], gU[i], rptr[i + 1] - rptr[i])) kpos[i] = mk++;
+    MfPlan P = mf_build_plan((int)n, (int)m, kpos, mk, hcp, hrv, rptr, rcol, rslot, SymOptions());
+    std::vector<int> rt(m > 0 ? m : 1, 1);
+    for (int64_t i = 0; i < m; ++i) rt[i] = rtype ? rtype[i] : 1;
+    MfValues V{hv.data(), jv.data(), Dd, sigp, hd, rt.data(), hsc, dw};
+    std::vector<double> dinv(P.S.nu);
+    mf_host_factor_solve(P, V, rhs, sol, dinv.data());
+    int np = 0;
+    for (int u = 0; u < P.S.nu; ++u) {
+        const double d = dinv[P.S.pos[u]];
+        if (dinv_by_unknown) dinv_by_unknown[u] = d;
+        if (d > 0.0 && std::isfinite(d)) ++np;
+    }
+    if (npos) *npos = np;
+    return SQPHIP_OK;
+}

@@ -15,6 +15,7 @@
 // join their cluster if the merged cluster still fits a tile.  Components sorted by size (ties: lowest vertex) are packed first-fit into tiles;
 // inside a tile variables come before rows.
 #include "sqphip_internal.hpp"
+#include "sparse.hpp"
 #include "../../include/sqphip.h"
 #include <algorithm>
 #include <numeric>
@@ -189,11 +190,10 @@ KktOrder kkt_order(int n, int m, const std::vector<int> &kpos, int mk, const std
     for (int i = 0; i < m; ++i) {
         const int s = jrowptr[i], e = jrowptr[i + 1];
         if (kpos[i] >= 0) { for (int t = s; t < e; ++t) edge(n + kpos[i], jrcol[t]); }
-        else if (e - s <= 32) { for (int a = s; a < e; ++a) for (int b = a + 1; b < e; ++b) edge(jrcol[a], jrcol[b]); }
-        else {                                             // long row: a chain ties the same cluster
-            for (int a = s; a + 1 < e; ++a) edge(jrcol[a], jrcol[a + 1]);
-            long_rows.emplace_back(jrcol.begin() + s, jrcol.begin() + e);
-        }
+        // an eliminated row is a clique among its variables (rows too long for that stay in the matrix:
+        // kkt_row_is_kept, sparse.hpp -- a chain stood in for the clique of such rows until round 2 and split
+        // coupled variables over different "independent" tiles)
+        else { for (int a = s; a < e; ++a) for (int b = a + 1; b < e; ++b) edge(jrcol[a], jrcol[b]); }
     }
     for (auto &l : adj) { std::sort(l.begin(), l.end()); l.erase(std::unique(l.begin(), l.end()), l.end()); }
     return kkt_order_from_graph(n, nc, adj, rows_last, long_rows);
@@ -210,7 +210,6 @@ extern "C" int sqphip_kkt_order(int64_t n, int64_t m, int64_t nnzJ, const int64_
     if (n <= 0 || m < 0 || !pos) return SQPHIP_EINVAL;
     std::vector<int> kpos(m > 0 ? m : 1, -1);
     int mk = 0;
-    for (int64_t i = 0; i < m; ++i) if (gL[i] == gU[i]) kpos[i] = mk++;
     std::vector<std::vector<int>> hc(n), jr(m);
     for (int64_t k = 0; k < nnzH; ++k) {
         const int r = (int)hrow[k] - 1, c = (int)hcol[k] - 1;
@@ -231,6 +230,8 @@ extern "C" int sqphip_kkt_order(int64_t n, int64_t m, int64_t nnzJ, const int64_
         std::sort(jr[i].begin(), jr[i].end()); jr[i].erase(std::unique(jr[i].begin(), jr[i].end()), jr[i].end());
         jrcol.insert(jrcol.end(), jr[i].begin(), jr[i].end()); jrowptr[i + 1] = (int)jrcol.size();
     }
+    for (int64_t i = 0; i < m; ++i)
+        if (sqphip::kkt_row_is_kept(gL[i], gU[i], jrowptr[i + 1] - jrowptr[i])) kpos[i] = mk++;
     sqphip::KktOrder o = sqphip::kkt_order((int)n, (int)m, kpos, mk, hcolptr, hrowval, jrowptr, jrcol, rows_last != 0);
     for (int u = 0; u < (int)n + mk; ++u) pos[u] = o.pos[u];
     if (n_lead_tiles) *n_lead_tiles = o.Ts;

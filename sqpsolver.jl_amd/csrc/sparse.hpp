@@ -1,0 +1,106 @@
+// sparse.hpp -- symbolic analysis of the sparse Newton matrix (host) and the plan the multifrontal kernels run
+// (mfront.hip).  Not part of the ABI.
+//
+// Seat in the reference: the symbolic phase of the linear solver behind Ipopt (MUMPS / MA57 analysis,
+// /root/reference/examples/acopf/opf.jl:59-64), done once per sparsity structure.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace sqphip {
+
+// Result of the symbolic analysis of one symmetric pattern.
+//   unknown u: variable j (u = j < n) or n + k for the k-th row that stays in the matrix
+//   position:  rank of an unknown in the elimination order
+// Supernodes are numbered in postorder (every child before its parent); the columns of a supernode are
+// contiguous positions [first, first + nc); its front is the dense (nc + nr) x (nc + nr) matrix over
+// [its columns | rows], rows = positions > last column, ascending.
+struct SparseSym {
+    int nu = 0;
+    std::vector<int> pos, inv;
+    int ns = 0;
+    std::vector<int> sn_first, sn_nc, sn_nr, sn_rowptr, sn_rows, sn_parent, sn_level;
+    std::vector<int> col2sn;            // position -> supernode
+    std::vector<int> rel;               // rel[sn_rowptr[c] + k]: index inside the parent's front of row k of child c
+    std::vector<int> child_ptr, child;  // children of every supernode, ascending
+    std::vector<long> front_off;        // offset of front s inside an instance's front arena (doubles); ld = nc + nr
+    long front_total = 0;
+    int nlevels = 0;
+    std::vector<int> level_ptr, level_sn;   // supernodes by level (leaves first), ascending inside a level
+    // statistics
+    long nnzL = 0;          // entries of L the dense fronts hold (explicit zeros of amalgamation included), diagonal excluded
+    long nnzL_exact = 0;    // entries of L without amalgamation
+    double flops = 0;       // multiply-adds x 2 of the dense partial factorisations
+    double flops_exact = 0; // sum over columns of colcount^2 (no amalgamation)
+    int max_front = 0, max_nc = 0;
+};
+
+// which rows stay in the condensed Newton matrix (options.kkt_condense): the equalities, whose block -D sits at the
+// regularisation, and rows too long to eliminate -- the clique J_i' D_i^-1 J_i of a row with k entries has k^2 of
+// them (a dense inequality such as sum(x) <= b would fill the whole matrix).  The oracle applies the same rule
+// (oracle/qp_ipm.c, ora_qp_create).
+constexpr int KKT_LONG_ROW = 32;
+inline bool kkt_row_is_kept(double gl, double gu, int row_nnz) { return gl == gu || row_nnz > KKT_LONG_ROW; }
+
+struct SymOptions {
+    int rows_after_vars = 1;   // a row becomes eligible for elimination only behind every variable it couples to
+    int small_front = 32;      // a child is always merged into its parent while the merged front stays within this
+    double zero_frac = 0.25;   // ... or while the explicit zeros stay below this fraction of the merged supernode's L
+    int order_method = 0;      // 0 approximate minimum degree (constrained), 1 natural order
+};
+
+// adj: symmetric adjacency lists over nu unknowns (sorted, unique, no self loops);
+// need[u] (may be empty): for rows_after_vars, the unknowns that must precede u (the variables of row u)
+SparseSym sparse_symbolic(int nu, const std::vector<std::vector<int>> &adj, const std::vector<std::vector<int>> &before,
+                          const SymOptions &opt);
+
+// the graph of the Newton matrix from the NLP structure: H full symmetric CSC, J CSR; kpos[i] >= 0: row i stays in
+// the matrix (unknown n + kpos[i]), kpos[i] < 0: row i is eliminated (clique among its variables)
+void kkt_graph(int n, int m, const std::vector<int> &kpos, int mk, const std::vector<int> &hcolptr,
+               const std::vector<int> &hrowval, const std::vector<int> &jrowptr, const std::vector<int> &jrcol,
+               std::vector<std::vector<int>> &adj, std::vector<std::vector<int>> &before);
+
+// ---------------------------------------------------------------------------------------------------------------
+// The multifrontal plan: SparseSym plus the assembly lists of the Newton matrix and the launch schedule.
+//
+// Front s of an instance is a dense (fs + 1) x fs column-major block (fs = nc + nr, ld = fs + 1) in the instance's
+// front arena: columns = [columns of the supernode | its rows]; the extra LAST ROW carries a right-hand side through
+// the elimination (fused forward solve: after the partial factorisation its first nc entries are L^-1 b of these
+// columns, the remaining nr are the update this front passes to its ancestors, exactly like the contribution block).
+// After mf_factor: columns 0..nc-1 hold L (unit diagonal implied, rows below), dinv[position] = 1 / D.
+//
+// Assembly: every structural entry of the lower triangle of the Newton matrix has ONE destination (front, local
+// offset) and a fixed list of items that are summed in a fixed order (no atomics, reproducible):
+enum { MF_ITEM_H = 0,        // hsc * hv[a]
+       MF_ITEM_JKEPT = 1,    // jv[a] unless row `row` is free
+       MF_ITEM_PAIR = 2,     // jv[a] * jv[b] / (Dd[row] + reg_d) unless row `row` is free  (eliminated row)
+       MF_ITEM_VDIAG = 3,    // hd[a] + sigp[a] + delta_w + reg_p
+       MF_ITEM_RDIAG = 4 };  // -(Dd[row] + reg_d), or -1 for a free row
+struct MfItem { int type, row, a, b; };
+
+// one kernel launch of the factorisation / of a solve sweep: fronts [begin, begin + count) of `sched`, all of one
+// size class (threads per front, LDS or in-place)
+struct MfLaunch { int begin, count, threads, lds_bytes; };
+
+struct MfPlan {
+    SparseSym S;
+    std::vector<long> off;                       // front offsets (doubles) with the (fs + 1) x fs layout
+    long stride = 0;                             // doubles per instance
+    std::vector<int> asm_ptr, dest_loc, item_ptr; // per front: destinations [asm_ptr[s], asm_ptr[s+1]); per destination: items
+    std::vector<MfItem> items;
+    std::vector<int> sched;                      // fronts in launch order
+    std::vector<MfLaunch> fac, fwd, bwd;
+    long nnzK = 0;                               // structural entries of the lower triangle (destinations)
+};
+
+// kpos / krow as in DV; jcolptr.. = CSC of J, jrowptr/jrcol/jrslot its CSR view, hcolptr/hrowval full symmetric CSC
+MfPlan mf_build_plan(int n, int m, const std::vector<int> &kpos, int mk, const std::vector<int> &hcolptr,
+                     const std::vector<int> &hrowval, const std::vector<int> &jrowptr, const std::vector<int> &jrcol,
+                     const std::vector<int> &jrslot, const SymOptions &opt);
+
+// Host reference of the numeric phase (tests of the plan; never on the product path): assembles from the item lists,
+// factorises front by front, solves K x = rhs.  Vectors in unknown order (variables, then kept rows); dinv by position.
+struct MfValues { const double *hv, *jv, *Dd, *sigp, *hd; const int *rtype; double hsc, dw; };
+void mf_host_factor_solve(const MfPlan &P, const MfValues &V, const double *rhs, double *sol, double *dinv);
+
+}  // namespace sqphip

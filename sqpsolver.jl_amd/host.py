@@ -77,6 +77,34 @@ def kkt_order(n, m, jrow, jcol, hrow, hcol, gL, gU, rows_last=True):
     return pos, ts.value, nf.value
 
 
+def kkt_symbolic(n, m, jrow, jcol, hrow, hcol, gL, gU, condense=True, rows_after_vars=True, small_front=0,
+                 zero_frac=-1.0):
+    """(pos, stats dict) of `sqphip_kkt_symbolic`: the symbolic analysis of the sparse Newton matrix; host-only."""
+    L = _lib.lib()
+    jr, jc, hr, hc = (np.ascontiguousarray(a, dtype=np.int64) for a in (jrow, jcol, hrow, hcol))
+    pos = np.zeros(n + m, dtype=np.int32); st = _lib.SymbolicStats()
+    rc = L.sqphip_kkt_symbolic(n, m, len(jr), _l(jr), _l(jc), len(hr), _l(hr), _l(hc), _d(_f(gL)), _d(_f(gU)),
+                               int(condense), int(rows_after_vars), int(small_front), float(zero_frac), _i(pos), C.byref(st))
+    if rc != 0:
+        raise SqpHipError(f"sqphip_kkt_symbolic failed ({rc})")
+    out = {k: getattr(st, k) for k, _ in _lib.SymbolicStats._fields_}
+    return pos[:out["order"]], out
+
+
+def mf_host_solve(n, m, jrow, jcol, hrow, hcol, gL, gU, condense, jval, hval, Dd, sigp, hd, rtype, hsc, dw, rhs):
+    """Host reference of the multifrontal numeric phase (`sqphip_mf_host_solve`): (sol, dinv_by_unknown, npos)."""
+    L = _lib.lib()
+    jr, jc, hr, hc = (np.ascontiguousarray(a, dtype=np.int64) for a in (jrow, jcol, hrow, hcol))
+    rhs = _f(rhs); sol = np.zeros_like(rhs); dinv = np.zeros_like(rhs); npos = C.c_int32()
+    rt = np.ascontiguousarray(rtype, dtype=np.int32)
+    rc = L.sqphip_mf_host_solve(n, m, len(jr), _l(jr), _l(jc), len(hr), _l(hr), _l(hc), _d(_f(gL)), _d(_f(gU)),
+                                int(condense), _d(_f(jval)), _d(_f(hval)), _d(_f(Dd)), _d(_f(sigp)), _d(_f(hd)), _i(rt),
+                                float(hsc), float(dw), _d(rhs), _d(sol), _d(dinv), C.byref(npos))
+    if rc != 0:
+        raise SqpHipError(f"sqphip_mf_host_solve failed ({rc})")
+    return sol, dinv, npos.value
+
+
 class Context:
     """Owns a sqphip_ctx (one NLP structure, `batch` instances)."""
 
@@ -124,6 +152,14 @@ class Context:
         self.L.sqphip_qp_stats(self.h, C.byref(it), C.byref(nf))
         return dict(p=p, lam=lam, mult_x_U=mu_u, mult_x_L=mu_l, slack=slack, status=st.value,
                     ipm_iters=it.value, n_factor=nf.value)
+
+    def mf_solve_test(self, inst, jval, hval, Dd, sigp, hd, rtype, hsc, dw, rhs):
+        """Kernel-level hook of the multifrontal path: (sol_fused, sol_standalone, dinv_by_unknown)."""
+        rhs = _f(rhs); a = np.zeros_like(rhs); b = np.zeros_like(rhs); dv = np.zeros_like(rhs)
+        rt = np.ascontiguousarray(rtype, dtype=np.int32)
+        self._ck(self.L.sqphip_mf_solve_test(self.h, inst, _d(_f(jval)), _d(_f(hval)), _d(_f(Dd)), _d(_f(sigp)),
+                                             _d(_f(hd)), _i(rt), float(hsc), float(dw), _d(rhs), _d(a), _d(b), _d(dv)))
+        return a, b, dv
 
     # ---- merit path
     def norm_violations(self, E, x, p=1):
