@@ -1,0 +1,40 @@
+"""Phase timing of k_mf_factor (zero / originals / extend-add / eliminate / write-back) per front, instance 0.
+Builds a traced copy of the library (-DSQPHIP_MF_TRACE) into /tmp and runs one batched SQP iteration."""
+import ctypes as C, os, subprocess, sys
+import numpy as np
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+from sqpsolver_jl_amd import _lib
+so = "/tmp/libsqphip_trace.so"
+srcs = [os.path.join(_lib._CSRC, s) for s in _lib.SOURCES]
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w",
+                       "-DSQPHIP_MF_TRACE", "-o", so] + srcs)
+_lib.SO_PATH = so
+import sqpsolver_jl_amd as pkg
+from sqpsolver_jl_amd.acopf_synth import acopf_synth, acopf_layout, contingency, CASES
+case, B = sys.argv[1], int(sys.argv[2])
+nb, ng, nl, seed = CASES[case]
+base = acopf_synth(nb, ng, nl, seed); lay0 = acopf_layout(base)
+ctx = pkg.Context(lay0.n, lay0.m, lay0.num_linear, lay0.jrow, lay0.jcol, lay0.hrow, lay0.hcol, lay0.xL, lay0.xU, lay0.gL,
+                  lay0.gU, pkg.default_options(kkt_mode=2, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1), batch=B)
+ctx.acopf_attach(base, lay0)
+for b in range(B):
+    net = base if b == 0 else contingency(base, b, seed)
+    ctx.acopf_set_instance(b, net, acopf_layout(net))
+ctx.sqp_reset(); ctx.sqp_run(1)
+c = ctx.counters()
+ns = c["n_supernodes"]
+buf = np.zeros((ns, 8), dtype=np.int64)
+L = _lib.lib()
+L.sqphip_mf_trace_read.argtypes = [C.POINTER(C.c_longlong), C.c_int]
+assert L.sqphip_mf_trace_read(buf.ctypes.data_as(C.POINTER(C.c_longlong)), ns) == 0
+d = np.diff(buf[:, :6], axis=1) * 10e-3       # 100 MHz ticks -> microseconds
+tot = d.sum(axis=1)
+order = np.argsort(-tot)
+names = ["zero", "orig", "extadd", "elim", "write"]
+print(f"{case} B={B}: {ns} fronts; sum over fronts (us):", {n: round(float(v), 1) for n, v in zip(names, d.sum(axis=0))})
+print("slowest fronts: idx total | " + " ".join(names))
+for s in order[:12]:
+    print(f"  {s:5d} {tot[s]:8.1f} | " + " ".join(f"{v:7.1f}" for v in d[s]))
+t0 = buf[:, 0].min()
+print("span of the last factorisation (us):", (buf[:, 5].max() - t0) * 10e-3)

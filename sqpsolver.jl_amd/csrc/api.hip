@@ -200,6 +200,16 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
                 M.off = C.upload(P.off);
                 M.asm_ptr = C.upload(P.asm_ptr); M.dest_loc = C.upload(P.dest_loc); M.item_ptr = C.upload(P.item_ptr);
                 M.items = C.upload(P.items); M.sched = C.upload(P.sched);
+                auto nz = [](const std::vector<int> &v) { return v.empty() ? std::vector<int>(1, 0) : v; };
+                M.dest_rc = C.upload(P.dest_rc);
+                M.ea_ptr = C.upload(P.ea_ptr); M.ea_rc = C.upload(nz(P.ea_rc));
+                M.ea_src_ptr = C.upload(P.ea_src_ptr); M.ea_src = C.upload(nz(P.ea_src));
+                M.ev_ptr = C.upload(P.ev_ptr); M.ev_idx = C.upload(nz(P.ev_idx));
+                M.ev_src_ptr = C.upload(P.ev_src_ptr); M.ev_src = C.upload(nz(P.ev_src));
+                M.level_ptr = C.upload(S.level_ptr); M.level_sn = C.upload(S.level_sn);
+                M.nlevels = S.nlevels; M.max_front = S.max_front;
+                M.nnzK = (int)P.nnzK;
+                M.vals = C.dalloc<double>((size_t)B * P.nnzK);
                 M.fronts = C.dalloc<double>((size_t)B * P.stride);
             } else if (d.condense && opt->kkt_tile_order) {
                 KktOrder o = kkt_order(d.n, (int)m, kpos, d.mk, PH.colptr, PH.rowval, rptr, rcol, /*rows_last=*/true);

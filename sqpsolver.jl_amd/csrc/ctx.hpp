@@ -50,9 +50,15 @@ struct MfDev {
     const long *off;
     long stride;                          // doubles of front storage per instance
     double *fronts;                       // [B][stride]
-    const int *asm_ptr, *dest_loc, *item_ptr;
+    const int *asm_ptr, *dest_loc, *dest_rc, *item_ptr;
     const MfItem *items;
+    const int *ea_ptr, *ea_rc, *ea_src_ptr, *ea_src;
+    const int *ev_ptr, *ev_idx, *ev_src_ptr, *ev_src;
+    const int *level_ptr, *level_sn;      // supernodes by level of the assembly tree (leaves first)
+    int nlevels, max_front;
     const int *sched;
+    int nnzK;                             // destinations (structural entries of the lower triangle)
+    double *vals;                         // [B][nnzK] assembled values of the destinations (k_mf_values)
 };
 
 // everything kernels need, by value

@@ -1,10 +1,16 @@
-// dev_util.hpp -- workgroup-level reductions shared by the vector kernels (256-thread workgroups)
+// dev_util.hpp -- workgroup-level reductions shared by the vector kernels
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace sqphip {
 
-#define TPB 256
+// threads of the per-instance vector kernels (interior-point vectors, merit reductions, ACOPF callbacks): these are
+// latency-bound gather loops over O(n + m + nnz) items of ONE instance per workgroup, so the lever is waves in flight
+// per instance.  Measured on MI355X, 512 x IEEE-118: 256 -> 1024 threads, see DESIGN.md section 5.
+#ifndef SQPHIP_VEC_THREADS
+#define SQPHIP_VEC_THREADS 1024
+#endif
+#define TPB SQPHIP_VEC_THREADS
 
 struct OpSum { __device__ static double f(double a, double b) { return a + b; } };
 struct OpMax { __device__ static double f(double a, double b) { return fmax(a, b); } };

@@ -82,28 +82,96 @@ MfPlan mf_build_plan(int n, int m, const std::vector<int> &kpos, int mk, const s
     P.item_ptr.push_back((int)P.items.size());
     for (int s = 0; s < S.ns; ++s) P.asm_ptr[s + 1] += P.asm_ptr[s];
     P.nnzK = (long)P.dest_loc.size();
-    // launch schedule: level by level (leaves first); inside a level the fronts are split by size class
-    //   class 0: fs + 1 <= 32      one wave per front, front in LDS
-    //   class 1: fs + 1 <= 90      256 threads per front, front in LDS (<= 64 KB)
-    //   class 2: larger            256 threads per front, in place in the front arena (L2 / HBM)
-    auto cls = [&](int s) { const int r = S.sn_nc[s] + S.sn_nr[s] + 1; return r <= 32 ? 0 : (r <= 90 ? 1 : 2); };
+    P.dest_rc.resize(P.dest_loc.size());
+    for (int s = 0; s < S.ns; ++s) {
+        const int ld = S.sn_nc[s] + S.sn_nr[s] + 1;
+        for (int e = P.asm_ptr[s]; e < P.asm_ptr[s + 1]; ++e) P.dest_rc[e] = (P.dest_loc[e] % ld) | ((P.dest_loc[e] / ld) << 16);
+    }
+    if (P.stride >= (1L << 31)) { fprintf(stderr, "sqphip: mf_build_plan: front arena too large for 32-bit offsets\n"); abort(); }
+    // extend-add gather lists
+    P.ea_ptr.assign(S.ns + 1, 0);
+    P.ea_src_ptr.push_back(0);
+    {
+        std::vector<std::tuple<int, int, int>> con;      // (column, row, source offset), children ascending
+        for (int s = 0; s < S.ns; ++s) {
+            const int fs = S.sn_nc[s] + S.sn_nr[s];
+            con.clear();
+            for (int q = S.child_ptr[s]; q < S.child_ptr[s + 1]; ++q) {
+                const int c = S.child[q], cnc = S.sn_nc[c], cnr = S.sn_nr[c], cld = cnc + cnr + 1;
+                const int *rel = S.rel.data() + S.sn_rowptr[c];
+                for (int jj = 0; jj < cnr; ++jj)
+                    for (int ii = jj; ii <= cnr; ++ii)
+                        con.emplace_back(rel[jj], ii < cnr ? rel[ii] : fs, (int)(P.off[c] + (long)(cnc + jj) * cld + cnc + ii));
+            }
+            std::stable_sort(con.begin(), con.end(), [](const std::tuple<int, int, int> &a, const std::tuple<int, int, int> &b) {
+                return std::tie(std::get<0>(a), std::get<1>(a)) < std::tie(std::get<0>(b), std::get<1>(b)); });
+            for (size_t r = 0; r < con.size(); ++r) {
+                const bool fresh = r == 0 || std::get<0>(con[r]) != std::get<0>(con[r - 1]) || std::get<1>(con[r]) != std::get<1>(con[r - 1]);
+                if (fresh) {
+                    if (r) P.ea_src_ptr.push_back((int)P.ea_src.size());
+                    P.ea_rc.push_back(std::get<1>(con[r]) | (std::get<0>(con[r]) << 16));
+                    P.ea_ptr[s + 1]++;
+                }
+                P.ea_src.push_back(std::get<2>(con[r]));
+            }
+            if (!con.empty()) P.ea_src_ptr.push_back((int)P.ea_src.size());
+        }
+        for (int s = 0; s < S.ns; ++s) P.ea_ptr[s + 1] += P.ea_ptr[s];
+    }
+    // ... and the vector version for the stand-alone forward solves: a child's update entry jj sits in the last row
+    // of column cnc + jj of its front
+    P.ev_ptr.assign(S.ns + 1, 0);
+    P.ev_src_ptr.push_back(0);
+    {
+        std::vector<std::pair<int, int>> con;            // (local index, source offset)
+        for (int s = 0; s < S.ns; ++s) {
+            con.clear();
+            for (int q = S.child_ptr[s]; q < S.child_ptr[s + 1]; ++q) {
+                const int c = S.child[q], cnc = S.sn_nc[c], cnr = S.sn_nr[c], cfs = cnc + cnr, cld = cfs + 1;
+                const int *rel = S.rel.data() + S.sn_rowptr[c];
+                for (int jj = 0; jj < cnr; ++jj) con.emplace_back(rel[jj], (int)(P.off[c] + (long)(cnc + jj) * cld + cfs));
+            }
+            std::stable_sort(con.begin(), con.end(), [](const std::pair<int, int> &a, const std::pair<int, int> &b) { return a.first < b.first; });
+            for (size_t r = 0; r < con.size(); ++r) {
+                if (r == 0 || con[r].first != con[r - 1].first) {
+                    if (r) P.ev_src_ptr.push_back((int)P.ev_src.size());
+                    P.ev_idx.push_back(con[r].first);
+                    P.ev_ptr[s + 1]++;
+                }
+                P.ev_src.push_back(con[r].second);
+            }
+            if (!con.empty()) P.ev_src_ptr.push_back((int)P.ev_src.size());
+        }
+        for (int s = 0; s < S.ns; ++s) P.ev_ptr[s + 1] += P.ev_ptr[s];
+    }
+    // launch schedule: level by level (leaves first); inside a level the fronts are split by size class = kernel
+    // variant of mfront.hip (T = 16-row tiles of the front with its right-hand-side row):
+    //   class 0: T <= 2    1 wave,  front image in LDS          class 3: T <= 8    4 waves, image in the front arena
+    //   class 1: T <= 4    2 waves, front image in LDS          class 4: T <= 13   8 waves, image in the front arena
+    //   class 2: T == 5    4 waves, front image in LDS          class 5: larger    rank-1 kernel in place (no MFMA)
+    auto tiles = [&](int s) { return (S.sn_nc[s] + S.sn_nr[s] + 1 + 15) / 16; };
+    auto cls = [&](int s) { const int T = tiles(s); return T <= 2 ? 0 : (T <= 4 ? 1 : (T <= 5 ? 2 : (T <= 8 ? 3 : (T <= 13 ? 4 : 5)))); };
+    static const int cls_threads[6] = {64, 128, 256, 256, 512, 256};
     for (int l = 0; l < S.nlevels; ++l) {
-        for (int c = 0; c < 3; ++c) {
-            MfLaunch L{(int)P.sched.size(), 0, c == 0 ? 64 : 256, 0};
+        for (int c = 0; c < 6; ++c) {
+            MfLaunch L{(int)P.sched.size(), 0, cls_threads[c], 0, c, 0};
             for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; ++q) {
                 const int s = S.level_sn[q];
                 if (cls(s) != c) continue;
                 P.sched.push_back(s);
                 L.count++;
-                const int fs = S.sn_nc[s] + S.sn_nr[s];
-                if (c < 2) L.lds_bytes = std::max(L.lds_bytes, (fs + 1) * fs * 8);
+                L.tiles = std::max(L.tiles, tiles(s));
             }
-            if (L.count) P.fac.push_back(L);
+            if (!L.count) continue;
+            // dynamic LDS: [image (16 T)^2 for classes 0-2][panel X and L: 2 x 4 x 16 T][4 x 4 block: 16][1 / D of the columns: 16 T]
+            const int R = 16 * L.tiles;
+            L.lds_bytes = c == 5 ? 0 : 8 * ((c <= 2 ? R * R : 0) + 8 * R + 16 + R);
+            P.fac.push_back(L);
         }
     }
     // solves: one launch per level, one wave per front (the fronts of a level in one block of `sched`)
     for (int l = 0; l < S.nlevels; ++l) {
-        MfLaunch L{(int)P.sched.size(), S.level_ptr[l + 1] - S.level_ptr[l], 64, 0};
+        MfLaunch L{(int)P.sched.size(), S.level_ptr[l + 1] - S.level_ptr[l], 64, 0, 0, 0};
         for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; ++q) {
             const int s = S.level_sn[q];
             P.sched.push_back(s);

@@ -43,6 +43,14 @@ __device__ __forceinline__ double mf_item_value(const MfItem &it, const double *
     }
 }
 
+// phase stamps of the factor kernel (instance 0 only; scripts/gpu_mf_trace.py builds with -DSQPHIP_MF_TRACE)
+#ifdef SQPHIP_MF_TRACE
+__device__ long long g_mf_trace[1 << 16][8];
+#define MF_TR(i) if (inst == 0 && threadIdx.x == 0 && s < (1 << 16)) g_mf_trace[s][i] = (long long)wall_clock64();
+#else
+#define MF_TR(i)
+#endif
+
 // Thread layout inside a front: RL row lanes x (NT / RL) column groups; RL = 16 / 32 / 64 by front height so that a
 // tiny front does not idle three quarters of its lanes.
 template <int NT, bool INPLACE>
@@ -59,9 +67,11 @@ __global__ __launch_bounds__(NT) void k_mf_factor(DV d, int sbegin, int want, in
     const int tid = threadIdx.x;
     const int rl_log = ld <= 16 ? 4 : (ld <= 32 ? 5 : 6);
     const int RL = 1 << rl_log, rlane = tid & (RL - 1), cg = tid >> rl_log, ncg = NT >> rl_log;
+    MF_TR(0)
     // 1. zero
     for (int e = tid; e < ld * fs; e += NT) F[e] = 0.0;
     __syncthreads();
+    MF_TR(1)
     // 2. structural entries of the Newton matrix that live in this front, right-hand side row
     {
         const IpmState &st = d.ist[inst];
@@ -80,6 +90,7 @@ __global__ __launch_bounds__(NT) void k_mf_factor(DV d, int sbegin, int want, in
         }
     }
     __syncthreads();
+    MF_TR(2)
     // 3. extend-add of the children's contribution blocks (rows cnc.. of columns cnc.. of the child's front, its
     //    right-hand-side row included), one child after the other: two children may hit the same entry
     for (int q = M.child_ptr[s]; q < M.child_ptr[s + 1]; ++q) {
@@ -94,6 +105,7 @@ __global__ __launch_bounds__(NT) void k_mf_factor(DV d, int sbegin, int want, in
         }
         __syncthreads();
     }
+    MF_TR(3)
     // 4. eliminate the nc columns of the supernode: right-looking, one barrier per column.  Column k keeps the
     //    unscaled entries d_k L_ik (nobody writes it after step k - 1); L_jk = F_jk / d_k is formed on the fly.
     for (int k = 0; k < nc; ++k) {
@@ -106,6 +118,7 @@ __global__ __launch_bounds__(NT) void k_mf_factor(DV d, int sbegin, int want, in
         }
         __syncthreads();
     }
+    MF_TR(4)
     // 5. results: L (scaled) and 1 / D, z = D^-1 L^-1 b, contribution block with its right-hand-side row
     double *dinv = d.dinv + (long)inst * d.Fpad + f0, *vv = d.vv + (long)inst * d.Fpad + f0;
     for (int j = cg; j < fs; j += ncg) {
@@ -119,51 +132,235 @@ __global__ __launch_bounds__(NT) void k_mf_factor(DV d, int sbegin, int want, in
             for (int i = j + rlane; i <= fs; i += RL) Gj[i] = Fj[i];
         }
     }
+    MF_TR(5)
+}
+
+#ifdef SQPHIP_MF_TRACE
+extern "C" int sqphip_mf_trace_read(long long *out, int nfronts)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mf_trace), sizeof(long long) * 8 * (size_t)nfronts);
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------
+// values of the structural entries of the Newton matrix: one thread per destination, the items of a destination
+// summed in list order.  Flat over the whole matrix and batch, so the latency-bound gather (item -> slot -> value)
+// runs at full occupancy and off the level-by-level critical path of the front kernels.
+__global__ __launch_bounds__(256) void k_mf_values(DV d, int want)
+{
+    const int inst = blockIdx.y;
+    if (d.phase[inst] != want) return;
+    const MfDev &M = d.mf;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= M.nnzK) return;
+    const IpmState &st = d.ist[inst];
+    const double *hv = d.hv + (long)inst * d.nnzhc, *jv = d.jv + (long)inst * d.nnzjc;
+    const double *Dd = d.Dd + (long)inst * d.m, *sigp = d.sigp + (long)inst * d.n, *hd = d.hd + (long)inst * d.n;
+    const int *rt = d.rtype + (long)inst * d.m;
+    double a = 0.0;
+    for (int k = M.item_ptr[e]; k < M.item_ptr[e + 1]; ++k) a += mf_item_value(M.items[k], hv, jv, Dd, sigp, hd, rt, st.hsc, st.dw);
+    M.vals[(long)inst * M.nnzK + e] = a;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The front kernel: one workgroup of NW waves per (front, instance).
+//   1. front image (LDS for fronts up to 80 rows, else the front's own storage in the arena): zero, the assembled
+//      values of its structural entries, the right-hand side row, the children's contribution blocks through the
+//      gather lists of the plan (one thread per receiving entry, sources in fixed order -- no barrier per child);
+//   2. the image moves into MFMA accumulator registers: the lower-triangular 16 x 16 tiles of the front are dealt
+//      round-robin to the waves, lane (l15, l4), element rr of a tile <-> row 16 ti + l15, column 16 tj + l4 + 4 rr;
+//   3. elimination four columns at a time: the 4 x 4 diagonal block goes through LDS to every lane (a uniform
+//      scalar LDL^T), each row of the panel is solved by three wave shuffles between the lane groups l4 = 0..3 that
+//      hold its four entries, the panel (X = L D and L, rows below the block only) is published in LDS and every
+//      tile receives the rank-4 update as ONE v_mfma_f64_16x16x4_f64: the accumulator layout of the panel is the
+//      B-operand layout already.  Two barriers per four columns; nothing but the panel touches LDS.
+//   4. L (scaled), 1 / D, D^-1 L^-1 b and the contribution block go back to the arena from the registers.
+// Explicit zeros of the padding (rows / columns beyond the front) stay zero: an all-zero panel row updates nothing.
+typedef double d4 __attribute__((ext_vector_type(4)));
 
-// forward substitution of one front by one wave: x (d.xv) holds the right-hand side in elimination order; on return
-// d.vv holds D^-1 L^-1 b for the columns of the front and the update for the ancestors sits in the last row of the
-// front's contribution block
-__global__ __launch_bounds__(64) void k_mf_fwd(DV d, int sbegin, int want, int generic)
+template <int NW, int MAXT, bool LDSIMG>
+__global__ __launch_bounds__(64 * NW) void k_mf_factor2(DV d, int sbegin, int want, int with_rhs, int Tl)
 {
+    constexpr int NT = 64 * NW;
     const int inst = blockIdx.y;
     if (d.phase[inst] != want) return;
     const MfDev &M = d.mf;
     const int s = M.sched[sbegin + blockIdx.x];
     const int nc = M.nc[s], nr = M.nr[s], fs = nc + nr, ld = fs + 1, f0 = M.first[s];
+    const double *arena = M.fronts + (long)inst * M.stride;
     double *G = M.fronts + (long)inst * M.stride + M.off[s];
-    const int lane = threadIdx.x;
     extern __shared__ double mf_lds[];
-    double *y = mf_lds;                       // fs entries (the launch sizes it for its largest front)
+    const int R = 16 * Tl;
+    double *Xp = mf_lds + (LDSIMG ? R * R : 0), *Lp = Xp + 4 * R, *blk = Lp + 4 * R, *dl = blk + 16;
+    double *F = LDSIMG ? mf_lds : G;
+    const int LD = LDSIMG ? R : ld;
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = (ld + 15) >> 4;
+    MF_TR(0)
+    // 1. image
+    if (LDSIMG) {
+        // the 16 T x 16 T corner of the R x R image; R = 16 T for most fronts of a launch: one flat loop
+        if (T == Tl) for (int e = tid; e < R * R; e += NT) F[e] = 0.0;
+        else for (int e = tid; e < 256 * T * T; e += NT) F[(e / (16 * T)) * LD + e % (16 * T)] = 0.0;
+    } else for (int e = tid; e < ld * fs; e += NT) F[e] = 0.0;
+    __syncthreads();
+    MF_TR(1)
+    {
+        const double *vals = M.vals + (long)inst * M.nnzK;
+        for (int e = M.asm_ptr[s] + tid; e < M.asm_ptr[s + 1]; e += NT) {
+            const int rc = M.dest_rc[e];
+            F[(rc >> 16) * LD + (rc & 0xffff)] = vals[e];
+        }
+        if (with_rhs) {
+            const double *b = d.xv + (long)inst * d.Fpad + f0;
+            for (int j = tid; j < nc; j += NT) F[j * LD + fs] = b[j];
+        }
+    }
+    __syncthreads();
+    MF_TR(2)
+    for (int t = M.ea_ptr[s] + tid; t < M.ea_ptr[s + 1]; t += NT) {
+        double a = 0.0;
+        for (int q = M.ea_src_ptr[t]; q < M.ea_src_ptr[t + 1]; ++q) a += arena[M.ea_src[q]];
+        const int rc = M.ea_rc[t];
+        F[(rc >> 16) * LD + (rc & 0xffff)] += a;
+    }
+    __syncthreads();
+    MF_TR(3)
+    // 2. tiles into registers
+    int ti_[MAXT], tj_[MAXT];
+    d4 acc[MAXT];
+#pragma unroll
+    for (int q = 0; q < MAXT; ++q) {
+        int rem = q * NW + wave, tj = 0;
+        while (tj < T && rem >= T - tj) { rem -= T - tj; ++tj; }
+        const bool valid = tj < T;
+        const int ti = tj + rem;
+        ti_[q] = valid ? ti : -1; tj_[q] = tj;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int col = 16 * tj + l4 + 4 * rr, row = 16 * ti + l15;
+            const bool in = valid && (LDSIMG || (row <= fs && col < fs));
+            acc[q][rr] = in ? F[col * LD + row] : 0.0;
+        }
+    }
+    __syncthreads();
+    // 3. elimination, four columns at a time
+    for (int tk = 0; 16 * tk < nc; ++tk) {
+#pragma unroll
+        for (int rr0 = 0; rr0 < 4; ++rr0) {
+            const int k0 = 16 * tk + 4 * rr0;
+            if (k0 >= nc) break;
+            const int bw = nc - k0 < 4 ? nc - k0 : 4;
+#pragma unroll
+            for (int q = 0; q < MAXT; ++q)
+                if (ti_[q] == tk && tj_[q] == tk) {
+                    const int a = l15 - 4 * rr0;
+                    if (a >= 0 && a < 4) blk[a * 4 + l4] = acc[q][rr0];
+                }
+            __syncthreads();
+            // the block's LDL^T, same numbers in every lane; columns beyond bw (a partial last block) eliminate nothing
+            double a10 = blk[4], a11 = blk[5], a20 = blk[8], a21 = blk[9], a22 = blk[10], a30 = blk[12], a31 = blk[13],
+                   a32 = blk[14], a33 = blk[15];
+            double i1 = 0.0, i2 = 0.0, i3 = 0.0, l21 = 0.0, l31 = 0.0, l32 = 0.0;
+            const double i0 = 1.0 / blk[0];
+            const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
+            a11 -= l10 * a10; a21 -= l10 * a20; a22 -= l20 * a20; a31 -= l10 * a30; a32 -= l20 * a30; a33 -= l30 * a30;
+            if (bw > 1) { i1 = 1.0 / a11; l21 = a21 * i1; l31 = a31 * i1; a22 -= l21 * a21; a32 -= l21 * a31; a33 -= l31 * a31; }
+            if (bw > 2) { i2 = 1.0 / a22; l32 = a32 * i2; a33 -= l32 * a32; }
+            if (bw > 3) i3 = 1.0 / a33;
+            const double lc0 = l4 == 1 ? l10 : (l4 == 2 ? l20 : (l4 == 3 ? l30 : 0.0));
+            const double lc1 = l4 == 2 ? l21 : (l4 == 3 ? l31 : 0.0);
+            const double lc2 = l4 == 3 ? l32 : 0.0;
+            const double ic = l4 == 0 ? i0 : (l4 == 1 ? i1 : (l4 == 2 ? i2 : i3));
+#pragma unroll
+            for (int q = 0; q < MAXT; ++q)
+                if (tj_[q] == tk && ti_[q] >= 0) {
+                    double x = acc[q][rr0];
+                    x -= __shfl(x, l15) * lc0;
+                    x -= __shfl(x, l15 + 16) * lc1;
+                    x -= __shfl(x, l15 + 32) * lc2;
+                    acc[q][rr0] = x;
+                    const int row = 16 * ti_[q] + l15;
+                    Xp[l4 * R + row] = x;
+                    Lp[l4 * R + row] = row >= k0 + 4 ? x * ic : 0.0;
+                }
+            if (tid < bw) dl[k0 + tid] = tid == 0 ? i0 : (tid == 1 ? i1 : (tid == 2 ? i2 : i3));
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < MAXT; ++q)
+                if (ti_[q] >= 0 && tj_[q] >= tk) {
+                    const double b = Xp[l4 * R + 16 * ti_[q] + l15];
+                    const double a = -Lp[l4 * R + 16 * tj_[q] + l15];
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[q], 0, 0, 0);
+                }
+        }
+    }
+    __syncthreads();
+    MF_TR(4)
+    // 4. results
+    double *dinv = d.dinv + (long)inst * d.Fpad + f0, *vv = d.vv + (long)inst * d.Fpad + f0;
+#pragma unroll
+    for (int q = 0; q < MAXT; ++q) {
+        if (ti_[q] < 0) continue;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int col = 16 * tj_[q] + l4 + 4 * rr, row = 16 * ti_[q] + l15;
+            const double v = acc[q][rr];
+            if (col < nc) {
+                if (row > col && row < fs) G[(long)col * ld + row] = v * dl[col];
+                else if (row == fs && with_rhs) vv[col] = v * dl[col];
+            } else if (col < fs && row >= col && row <= fs) G[(long)col * ld + row] = v;
+        }
+    }
+    for (int k = tid; k < nc; k += NT) dinv[k] = dl[k];
+    MF_TR(5)
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Triangular solves.  One WAVE per front; `y` is the wave's LDS vector (height of the largest front).  Between the
+// lanes of one wave LDS accesses are ordered by the hardware; wave_sync() only keeps the compiler from moving them.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// forward substitution of one front: d.xv holds the right-hand side in elimination order; on return d.vv holds
+// D^-1 L^-1 b for the columns of the front and the update for the ancestors sits in the last row of the front's
+// contribution block (where the fused elimination of k_mf_factor2 leaves it too)
+__device__ __forceinline__ void mf_front_fwd(const DV &d, int inst, int s, double *y, int lane, int generic)
+{
+    const MfDev &M = d.mf;
+    const int nc = M.nc[s], nr = M.nr[s], fs = nc + nr, ld = fs + 1, f0 = M.first[s];
+    const double *arena = M.fronts + (long)inst * M.stride;
+    double *G = M.fronts + (long)inst * M.stride + M.off[s];
     const double *b = d.xv + (long)inst * d.Fpad + f0;
     for (int i = lane; i < fs; i += 64) y[i] = i < nc ? b[i] : 0.0;
-    __syncthreads();
-    for (int q = M.child_ptr[s]; q < M.child_ptr[s + 1]; ++q) {
-        const int c = M.child[q];
-        const int cnc = M.nc[c], cnr = M.nr[c], cfs = cnc + cnr, cld = cfs + 1;
-        const double *Cg = M.fronts + (long)inst * M.stride + M.off[c];
-        const int *rel = M.rel + M.rowptr[c];
-        for (int jj = lane; jj < cnr; jj += 64) y[rel[jj]] += Cg[(long)(cnc + jj) * cld + cfs];
-        __syncthreads();
+    wave_sync();
+    // updates of the children through the gather lists (one lane per receiving entry, sources in fixed order)
+    for (int t = M.ev_ptr[s] + lane; t < M.ev_ptr[s + 1]; t += 64) {
+        double a = 0.0;
+        for (int q = M.ev_src_ptr[t]; q < M.ev_src_ptr[t + 1]; ++q) a += arena[M.ev_src[q]];
+        y[M.ev_idx[t]] += a;
     }
+    wave_sync();
     const double *dinv = d.dinv + (long)inst * d.Fpad + f0;
     double *vv = d.vv + (long)inst * d.Fpad + f0;
     if (nc <= 64 && !generic) {
         // lane i owns y_i of the triangular part; y_k travels by a wave shuffle (no barrier, loads pipeline freely)
         double yi = lane < nc ? y[lane] : 0.0;
-#pragma unroll 4
+#pragma unroll 8
         for (int k = 0; k < nc - 1; ++k) {
             const double l = (lane > k && lane < nc) ? G[(long)k * ld + lane] : 0.0;
             const double yk = __shfl(yi, k);
             yi -= l * yk;
         }
         if (lane < nc) { y[lane] = yi; vv[lane] = yi * dinv[lane]; }
-        __syncthreads();
+        wave_sync();
         for (int i = nc + lane; i < fs; i += 64) {
             double acc = y[i];
-#pragma unroll 4
+#pragma unroll 8
             for (int k = 0; k < nc; ++k) acc -= G[(long)k * ld + i] * y[k];
             G[(long)i * ld + fs] = acc;
         }
@@ -171,39 +368,33 @@ __global__ __launch_bounds__(64) void k_mf_fwd(DV d, int sbegin, int want, int g
         for (int k = 0; k < nc; ++k) {
             const double yk = y[k];
             for (int i = k + 1 + lane; i < fs; i += 64) y[i] -= G[(long)k * ld + i] * yk;
-            __syncthreads();
+            wave_sync();
         }
         for (int k = lane; k < nc; k += 64) vv[k] = y[k] * dinv[k];
         for (int i = nc + lane; i < fs; i += 64) G[(long)i * ld + fs] = y[i];
     }
 }
 
-// backward substitution of one front by one wave: x_cols = L11^-T (vv_cols - L21' x_rows) into d.xv
-__global__ __launch_bounds__(64) void k_mf_bwd(DV d, int sbegin, int want, int generic)
+// backward substitution of one front: x_cols = L11^-T (vv_cols - L21' x_rows) into d.xv
+__device__ __forceinline__ void mf_front_bwd(const DV &d, int inst, int s, double *x, int lane, int generic)
 {
-    const int inst = blockIdx.y;
-    if (d.phase[inst] != want) return;
     const MfDev &M = d.mf;
-    const int s = M.sched[sbegin + blockIdx.x];
     const int nc = M.nc[s], nr = M.nr[s], fs = nc + nr, ld = fs + 1, f0 = M.first[s];
     const double *G = M.fronts + (long)inst * M.stride + M.off[s];
-    const int lane = threadIdx.x;
-    extern __shared__ double mf_lds[];
-    double *x = mf_lds;
     double *xg = d.xv + (long)inst * d.Fpad;
     const double *vv = d.vv + (long)inst * d.Fpad + f0;
     const int *rows = M.rows + M.rowptr[s];
     for (int i = lane; i < fs; i += 64) x[i] = i < nc ? vv[i] : xg[rows[i - nc]];
-    __syncthreads();
+    wave_sync();
     if (nc <= 64 && !generic) {
         // lane k owns column k: its own dot product with x_rows, then the unit upper triangular solve by shuffles
         double t = lane < nc ? x[lane] : 0.0;
         if (lane < nc) {
             const double *Gk = G + (long)lane * ld;
-#pragma unroll 4
+#pragma unroll 8
             for (int i = nc; i < fs; ++i) t -= Gk[i] * x[i];
         }
-#pragma unroll 4
+#pragma unroll 8
         for (int i = nc - 1; i > 0; --i) {
             const double l = lane < i ? G[(long)lane * ld + i] : 0.0;
             const double xi = __shfl(t, i);
@@ -217,9 +408,49 @@ __global__ __launch_bounds__(64) void k_mf_bwd(DV d, int sbegin, int want, int g
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
             if (lane == 0) x[k] -= a;
-            __syncthreads();
+            wave_sync();
         }
         for (int k = lane; k < nc; k += 64) xg[f0 + k] = x[k];
+    }
+}
+
+// level-by-level launches: one wave per (front of the level, instance) -- few instances, wide levels
+__global__ __launch_bounds__(64) void k_mf_fwd(DV d, int sbegin, int want, int generic)
+{
+    const int inst = blockIdx.y;
+    if (d.phase[inst] != want) return;
+    extern __shared__ double mf_lds[];
+    mf_front_fwd(d, inst, d.mf.sched[sbegin + blockIdx.x], mf_lds, threadIdx.x, generic);
+}
+
+__global__ __launch_bounds__(64) void k_mf_bwd(DV d, int sbegin, int want, int generic)
+{
+    const int inst = blockIdx.y;
+    if (d.phase[inst] != want) return;
+    extern __shared__ double mf_lds[];
+    mf_front_bwd(d, inst, d.mf.sched[sbegin + blockIdx.x], mf_lds, threadIdx.x, generic);
+}
+
+// whole solve of one instance by ONE workgroup of NWV waves: the waves deal out the fronts of a level, a workgroup
+// barrier closes the level (the vectors live in global memory, visible CU-wide after the barrier).  With hundreds of
+// instances in flight this fills the chip without a launch per level: 2 x levels launches become one.
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void k_mf_solve_inst(DV d, int want, int do_fwd, int generic)
+{
+    const int inst = blockIdx.x;
+    if (d.phase[inst] != want) return;
+    const MfDev &M = d.mf;
+    extern __shared__ double mf_lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double *y = mf_lds + (long)wave * M.max_front;
+    if (do_fwd)
+        for (int l = 0; l < M.nlevels; ++l) {
+            for (int q = M.level_ptr[l] + wave; q < M.level_ptr[l + 1]; q += NWV) mf_front_fwd(d, inst, M.level_sn[q], y, lane, generic);
+            __syncthreads();
+        }
+    for (int l = M.nlevels - 1; l >= 0; --l) {
+        for (int q = M.level_ptr[l] + wave; q < M.level_ptr[l + 1]; q += NWV) mf_front_bwd(d, inst, M.level_sn[q], y, lane, generic);
+        __syncthreads();
     }
 }
 
@@ -234,14 +465,20 @@ void mf_factor(Ctx &C, int want, bool with_rhs)
 {
     const DV &d = C.d;
     hipStream_t s = C.stream;
+    static const bool v1 = getenv("SQPHIP_MF_V1") != nullptr;      // cross-check: the plain rank-1 kernel for every front
+    const int wr = (int)with_rhs;
+    if (!v1) hipLaunchKernelGGL(k_mf_values, dim3((d.mf.nnzK + 255) / 256, d.B), dim3(256), 0, s, d, want);
     for (const MfLaunch &L : C.mfp.fac) {
         const dim3 grid(L.count, d.B);
-        if (L.threads == 64)
-            hipLaunchKernelGGL((k_mf_factor<64, false>), grid, dim3(64), L.lds_bytes, s, d, L.begin, want, (int)with_rhs);
-        else if (L.lds_bytes > 0)
-            hipLaunchKernelGGL((k_mf_factor<256, false>), grid, dim3(256), L.lds_bytes, s, d, L.begin, want, (int)with_rhs);
-        else
-            hipLaunchKernelGGL((k_mf_factor<256, true>), grid, dim3(256), 0, s, d, L.begin, want, (int)with_rhs);
+        const int cls = v1 ? 5 : L.cls;
+        switch (cls) {
+        case 0: hipLaunchKernelGGL((k_mf_factor2<1, 3, true>), grid, dim3(64), L.lds_bytes, s, d, L.begin, want, wr, L.tiles); break;
+        case 1: hipLaunchKernelGGL((k_mf_factor2<2, 5, true>), grid, dim3(128), L.lds_bytes, s, d, L.begin, want, wr, L.tiles); break;
+        case 2: hipLaunchKernelGGL((k_mf_factor2<4, 4, true>), grid, dim3(256), L.lds_bytes, s, d, L.begin, want, wr, L.tiles); break;
+        case 3: hipLaunchKernelGGL((k_mf_factor2<4, 9, false>), grid, dim3(256), L.lds_bytes, s, d, L.begin, want, wr, L.tiles); break;
+        case 4: hipLaunchKernelGGL((k_mf_factor2<8, 12, false>), grid, dim3(512), L.lds_bytes, s, d, L.begin, want, wr, L.tiles); break;
+        default: hipLaunchKernelGGL((k_mf_factor<256, true>), grid, dim3(256), 0, s, d, L.begin, want, wr); break;
+        }
     }
     C.mf_factor_launches += (long)C.mfp.fac.size();
 }
@@ -252,6 +489,12 @@ void mf_solve(Ctx &C, int want, bool skip_fwd)
     const DV &d = C.d;
     hipStream_t s = C.stream;
     const int generic = mf_generic_solves();
+    // one workgroup per instance when the batch alone fills the chip, else a launch per level
+    static const int inst_min = getenv("SQPHIP_MF_INST_SOLVE_MIN") ? atoi(getenv("SQPHIP_MF_INST_SOLVE_MIN")) : 128;
+    if (d.B >= inst_min && d.mf.max_front * 8 * 16 <= 64 * 1024) {
+        hipLaunchKernelGGL(k_mf_solve_inst<16>, dim3(d.B), dim3(1024), (size_t)d.mf.max_front * 8 * 16, s, d, want, skip_fwd ? 0 : 1, generic);
+        return;
+    }
     if (!skip_fwd)
         for (const MfLaunch &L : C.mfp.fwd)
             hipLaunchKernelGGL(k_mf_fwd, dim3(L.count, d.B), dim3(64), L.lds_bytes, s, d, L.begin, want, generic);

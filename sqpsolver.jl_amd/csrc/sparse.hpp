@@ -79,8 +79,9 @@ enum { MF_ITEM_H = 0,        // hsc * hv[a]
 struct MfItem { int type, row, a, b; };
 
 // one kernel launch of the factorisation / of a solve sweep: fronts [begin, begin + count) of `sched`, all of one
-// size class (threads per front, LDS or in-place)
-struct MfLaunch { int begin, count, threads, lds_bytes; };
+// size class.  Factorisation: cls = kernel variant (mfront.hip, mf_factor), tiles = 16-row tiles of the largest front
+// of the launch (sizes the LDS image), lds_bytes = dynamic LDS.
+struct MfLaunch { int begin, count, threads, lds_bytes, cls, tiles; };
 
 struct MfPlan {
     SparseSym S;
@@ -88,6 +89,15 @@ struct MfPlan {
     long stride = 0;                             // doubles per instance
     std::vector<int> asm_ptr, dest_loc, item_ptr; // per front: destinations [asm_ptr[s], asm_ptr[s+1]); per destination: items
     std::vector<MfItem> items;
+    // per front: (row | column << 16) of each destination, for kernels that keep the front in another leading dimension
+    std::vector<int> dest_rc;
+    // extend-add as a gather: per front the entries that receive contributions [ea_ptr[s], ea_ptr[s+1]), each with
+    // its position (row | column << 16) and its sources [ea_src_ptr[t], ea_src_ptr[t+1]) = offsets into the
+    // instance's front arena, children in ascending order (fixed summation order, no barrier between children)
+    std::vector<int> ea_ptr, ea_rc, ea_src_ptr, ea_src;
+    // the same for vectors (forward solves): per front the local indices that receive a child's update
+    // [ev_ptr[s], ev_ptr[s+1]), each with its sources (offsets of the children's update entries in the arena)
+    std::vector<int> ev_ptr, ev_idx, ev_src_ptr, ev_src;
     std::vector<int> sched;                      // fronts in launch order
     std::vector<MfLaunch> fac, fwd, bwd;
     long nnzK = 0;                               // structural entries of the lower triangle (destinations)
