@@ -1,18 +1,26 @@
 #!/usr/bin/env python3
 """Headline benchmark: QP sub-problems per second of the batched SQP-TR hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+           bench.py --gpus N --steps K --warmup W          (one rank per GPU; --gpus must equal WORLD_SIZE)
 
-One "step" = one SQP-TR outer iteration of every instance of the rank's batch: device ACOPF
-evaluation, the trust-region QP (or feasibility-restoration / second-order-correction) sub-problem
-solved by the on-device interior-point method, merit + ratio test.  Workload at N = 1: the per-GPU
-shard of BASELINE.json configs[3] -- 64 IEEE-118-shaped ACOPF contingency scenarios (512 over 8 GPUs,
-weak scaling: 64 per rank), KKT order 2813 condensed to 2069 (options.kkt_condense) and ordered into 23 independent
-leading tiles + a dense remainder of 673 (options.kkt_tile_order), fp64 LDL^T, synthetic
-data of that shape, SQP options of
-/root/reference/examples/acopf/opf.jl:76-79.  Inputs are resident in HBM before the timed region.
-Ranks never exchange iterates; the timed region ends with one all-gather of (ret, iter, done) per
-instance over RCCL.  Prints ONE JSON line on rank 0.
+One "step" = one SQP-TR outer iteration of every instance of the job: device ACOPF evaluation, the trust-region QP
+(or feasibility-restoration / second-order-correction) sub-problem solved by the on-device interior-point method,
+merit + ratio test.  Workload: BASELINE.json configs[3] -- 512 IEEE-118-shaped ACOPF contingency scenarios, ALL of
+them on one GPU at N = 1 and 512 / N per rank at N > 1 (strong scaling); Newton matrix of order 2813 condensed to 2069,
+factorised by the multifrontal path (options.kkt_mode = 0 picks it), fp64, synthetic data of that shape, SQP options
+of /root/reference/examples/acopf/opf.jl:76-79.  Inputs are resident in HBM before the timed region.  Ranks never
+exchange iterates; the timed region ends with one all-gather of (ret, iter, done) per instance over RCCL
+(sqphip_gather_status).  Prints ONE JSON line on rank 0.
+
+Besides the contract's fields the line carries (rank 0, outside the timed region):
+  roofline       the multifrontal factor + solve kernels against the HBM roof (B_sparse)
+  dense_ldlt     the dense MFMA LDL^T of round 1 on its own (N = 2813, 64 instances): ms and TFLOP/s of N^3/3 vs 78.6
+  termination    the same 512 scenarios run until every instance has terminated (at most 60 outer iterations), with
+                 the reference's Hessian sign (literal_quirks = 1: the sub-problems are non-convex and most runs hit
+                 the limit) and with the textbook sign (literal_quirks = 0: nearly all converge)
+  cpu_baseline   the CPU restatement (oracle/, its own sparse LDL^T), instances spread over the host cores
 """
 from __future__ import annotations
 
@@ -27,6 +35,15 @@ sys.path.insert(0, _ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet fp64 matrix peak; MI355X_MICROARCH.md has no fp64 row.  The on-box
                                # register-resident MFMA probe (printed next to it) sustains 77.6 of it.
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~ 8 TB/s
+DEFAULT_BATCH = {"case14": 512, "case118": 512, "case1354": 32, "case9241": 4}
+
+
+def host_cores():
+    try:
+        return max(1, min(16, len(os.sched_getaffinity(0))))   # the GPU box grants 16 host cores per GPU
+    except AttributeError:
+        return max(1, min(16, os.cpu_count() or 1))
 
 
 def main():
@@ -34,23 +51,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="case118", choices=["case14", "case118"])
-    ap.add_argument("--batch", type=int, default=64, help="instances per GPU")
-    ap.add_argument("--groups", type=int, default=1,
-                    help="instance groups per GPU, each a context with its own HIP stream pair, driven "
-                         "concurrently so that the latency-bound panel / solve phases of one group "
-                         "overlap the MFMA-bound updates of another (2 gives about +5 % QP/s on MI355X but the "
-                         "HIP-event kernel timing then includes queueing behind the other group, so the "
-                         "default keeps one group and a clean roofline measurement)")
+    ap.add_argument("--workload", default="case118", choices=["case14", "case118", "case1354", "case9241"])
+    ap.add_argument("--batch", type=int, default=None, help="instances of the whole job (default 512 for case118)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-termination", action="store_true", help="skip the run-to-termination legs")
+    ap.add_argument("--no-dense-ldlt", action="store_true", help="skip the dense LDL^T record")
     ap.add_argument("--literal-quirks", type=int, default=1)
-    ap.add_argument("--kkt-tile-order", type=int, default=None,
-                    help="options.kkt_tile_order (default: the library default)")
-    ap.add_argument("--kkt-condense", type=int, default=None,
-                    help="options.kkt_condense (default: the library default)")
-    ap.add_argument("--ipm-corrector", type=int, default=1,
-                    help="options.ipm_corrector (library default 1: predictor-corrector interior-point iterations)")
-    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event timing of k_trailing")
+    ap.add_argument("--kkt-mode", type=int, default=0, help="options.kkt_mode: 0 auto (sparse here), 1 dense MFMA, 2 sparse")
+    ap.add_argument("--kkt-tile-order", type=int, default=None)
+    ap.add_argument("--kkt-condense", type=int, default=None)
+    ap.add_argument("--ipm-corrector", type=int, default=1)
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event timing of the factor / solve kernels")
     ap.add_argument("--sqp-options", default="example", choices=["example", "defaults"],
                     help="example: tol_infeas 1e-6, tol_residual 1e-4, use_soc (examples/acopf/opf.jl:76-79, the headline); "
                          "defaults: the reference's Parameters defaults (parameters.jl:17-29: tol_residual 1e-6, no SOC)")
@@ -60,15 +71,20 @@ def main():
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"[bench] --gpus {args.gpus} but WORLD_SIZE is {world}: launch N > 1 as\n"
+                  f"  python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
+                  f"--master-port 29500 bench.py --gpus {args.gpus} ...", file=sys.stderr)
+        sys.exit(2)
+
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     if args.one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -77,6 +93,7 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend="gloo")
+    dev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")   # collective buffers
 
     import sqpsolver_jl_amd as pkg
     from sqpsolver_jl_amd.acopf_synth import acopf_synth, acopf_layout, contingency, CASES
@@ -84,41 +101,55 @@ def main():
     from sqpsolver_jl_amd import _lib
 
     nb, ng, nl, seed = CASES[args.workload]
-    B = args.batch
-    total = B * world
+    total = args.batch or DEFAULT_BATCH[args.workload]
     lo, hi = shard_range(total, world, rank)
+    B = hi - lo
     base = acopf_synth(nb, ng, nl, seed)
     lay0 = acopf_layout(base)
-    # examples/acopf/opf.jl:72-80
     use_soc = 1 if args.sqp_options == "example" else 0
     sqp_kw = dict(tol_infeas=1e-6, tol_residual=1e-4, use_soc=1) if use_soc else {}
-    lin_kw = {} if args.kkt_condense is None else {"kkt_condense": args.kkt_condense}
+    lin_kw = {"kkt_mode": args.kkt_mode}
+    if args.kkt_condense is not None:
+        lin_kw["kkt_condense"] = args.kkt_condense
     if args.kkt_tile_order is not None:
         lin_kw["kkt_tile_order"] = args.kkt_tile_order
-    opts = pkg.default_options(max_iter=3000, literal_quirks=args.literal_quirks, device=local_rank,
-                               ipm_corrector=args.ipm_corrector, **lin_kw, **sqp_kw)
-    import threading
-    G = max(1, min(args.groups, hi - lo))
-    ctxs, nets = [], []
-    for gi in range(G):
-        glo, ghi = shard_range(hi - lo, G, gi)
-        ctx = pkg.Context(lay0.n, lay0.m, lay0.num_linear, lay0.jrow, lay0.jcol, lay0.hrow, lay0.hcol,
-                          lay0.xL, lay0.xU, lay0.gL, lay0.gU, opts, batch=ghi - glo)
-        ctx.acopf_attach(base, lay0)
-        for b, s_id in enumerate(range(lo + glo, lo + ghi)):
-            net = base if s_id == 0 else contingency(base, s_id, seed)
-            lay = acopf_layout(net)
-            ctx.acopf_set_instance(b, net, lay)
-            nets.append((net, lay))
-        ctx.sqp_reset()
-        ctxs.append(ctx)
 
-    def counters_sum():
-        tot = {}
-        for c in ctxs:
-            for k, v in c.counters().items():
-                tot[k] = tot.get(k, 0) + v
-        return tot
+    scen = {}
+
+    def scenario(s_id):
+        if s_id not in scen:
+            net = base if s_id == 0 else contingency(base, s_id, seed)
+            scen[s_id] = (net, acopf_layout(net))
+        return scen[s_id]
+
+    def make_ctx(literal_quirks, max_iter=3000):
+        opts = pkg.default_options(max_iter=max_iter, literal_quirks=literal_quirks, device=local_rank,
+                                   ipm_corrector=args.ipm_corrector, **lin_kw, **sqp_kw)
+        ctx = pkg.Context(lay0.n, lay0.m, lay0.num_linear, lay0.jrow, lay0.jcol, lay0.hrow, lay0.hcol,
+                          lay0.xL, lay0.xU, lay0.gL, lay0.gU, opts, batch=B)
+        ctx.acopf_attach(base, lay0)
+        for b, s_id in enumerate(range(lo, hi)):
+            ctx.acopf_set_instance(b, *scenario(s_id))
+        ctx.sqp_reset()
+        return ctx, opts
+
+    ctx, opts = make_ctx(args.literal_quirks)
+
+    # the status gather: RCCL inside the library (sqphip_gather_status); torch.distributed only carries the unique id
+    use_lib_comm = False
+    if world > 1 and args.backend == "nccl" and not args.one_device:
+        try:
+            idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(pkg.Context.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, src=0)
+            ctx.comm_init(bytes(idt.cpu().numpy().tobytes()), world, rank)
+            use_lib_comm = True
+        except Exception as e:          # never lose the measurement to the gather: fall back to torch.distributed
+            print(f"[bench] rank {rank}: sqphip_comm_init failed ({e}); status gather through torch.distributed", file=sys.stderr)
+        ok = torch.tensor([1 if use_lib_comm else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        use_lib_comm = bool(ok.item())
 
     def sync():
         torch.cuda.synchronize()
@@ -126,34 +157,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    dev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")   # collective buffers
-
     def run_steps(k):
-        """k outer SQP-TR iterations of every instance of the shard (continuous batching inside the
-        library: an instance never waits for the slowest sub-problem of the batch), then the status
-        all-gather across ranks."""
-        ths = [threading.Thread(target=c.sqp_run, args=(k,)) for c in ctxs]   # ctypes drops the GIL
-        for t in ths:
-            t.start()
-        for t in ths:
-            t.join()
-        parts = [c.sqp_status() for c in ctxs]
-        ret, it, done = (np.concatenate([p[i] for p in parts]) for i in range(3))
-        return gather_status(ret, it, done, total, device=dev)
+        """k outer SQP-TR iterations of every instance of the block (continuous batching inside the library: an
+        instance never waits for the slowest sub-problem of the batch), then the status all-gather across ranks."""
+        ctx.sqp_run(k)
+        if use_lib_comm:
+            return ctx.gather_status(total)
+        return gather_status(*ctx.sqp_status(), total, device=dev)
 
     if args.warmup > 0:
         run_steps(args.warmup)
-    c0 = counters_sum()
-    for c in ctxs:
-        c.set_timing(not args.no_kernel_timing)
+    c0 = ctx.counters()
+    ctx.set_timing(not args.no_kernel_timing)
     sync()
     t0 = time.perf_counter()
     g_ret, g_it, g_done = run_steps(args.steps)
     sync()
     t1 = time.perf_counter()
-    for c in ctxs:
-        c.set_timing(False)
-    c1 = counters_sum()
+    ctx.set_timing(False)
+    c1 = ctx.counters()
 
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     stats = torch.tensor([c1["n_qp"] - c0["n_qp"], c1["n_ipm_iter"] - c0["n_ipm_iter"],
@@ -164,50 +186,106 @@ def main():
     elapsed = float(elapsed.item())
     n_qp, n_ipm, n_fac = (float(v) for v in stats.tolist())
 
-    # roofline of the dominant kernel (k_trailing, fp64 MFMA), rank-0 local measurement
-    cinfo = ctxs[0].counters()
-    N = int(cinfo["kkt_order"])         # order of the factorised matrices (n + m, or the condensed order)
+    # ---- roofline of the dominant kernels, rank-0 local measurement (HIP events on the library's stream)
     N_full = lay0.n + lay0.m
-    N_c = lay0.n + int(np.sum(lay0.gL == lay0.gU))       # condensed order (before tile padding)
-    lead = int(cinfo["lead_tiles"])
+    N = int(c1["kkt_order"])
     loc_fac = c1["n_factor"] - c0["n_factor"]
-    tr_sec = c1["trailing_seconds"] - c0["trailing_seconds"]
-    tr_launch = c1["trailing_launches"] - c0["trailing_launches"]
-    # algorithmic flops of the k_trailing launches of one factorisation, as the library schedules them
-    achieved = loc_fac * float(cinfo["trailing_flops_per_factor"]) / tr_sec / 1e12 if tr_sec > 0 else 0.0
+    fac_sec = c1["ldlt_seconds"] - c0["ldlt_seconds"]
+    sol_sec = c1["solve_seconds"] - c0["solve_seconds"]
     probe = None
     if rank == 0:
         import ctypes as C
         v = C.c_double()
         if _lib.lib().sqphip_mfma_f64_peak(local_rank, C.byref(v)) == 0:
             probe = v.value
-    traffic = None
-    tpath = os.path.join(_ROOT, "profiles", "trailing_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    if c1["sparse"]:
+        # B_sparse = 12 nnz(K_lower) [values + indices read] + 8 nnz(L) [written] + 2 x 8 nnz(L)
+        # [forward + backward reads] + 4 x 8 N [vectors] per factorisation with its solve, per instance.  The
+        # refinement / corrector solves of an iteration add time but no bytes here: the fraction is a lower bound.
+        b_sparse = 12.0 * c1["nnz_k"] + 24.0 * c1["nnz_l"] + 32.0 * N
+        ksec = fac_sec + sol_sec
+        achieved = loc_fac * b_sparse / ksec / 1e9 if ksec > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(_ROOT, "profiles", "mf_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_instance_factorisation")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": "k_mf_values + k_mf_factor2<*> (factor, v_mfma_f64_16x16x4_f64 rank-4 blocks) + "
+                                              "k_mf_fwd / k_mf_bwd (solves)",
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": traffic, "traffic_static": True,
+                    "bytes_per_instance_factorisation": b_sparse, "nnz_k_lower": int(c1["nnz_k"]), "nnz_l": int(c1["nnz_l"]),
+                    "instance_factorisations": int(loc_fac), "factor_seconds": fac_sec, "solve_seconds": sol_sec,
+                    "share_of_wall": ksec / (t1 - t0) if t1 > t0 else None,
+                    "whole_factor_mfma_frac": (loc_fac * c1["factor_flops"] / fac_sec / 1e12 / FP64_MFMA_PEAK_TFLOPS) if fac_sec > 0 else None,
+                    "supernodes": int(c1["n_supernodes"]), "levels": int(c1["n_levels"]), "max_front": int(c1["max_front"]),
+                    "onbox_mfma_probe_tflops": probe}
+    else:
+        tr_sec = c1["trailing_seconds"] - c0["trailing_seconds"]
+        tr_launch = c1["trailing_launches"] - c0["trailing_launches"]
+        achieved = loc_fac * float(c1["trailing_flops_per_factor"]) / tr_sec / 1e12 if tr_sec > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "k_trailing + k_trailing_list (v_mfma_f64_16x16x4_f64)",
+                    "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "launches": int(tr_launch), "avg_launch_ms": 1e3 * tr_sec / tr_launch if tr_launch else None,
+                    "share_of_wall": tr_sec / (t1 - t0) if t1 > t0 else None,
+                    "onbox_mfma_probe_tflops": probe}
+    ctx.close()
+
+    # ---- rank 0, single-GPU only: the dense MFMA LDL^T on its own, the run-to-termination legs, the CPU baseline
+    dense = None
+    if rank == 0 and not args.no_dense_ldlt:
+        import ctypes as C
+        sec, trs, nl_ = C.c_double(), C.c_double(), C.c_int64()
+        if _lib.lib().sqphip_ldlt_bench(local_rank, 64, 2813, 3, C.byref(sec), C.byref(trs), C.byref(nl_)) == 0 and sec.value > 0:
+            tf = 64 * 2813.0 ** 3 / 3.0 / sec.value / 1e12
+            dense = {"what": "batched dense LDL^T (ldlt.hip), 64 matrices of order 2813 (IEEE-118 full Newton matrix)",
+                     "ms_per_batch": 1e3 * sec.value, "tflops_n3_over_3": tf, "peak": FP64_MFMA_PEAK_TFLOPS,
+                     "frac": tf / FP64_MFMA_PEAK_TFLOPS, "k_trailing_ms": 1e3 * trs.value, "k_trailing_launches": int(nl_.value)}
+
+    termination = None
+    if rank == 0 and world == 1 and not args.no_termination:
+        termination = {}
+        for lq in (1, 0):
+            tctx, _ = make_ctx(lq, max_iter=60)
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            tctx.sqp_run(0)
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            tc = tctx.counters()
+            ret, it, done = tctx.sqp_status()
+            termination[f"literal_quirks_{lq}"] = {
+                "seconds": tb - ta, "qp_solved": int(tc["n_qp"]), "qp_per_s": tc["n_qp"] / (tb - ta),
+                "instances_done": int(np.sum(done)), "converged_ret0": int(np.sum(ret == 0)),
+                "iteration_limit": int(np.sum(ret == -1)), "other": int(np.sum((ret != 0) & (ret != -1))),
+                "outer_iterations_median": float(np.median(it)), "ipm_iterations_per_qp": tc["n_ipm_iter"] / max(1, tc["n_qp"]),
+                "factorisations_per_qp": tc["n_factor"] / max(1, tc["n_qp"])}
+            tctx.close()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # CPU restatement (NOT Julia/Ipopt) on a bounded sample: instance 0, first 6 outer iterations (about 12 s)
+        # CPU restatement (NOT Julia/Ipopt): a bounded sample of the same workload, one scenario per host thread
+        from concurrent.futures import ThreadPoolExecutor
         from oracle import oracle as O
-        try:
-            cores = max(1, min(16, len(os.sched_getaffinity(0))))   # the GPU box grants 16 host cores per GPU
-        except AttributeError:
-            cores = max(1, min(16, os.cpu_count() or 1))
-        oo = O.default_options(max_iter=6, literal_quirks=args.literal_quirks, num_threads=cores,
-                               ipm_corrector=args.ipm_corrector, kkt_condense=int(opts.kkt_condense),
-                               kkt_tile_order=int(opts.kkt_tile_order), **sqp_kw)
-        ro = O.sqp_solve(O.problem_acopf(*nets[0]), oo)
-        N_cpu = lay0.n + (int(np.sum(lay0.gL == lay0.gU)) if int(opts.kkt_condense) else lay0.m)
-        cpu = {"value": ro["n_qp"] / ro["qp_seconds"] if ro["qp_seconds"] > 0 else 0.0,
-               "unit": "QP subproblems/s", "cores": cores, "kind": "port",
-               "sample": f"{args.workload} scenario 0, first 6 SQP-TR iterations = {ro['n_qp']} sub-problems, "
-                         f"{ro['n_factor']} dense LDL^T of order {N_cpu} (plain dense, in the product's order), "
-                         f"{ro['qp_seconds']:.1f} s; CPU restatement "
-                         f"(oracle/), not Julia/Ipopt"}
+        cores = host_cores()
+        n_s = min(total, {"case14": 512, "case118": 512, "case1354": 16, "case9241": 1}[args.workload])
+        k_it = args.steps + args.warmup
+        oo = O.default_options(max_iter=k_it, literal_quirks=args.literal_quirks, num_threads=1, kkt_mode=2,
+                               ipm_corrector=args.ipm_corrector, **sqp_kw)
+        probs = [O.problem_acopf(*scenario(s)) for s in range(n_s)]
+        ta = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=cores) as ex:          # ctypes releases the GIL inside ora_sqp_tr_solve
+            res = list(ex.map(lambda p: O.sqp_solve(p, oo), probs))
+        tb = time.perf_counter()
+        nq = sum(r["n_qp"] for r in res)
+        cpu = {"value": nq / (tb - ta), "unit": "QP subproblems/s", "cores": cores, "kind": "port",
+               "sample": f"{args.workload} scenarios 0..{n_s - 1}, first {k_it} SQP-TR iterations each = {nq} sub-problems, "
+                         f"{sum(r['n_factor'] for r in res)} sparse LDL^T of order {N} (oracle/sparse_ldlt.c, its own "
+                         f"minimum-degree order), one scenario per thread on {cores} host threads, {tb - ta:.1f} s; CPU "
+                         f"restatement (oracle/), not Julia/Ipopt"}
 
     if rank == 0:
         out = {
@@ -219,33 +297,33 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / max(1, args.steps),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{B} x IEEE-{nb}-bus-shaped ACOPF contingency scenarios per GPU "
-                                   f"(BASELINE.json configs[3] shard), KKT order {N_full}"
-                                   + (f" condensed to {N_c}" if int(opts.kkt_condense) else "")
-                                   + (f", ordered into {lead} independent leading tiles + a dense remainder of {N - 64 * lead}"
-                                      if lead else "") + ", fp64 LDL^T, SQP-TR outer iterations",
-                       "instances_total": total, "kkt_order": N, "use_soc": use_soc, "sqp_options": args.sqp_options,
-                       "groups_per_gpu": G,
+            "config": {"workload": f"{total} x IEEE-{nb}-bus-shaped ACOPF contingency scenarios (BASELINE.json configs[3]"
+                                   f"{'' if args.workload == 'case118' else ' shape: ' + args.workload}), {B} per GPU, "
+                                   f"Newton matrix of order {N_full}" + (f" condensed to {N}" if int(opts.kkt_condense) else "")
+                                   + (", multifrontal LDL^T" if c1["sparse"] else ", dense MFMA LDL^T")
+                                   + ", fp64, SQP-TR outer iterations",
+                       "instances_total": total, "instances_per_gpu": B, "kkt_order": N, "kkt_order_full": N_full,
+                       "use_soc": use_soc, "sqp_options": args.sqp_options,
                        "literal_quirks": args.literal_quirks, "ipm_corrector": args.ipm_corrector,
-                       "kkt_condense": int(opts.kkt_condense), "kkt_order_full": N_full,
-                       "kkt_tile_order": int(opts.kkt_tile_order), "independent_lead_tiles": int(cinfo["lead_tiles"]),
+                       "kkt_mode": args.kkt_mode, "sparse_solver": int(c1["sparse"]), "kkt_condense": int(opts.kkt_condense),
+                       "status_gather": "sqphip_gather_status (RCCL)" if use_lib_comm else
+                                        ("local" if world == 1 else "torch.distributed " + args.backend),
                        "qp_solved": n_qp, "ipm_iterations": n_ipm, "kkt_factorisations": n_fac,
-                       "ldlt_dense_equivalent_tflops_wall": n_fac * ((N_c if int(opts.kkt_condense) else N_full) ** 3 / 3.0) / elapsed / 1e12 if elapsed > 0 else 0.0,
-                       "instances_done": int(np.sum(g_done))},
-            "roofline": {"bound": "mfma", "kernel": "k_trailing + k_trailing_list (v_mfma_f64_16x16x4_f64)",
-                         "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "launches": tr_launch, "avg_launch_ms": 1e3 * tr_sec / tr_launch if tr_launch else None,
-                         "onbox_mfma_probe_tflops": probe},
+                       "ipm_iterations_per_qp": n_ipm / max(1.0, n_qp), "factorisations_per_qp": n_fac / max(1.0, n_qp),
+                       "instances_done_in_timed_steps": int(np.sum(g_done)),
+                       "note": "with literal_quirks = 1 (the reference's JuMP-sign Hessian, SURVEY.md App. C #2) the "
+                               "sub-problems are non-convex and most scenarios never meet the termination test; see "
+                               "`termination` for both sign conventions run to the end"},
+            "roofline": roofline,
+            "dense_ldlt": dense,
+            "termination": termination,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    for c in ctxs:
-        c.close()
     if world > 1:
         dist.destroy_process_group()
 

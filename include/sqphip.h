@@ -240,6 +240,18 @@ int sqphip_sqp_get(sqphip_ctx *ctx, int32_t inst, double *x, double *g, double *
 /* ret codes and iteration counts of the whole batch, device -> host (the arrays a host layer
  * all-gathers across ranks); done[i] = 1 once instance i has terminated */
 int sqphip_sqp_status(sqphip_ctx *ctx, int32_t *ret_codes, int32_t *iters, int32_t *done);
+/* ---- multi-GPU: the convergence-status gather --------------------------------------
+ * Independent instances are cut into `world` contiguous blocks (sizes differing by at most one, rank r holding block r;
+ * one process and one context per GPU, the context's batch = its block).  The only exchange between ranks is an
+ * all-gather of int32 (ret, iter, done) per instance over RCCL on a communicator the library owns: rank 0 obtains the
+ * 128-byte ncclUniqueId with sqphip_comm_unique_id and ships it to the other ranks by whatever channel the host has
+ * (MPI, a file, torch.distributed, Julia's Distributed), every rank then calls sqphip_comm_init.  RCCL is loaded with
+ * dlopen on the first of these calls; a single-rank host never needs it and sqphip_gather_status then returns the
+ * local table.  Outputs: length `total`, ordered by global instance id; any may be NULL. */
+int sqphip_comm_unique_id(void *id128);
+int sqphip_comm_init(sqphip_ctx *ctx, const void *id128, int32_t world, int32_t rank);
+int sqphip_gather_status(sqphip_ctx *ctx, int32_t total, int32_t *ret_codes, int32_t *iters, int32_t *done);
+int sqphip_comm_destroy(sqphip_ctx *ctx);
 /* per-instance trace rows (columns of the reference's log line, sqp_trust_region.jl:605-634):
  * rows[k*12 + {iter, accepted, fr, sub_status, ipm_iters, f, phi, mu, delta, |p|, inf_pr, inf_du}] */
 int sqphip_sqp_trace(sqphip_ctx *ctx, int32_t inst, double *rows, int32_t cap, int32_t *len);

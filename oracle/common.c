@@ -26,7 +26,8 @@ void ora_default_options(ora_options *o)
     o->num_threads = 1;
     o->ipm_corrector = 1;
     o->kkt_condense = 1;
-    o->kkt_tile_order = 1;
+    o->kkt_tile_order = 0;
+    o->kkt_mode = 0;
 }
 
 /* Julia's isapprox(a, b) with default rtol = sqrt(eps), atol = 0

@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "build", "liboracle.so")
-_SRCS = ["common.c", "qp_ipm.c", "sqp_tr.c", "problems.c", "sqp_oracle.h"]
+_SRCS = ["common.c", "qp_ipm.c", "sqp_tr.c", "problems.c", "sparse_ldlt.c", "sqp_oracle.h"]
 
 MODE_QP, MODE_FR, MODE_SOC, MODE_LP, MODE_L1QP, MODE_INFEAS = range(6)
 MOI_LOCALLY_SOLVED, MOI_LOCALLY_INFEASIBLE, MOI_ITERATION_LIMIT = 4, 5, 11
@@ -25,7 +25,8 @@ class Options(C.Structure):
                [("max_iter", C.c_int), ("use_soc", C.c_int), ("literal_quirks", C.c_int),
                 ("ipm_tol", C.c_double),
                 ("ipm_max_iter", C.c_int), ("ipm_phase1", C.c_int), ("num_threads", C.c_int),
-                ("ipm_corrector", C.c_int), ("kkt_condense", C.c_int), ("kkt_tile_order", C.c_int)]
+                ("ipm_corrector", C.c_int), ("kkt_condense", C.c_int), ("kkt_tile_order", C.c_int),
+                ("kkt_mode", C.c_int)]
 
 
 class TraceRow(C.Structure):
@@ -143,7 +144,7 @@ def _apply_order(opts, n, m, jrow1, jcol1, hrow1, hcol1, gL, gU):
     same mathematics (tests/test_oracle_kat.py compares it with the natural order), following the product's one only
     keeps the two implementations on one rounding trajectory."""
     if not (opts.kkt_condense and opts.kkt_tile_order):
-        set_kkt_order(None); return
+        return                  # the oracle's own order (natural for the dense LDL^T, its minimum degree for the sparse one)
     import sqpsolver_jl_amd as _pkg
     pos, _, _ = _pkg.kkt_order(int(n), int(m), jrow1, jcol1, hrow1, hcol1, f64(gL), f64(gU))
     set_kkt_order(pos)

@@ -61,6 +61,11 @@ struct ora_qp {
     int64_t *kpos, *jrowptr, *jrcol, *jrslot;
     int64_t *ord;      /* rank of unknown u (variable j, or n + kpos) in the factorised matrix (ora_set_kkt_order) */
     double *rhsc;
+    /* sparse linear algebra (opt.kkt_mode): the Newton matrix as triplets in a fixed enumeration order (kkt_triplets) */
+    int sparse;
+    ora_sldl *sl;
+    int64_t nt;
+    double *tv;
     double delta_w_last;
     /* stats */
     int ipm_iters, n_factor;
@@ -82,6 +87,8 @@ void ora_set_kkt_order(const int32_t *rank, int64_t len)
     for (int64_t i = 0; i < len; ++i) g_kkt_rank[i] = rank[i];
     g_kkt_len = len;
 }
+
+static void kkt_sparse_setup(ora_qp *q);
 
 ora_qp *ora_qp_create(int64_t n, int64_t m, int64_t num_linear,
                       const int64_t *jcolptr, const int64_t *jrowval,
@@ -122,12 +129,18 @@ ora_qp *ora_qp_create(int64_t n, int64_t m, int64_t num_linear,
     q->dvl = dalloc(m); q->dvu = dalloc(m);
     q->k_gl = dalloc(n); q->k_gu = dalloc(n); q->k_al = dalloc(m); q->k_au = dalloc(m);
     q->k_tp = dalloc(m); q->k_tm = dalloc(m);
-    q->K = dalloc(q->ld * q->N); q->dinv = dalloc(q->N);
+    q->dinv = dalloc(q->N);
     q->rhs = dalloc(q->N); q->sol = dalloc(q->N); q->res = dalloc(q->N);
     q->sigp = dalloc(n); q->D = dalloc(m);
     q->kpos = (int64_t *)malloc(sizeof(int64_t) * (size_t)(m + 1));
     q->mk = 0;
-    for (int64_t i = 0; i < m; ++i) q->kpos[i] = (gL[i] == gU[i]) ? q->mk++ : -1;
+    {   /* rows that stay in the condensed matrix: the equalities, and rows with more than 32 entries (eliminating
+         * such a row would put a clique of that size into the matrix) -- the same rule as the product */
+        int64_t *cnt = (int64_t *)calloc((size_t)(m + 1), sizeof(int64_t));
+        for (int64_t k = 0; k < q->nnzj; ++k) cnt[jrowval[k]]++;
+        for (int64_t i = 0; i < m; ++i) q->kpos[i] = (gL[i] == gU[i] || cnt[i] > 32) ? q->mk++ : -1;
+        free(cnt);
+    }
     q->Nc = n + q->mk;
     q->ord = (int64_t *)malloc(sizeof(int64_t) * (size_t)(q->Nc + 1));
     for (int64_t u = 0; u < q->Nc; ++u) q->ord[u] = (g_kkt_len == q->Nc) ? g_kkt_rank[u] : u;
@@ -146,6 +159,12 @@ ora_qp *ora_qp_create(int64_t n, int64_t m, int64_t num_linear,
             }
         free(fill);
     }
+    {
+        const int64_t Nf = q->opt.kkt_condense ? q->Nc : q->N;
+        q->sparse = q->opt.kkt_mode == 2 || (q->opt.kkt_mode == 0 && Nf >= 3000);
+    }
+    if (q->sparse) kkt_sparse_setup(q);
+    else q->K = dalloc(q->ld * q->N);
     return q;
 }
 
@@ -157,8 +176,9 @@ void ora_qp_destroy(ora_qp *q)
         q->p, q->zl, q->zu, q->s, q->tp, q->tm, q->y, q->vl, q->vu, q->dp, q->dzl, q->dzu, q->ds,
         q->dtp, q->dtm, q->dy, q->dvl, q->dvu, q->k_gl, q->k_gu, q->k_al, q->k_au, q->k_tp, q->k_tm,
         q->K, q->dinv, q->rhs, q->sol, q->res, q->sigp, q->D, q->zp, q->zm,
-        q->kpos, q->jrowptr, q->jrcol, q->jrslot, q->rhsc, q->ord };
+        q->kpos, q->jrowptr, q->jrcol, q->jrslot, q->rhsc, q->ord, q->tv };
     for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) free(ptrs[i]);
+    ora_sldl_free(q->sl);
     free(q);
 }
 
@@ -366,6 +386,61 @@ static void kkt_assemble_condensed(ora_qp *q, double delta_w)
 #undef KADD
 }
 
+/* The same matrix (full or condensed form) as triplets over the unknowns u = variable j, or n + (row | kept position),
+ * in a fixed enumeration order; free rows keep their structural entries with value 0 (diagonal -1) so that the
+ * pattern does not depend on the mode.  ti / tj / tv: whichever is non-NULL is filled; returns the count. */
+static int64_t kkt_triplets(const ora_qp *q, double delta_w, int64_t *ti, int64_t *tj, double *tv)
+{
+    const int64_t n = q->n, m = q->m;
+    const int cond = q->opt.kkt_condense;
+    int64_t t = 0;
+#define TADD(a, b, v) do { if (ti) { ti[t] = (a); tj[t] = (b); } if (tv) tv[t] = (v); ++t; } while (0)
+    for (int64_t j = 0; j < n; ++j) {
+        TADD(j, j, tv ? q->hd[j] + q->sigp[j] + delta_w + ipm_reg_p() : 0.0);
+        for (int64_t k = q->hcolptr[j]; k < q->hcolptr[j + 1]; ++k) {
+            const int64_t i = q->hrowval[k];
+            if (i >= j) TADD(i, j, tv ? q->hv[k] : 0.0);
+        }
+    }
+    for (int64_t i = 0; i < m; ++i) {
+        const int act = tv ? q->rtype[i] != ROW_FREE : 1;
+        const int64_t u = cond ? (q->kpos[i] >= 0 ? n + q->kpos[i] : -1) : n + i;
+        if (u >= 0) {
+            TADD(u, u, tv ? (act ? -(q->D[i] + ipm_reg_d()) : -1.0) : 0.0);
+            for (int64_t s = q->jrowptr[i]; s < q->jrowptr[i + 1]; ++s) TADD(u, q->jrcol[s], (tv && act) ? q->jv[q->jrslot[s]] : 0.0);
+        } else {
+            const double f = (tv && act) ? 1.0 / (q->D[i] + ipm_reg_d()) : 0.0;
+            for (int64_t a = q->jrowptr[i]; a < q->jrowptr[i + 1]; ++a)
+                for (int64_t b = q->jrowptr[i]; b <= a; ++b)
+                    TADD(q->jrcol[a], q->jrcol[b], (tv && act) ? q->jv[q->jrslot[a]] * f * q->jv[q->jrslot[b]] : 0.0);
+        }
+    }
+#undef TADD
+    return t;
+}
+
+static void kkt_sparse_setup(ora_qp *q)
+{
+    const int64_t n = q->n, m = q->m, Nf = q->opt.kkt_condense ? q->Nc : q->N;
+    q->nt = kkt_triplets(q, 0.0, NULL, NULL, NULL);
+    int64_t *ti = (int64_t *)malloc(sizeof(int64_t) * (size_t)(q->nt + 1)), *tj = (int64_t *)malloc(sizeof(int64_t) * (size_t)(q->nt + 1));
+    kkt_triplets(q, 0.0, ti, tj, NULL);
+    /* a row of the matrix is eliminated behind every variable it couples to */
+    int64_t *bp = (int64_t *)calloc((size_t)(Nf + 2), sizeof(int64_t)), *bi = (int64_t *)malloc(sizeof(int64_t) * (size_t)(q->nnzj + 1));
+    int64_t o = 0;
+    for (int64_t u = 0; u < n; ++u) bp[u + 1] = 0;
+    for (int64_t i = 0; i < m; ++i) {
+        const int64_t u = q->opt.kkt_condense ? (q->kpos[i] >= 0 ? n + q->kpos[i] : -1) : n + i;
+        if (u < 0) continue;
+        for (int64_t s = q->jrowptr[i]; s < q->jrowptr[i + 1]; ++s) bi[o++] = q->jrcol[s];
+        bp[u + 1] = o;          /* rows are visited in ascending u, variables (u < n) have empty lists */
+    }
+    for (int64_t u = n; u < Nf; ++u) if (bp[u + 1] < bp[u]) bp[u + 1] = bp[u];
+    q->sl = ora_sldl_analyse(Nf, q->nt, ti, tj, bp, bi, 0);
+    q->tv = dalloc(q->nt);
+    free(ti); free(tj); free(bp); free(bi);
+}
+
 /* res = rhs - K sol  with K applied through its sparse pieces */
 static double kkt_residual(const ora_qp *q, double delta_w, const double *rhs, const double *sol,
                            double *res)
@@ -396,13 +471,17 @@ static int kkt_factor(ora_qp *q, double dw_floor, double *delta_w_out)
     double dw = dw_floor;
     for (int attempt = 0; attempt < 60; ++attempt) {
         const int64_t Nf = q->opt.kkt_condense ? q->Nc : q->N;
-        if (q->opt.kkt_condense) kkt_assemble_condensed(q, dw); else kkt_assemble(q, dw);
-        int64_t np = 0, nn = 0;
-        ora_ldlt_factor(Nf, q->K, q->ld, q->dinv, Nf, &np, &nn, q->opt.num_threads);
+        int64_t np = 0, nn = 0, bad = 0;
+        if (q->sparse) {
+            kkt_triplets(q, dw, NULL, NULL, q->tv);
+            np = ora_sldl_numeric(q->sl, q->tv, &bad);
+        } else {
+            if (q->opt.kkt_condense) kkt_assemble_condensed(q, dw); else kkt_assemble(q, dw);
+            ora_ldlt_factor(Nf, q->K, q->ld, q->dinv, Nf, &np, &nn, q->opt.num_threads);
+        }
         q->n_factor++;
         if (np == q->n) {
-            int64_t bad = 0;
-            for (int64_t j = 0; j < Nf; ++j) if (!isfinite(q->dinv[j]) || q->dinv[j] == 0.0) ++bad;
+            if (!q->sparse) for (int64_t j = 0; j < Nf; ++j) if (!isfinite(q->dinv[j]) || q->dinv[j] == 0.0) ++bad;
             if (!bad) {
                 if (dw > 0.0) q->delta_w_last = dw;
                 *delta_w_out = dw;
@@ -439,13 +518,14 @@ static void kkt_apply(ora_qp *q, const double *rhs, double *sol)
                 int64_t i = q->jrowval[k];
                 if (q->rtype[i] != ROW_FREE && q->kpos[i] < 0) acc += q->jv[k] * rhs[n + i] / (q->D[i] + ipm_reg_d());
             }
-            rc[ord[j]] = rhs[j] + acc;
+            rc[q->sparse ? j : ord[j]] = rhs[j] + acc;
         }
-        for (int64_t i = 0; i < m; ++i) if (q->kpos[i] >= 0) rc[ord[n + q->kpos[i]]] = rhs[n + i];
-        ora_ldlt_solve(q->Nc, q->K, q->ld, q->dinv, rc);
-        for (int64_t j = 0; j < n; ++j) sol[j] = rc[ord[j]];
+        for (int64_t i = 0; i < m; ++i) if (q->kpos[i] >= 0) rc[q->sparse ? n + q->kpos[i] : ord[n + q->kpos[i]]] = rhs[n + i];
+        if (q->sparse) ora_sldl_solve(q->sl, rc);
+        else ora_ldlt_solve(q->Nc, q->K, q->ld, q->dinv, rc);
+        for (int64_t j = 0; j < n; ++j) sol[j] = rc[q->sparse ? j : ord[j]];
         for (int64_t i = 0; i < m; ++i) {
-            if (q->kpos[i] >= 0) { sol[n + i] = rc[ord[n + q->kpos[i]]]; continue; }
+            if (q->kpos[i] >= 0) { sol[n + i] = rc[q->sparse ? n + q->kpos[i] : ord[n + q->kpos[i]]]; continue; }
             if (q->rtype[i] == ROW_FREE) { sol[n + i] = -rhs[n + i]; continue; }     /* row -1 * q = b */
             double acc = 0.0;
             for (int64_t t = q->jrowptr[i]; t < q->jrowptr[i + 1]; ++t) acc += q->jv[q->jrslot[t]] * sol[q->jrcol[t]];
@@ -453,7 +533,8 @@ static void kkt_apply(ora_qp *q, const double *rhs, double *sol)
         }
     } else {
         memcpy(sol, rhs, sizeof(double) * (size_t)N);
-        ora_ldlt_solve(N, q->K, q->ld, q->dinv, sol);
+        if (q->sparse) ora_sldl_solve(q->sl, sol);
+        else ora_ldlt_solve(N, q->K, q->ld, q->dinv, sol);
     }
 }
 

@@ -65,10 +65,26 @@ typedef struct {
                           first inertia correction on; 0: monotone Fiacco-McCormick rule throughout */
     int kkt_condense;  /* 1: eliminate the rows with gL != gU (their block of the Newton matrix is the diagonal -D)
                           before factorising: dense LDL^T of order n + #equality rows instead of n + m */
-    int kkt_tile_order; /* 1: factorise the condensed matrix in the order the product library uses (its host-only
-                           sqphip_kkt_order), so that both sides stay on one trajectory; the permutation is handed in
-                           by oracle.py through ora_set_kkt_order -- the C code itself does not read this field */
+    int kkt_tile_order; /* 0 (default): the oracle orders its factorisation by itself.  1 (tests of the product's dense
+                           tile order only): factorise the condensed matrix in the order the product library uses (its
+                           host-only sqphip_kkt_order), so that both sides stay on one rounding trajectory; the
+                           permutation is handed in by oracle.py through ora_set_kkt_order -- the C code itself does
+                           not read this field */
+    int kkt_mode;       /* linear algebra of the Newton systems: 1 dense LDL^T (above), 2 sparse LDL^T with the oracle's
+                           own minimum-degree order (sparse_ldlt.c), 0 (default): sparse from order 3000 up, else dense */
 } ora_options;
+
+/* sparse_ldlt.c: sparse LDL^T without pivoting (ordering + up-looking factorisation), the checker of the product's
+ * multifrontal path.  Triplets (ti, tj) in any triangle, duplicates summed; bp / bi (may be NULL): CSR lists of the
+ * indices that must be eliminated before index u; natural != 0 skips the ordering. */
+typedef struct ora_sldl ora_sldl;
+ora_sldl *ora_sldl_analyse(int64_t n, int64_t nt, const int64_t *ti, const int64_t *tj, const int64_t *bp,
+                           const int64_t *bi, int natural);
+void ora_sldl_free(ora_sldl *S);
+int64_t ora_sldl_nnz_l(const ora_sldl *S);
+const int64_t *ora_sldl_perm(const ora_sldl *S);
+int64_t ora_sldl_numeric(ora_sldl *S, const double *tv, int64_t *nbad);
+void ora_sldl_solve(const ora_sldl *S, double *x);
 
 typedef double (*ora_eval_f_t)(void *ud, const double *x);
 typedef void (*ora_eval_grad_f_t)(void *ud, const double *x, double *grad);

@@ -9,7 +9,7 @@ import subprocess
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 SO_PATH = os.path.join(_CSRC, "libsqphip.so")
 SOURCES = ["ldlt.hip", "kernel_api.hip", "ipm.hip", "acopf.hip", "sqp.hip", "api.hip", "order.hip", "symbolic.hip",
-           "mfplan.hip", "mfront.hip"]
+           "mfplan.hip", "mfront.hip", "comm.hip"]
 HEADERS = ["sqphip_internal.hpp", "ctx.hpp", "sparse.hpp", "dev_util.hpp", "acopf_dev.hpp", os.path.join("..", "..", "include", "sqphip.h")]
 
 _lib = None
@@ -26,7 +26,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if stale:
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-Wno-unused-value", "-o", SO_PATH] + srcs
+               "-Wno-unused-value", "-Wno-pass-failed", "-o", SO_PATH] + srcs + ["-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
@@ -115,6 +115,10 @@ def lib():
             L.sqphip_sqp_get.argtypes = [vp, C.c_int32, dp, dp, dp, dp, dp, dp, ip, ip]
             L.sqphip_sqp_status.argtypes = [vp, ip, ip, ip]
             L.sqphip_sqp_trace.argtypes = [vp, C.c_int32, dp, C.c_int32, ip]
+            L.sqphip_comm_unique_id.argtypes = [vp]
+            L.sqphip_comm_init.argtypes = [vp, vp, C.c_int32, C.c_int32]
+            L.sqphip_gather_status.argtypes = [vp, C.c_int32, ip, ip, ip]
+            L.sqphip_comm_destroy.argtypes = [vp]
             L.sqphip_get_counters.argtypes = [vp, C.POINTER(Counters)]
             L.sqphip_reset_counters.argtypes = [vp]
             L.sqphip_set_timing.argtypes = [vp, C.c_int32]
@@ -129,6 +133,7 @@ EXPORTS = [
     "sqphip_compute_qmodel", "sqphip_compute_derivative", "sqphip_tr_update",
     "sqphip_kkt_order", "sqphip_kkt_symbolic", "sqphip_mf_host_solve", "sqphip_mf_solve_test", "sqphip_acopf_attach", "sqphip_acopf_set_shunts", "sqphip_acopf_set_dclines", "sqphip_acopf_set_instance", "sqphip_acopf_eval", "sqphip_sqp_reset",
     "sqphip_sqp_run", "sqphip_sqp_get", "sqphip_sqp_status", "sqphip_sqp_trace",
+    "sqphip_comm_unique_id", "sqphip_comm_init", "sqphip_gather_status", "sqphip_comm_destroy",
     "sqphip_get_counters", "sqphip_reset_counters", "sqphip_set_timing", "sqphip_ldlt_factor_host",
     "sqphip_ldlt_solve_host", "sqphip_ldlt_bench", "sqphip_ldlt_stress", "sqphip_mfma_f64_peak", "sqphip_armijo_alpha", "sqphip_compute_mu_rule",
 ]

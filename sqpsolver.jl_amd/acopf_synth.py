@@ -28,7 +28,7 @@ from __future__ import annotations
 import dataclasses
 import numpy as np
 
-__all__ = ["Network", "acopf_synth", "contingency", "NlpLayout", "acopf_layout",
+__all__ = ["Network", "acopf_synth", "contingency", "renumber_buses", "NlpLayout", "acopf_layout",
            "CASES"]
 
 # nb, ng, nl per SURVEY.md section 8 table
@@ -245,6 +245,22 @@ def contingency(net: Network, s: int, base_seed: int) -> Network:
         net, pd=net.pd * scale, qd=net.qd * scale, status=net.status.copy())
     out.status[k] = 0.0
     return out
+
+
+def renumber_buses(net: Network, seed: int) -> Network:
+    """The same network with its buses renumbered by a random permutation (branch and generator order kept).
+    `acopf_synth` numbers buses along its spanning tree, so neighbours in the numbering are neighbours in the grid;
+    real case files carry no such order.  Used by the tests of the orderings: nothing may depend on the numbering."""
+    rng = np.random.default_rng(seed)
+    new = rng.permutation(net.nb)                 # old bus b becomes bus new[b]
+    old = np.empty(net.nb, dtype=np.int64); old[new] = np.arange(net.nb)
+
+    def bus(a):
+        return None if a is None else np.asarray(a)[old]
+    return dataclasses.replace(
+        net, pd=bus(net.pd), qd=bus(net.qd), vmin=bus(net.vmin), vmax=bus(net.vmax), ref_bus=int(new[net.ref_bus]),
+        gen_bus=new[net.gen_bus].astype(np.int32), f_bus=new[net.f_bus].astype(np.int32),
+        t_bus=new[net.t_bus].astype(np.int32), gs=bus(net.gs), bs=bus(net.bs))
 
 
 @dataclasses.dataclass

@@ -11,11 +11,10 @@
 
 using namespace sqphip;
 
-struct sqphip_ctx { Ctx c; };
-
 Ctx::~Ctx()
 {
     tm.flush();
+    comm_release(*this);
     plan.destroy_lookahead();
     for (void *p : allocs) hipFree(p);
     if (h_counters) hipHostFree(h_counters);

@@ -133,6 +133,9 @@ struct Ctx {
     int *h_counters = nullptr;  // pinned
     std::vector<int> h_kpos;    // host copy of DV::kpos (row -> kept position or -1)
     bool acopf_attached = false;
+    // RCCL communicator for the status gather (comm.hip); null: single rank
+    void *comm = nullptr, *comm_buf = nullptr;
+    int comm_world = 1, comm_rank = 0;
     // host copies of structure for misc use
     int64_t n = 0, m = 0;
     // counters
@@ -163,6 +166,8 @@ void ipm_run_all(Ctx &C);            // runs every instance whose IpmState.start
 void ipm_sweep(Ctx &C, bool sqp_level);
 void sqp_stage_kernels(Ctx &C);      // sqp.hip: SQP-level kernels of a sweep
 void launch_qp_gather(Ctx &C);       // COO -> CSC for instances with start set (stage 0)
+// comm.hip
+void comm_release(Ctx &C);
 // mfront.hip
 void mf_factor(Ctx &C, int want, bool with_rhs);
 void mf_solve(Ctx &C, int want, bool skip_fwd);
@@ -176,3 +181,5 @@ void sqp_run(Ctx &C, int max_outer);
 void merit_eval(Ctx &C, int op, double a0, double a1, int flag, double *out_host);
 
 }  // namespace sqphip
+
+struct sqphip_ctx { sqphip::Ctx c; };     // the opaque handle of include/sqphip.h

@@ -489,8 +489,11 @@ void mf_solve(Ctx &C, int want, bool skip_fwd)
     const DV &d = C.d;
     hipStream_t s = C.stream;
     const int generic = mf_generic_solves();
-    // one workgroup per instance when the batch alone fills the chip, else a launch per level
-    static const int inst_min = getenv("SQPHIP_MF_INST_SOLVE_MIN") ? atoi(getenv("SQPHIP_MF_INST_SOLVE_MIN")) : 128;
+    // a launch per level, one wave per (front, instance).  The alternative -- ONE workgroup of 16 waves per instance
+    // walking all levels behind workgroup barriers (k_mf_solve_inst, batch >= SQPHIP_MF_INST_SOLVE_MIN) -- saves the
+    // 2 x levels launches but caps the parallelism at 16 waves per instance: measured 5306 against 5948 QP/s on
+    // 512 x IEEE-118, so it is off unless asked for.
+    static const int inst_min = getenv("SQPHIP_MF_INST_SOLVE_MIN") ? atoi(getenv("SQPHIP_MF_INST_SOLVE_MIN")) : (1 << 30);
     if (d.B >= inst_min && d.mf.max_front * 8 * 16 <= 64 * 1024) {
         hipLaunchKernelGGL(k_mf_solve_inst<16>, dim3(d.B), dim3(1024), (size_t)d.mf.max_front * 8 * 16, s, d, want, skip_fwd ? 0 : 1, generic);
         return;

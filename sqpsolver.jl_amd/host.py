@@ -273,6 +273,27 @@ class Context:
             out.append(r)
         return out
 
+    # ---- multi-GPU status gather (RCCL inside the library)
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        rc = _lib.lib().sqphip_comm_unique_id(C.cast(buf, C.c_void_p))
+        if rc != 0:
+            raise SqpHipError(f"sqphip_comm_unique_id failed ({rc})")
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, world: int, rank: int):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._ck(self.L.sqphip_comm_init(self.h, C.cast(buf, C.c_void_p), int(world), int(rank)))
+
+    def gather_status(self, total: int):
+        ret = np.zeros(total, dtype=np.int32); it = np.zeros(total, dtype=np.int32); done = np.zeros(total, dtype=np.int32)
+        self._ck(self.L.sqphip_gather_status(self.h, int(total), _i(ret), _i(it), _i(done)))
+        return ret, it, done
+
+    def comm_destroy(self):
+        self._ck(self.L.sqphip_comm_destroy(self.h))
+
     def counters(self):
         c = _lib.Counters()
         self._ck(self.L.sqphip_get_counters(self.h, C.byref(c)))

@@ -15,7 +15,7 @@ import scipy.sparse as sp
 
 import sqpsolver_jl_amd as pkg
 from sqpsolver_jl_amd import _lib
-from sqpsolver_jl_amd.acopf_synth import acopf_synth, acopf_layout, contingency, CASES
+from sqpsolver_jl_amd.acopf_synth import acopf_synth, acopf_layout, contingency, renumber_buses, CASES
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -394,7 +394,7 @@ def test_tile_ordered_kkt_matches_oracle():
     try:
         O.set_kkt_order(pos)
         ctx = pkg.Context(lay.n, lay.m, lay.num_linear, lay.jrow, lay.jcol, lay.hrow, lay.hcol, lay.xL, lay.xU,
-                          lay.gL, lay.gU, pkg.default_options(kkt_tile_order=1))
+                          lay.gL, lay.gU, pkg.default_options(kkt_tile_order=1, kkt_mode=1))
         assert ctx.counters()["kkt_order"] == nf
         osolve = _oracle_qp(P, S, O.default_options())
         rng = np.random.default_rng(2)
@@ -412,7 +412,7 @@ def test_tile_ordered_kkt_matches_oracle():
         for quirks in (0, 1):
             kw = dict(max_iter=25, tol_infeas=1e-6, tol_residual=1e-4, literal_quirks=quirks, use_soc=1)
             ctx = pkg.Context(lay.n, lay.m, lay.num_linear, lay.jrow, lay.jcol, lay.hrow, lay.hcol, lay.xL, lay.xU,
-                              lay.gL, lay.gU, pkg.default_options(kkt_tile_order=1, **kw), batch=len(nets))
+                              lay.gL, lay.gU, pkg.default_options(kkt_tile_order=1, kkt_mode=1, **kw), batch=len(nets))
             ctx.acopf_attach(base, lay)
             for b in range(len(nets)):
                 ctx.acopf_set_instance(b, nets[b], lays[b])
@@ -433,7 +433,7 @@ def test_tile_ordered_kkt_matches_oracle():
         try:
             O.set_kkt_order(pos)
             ctx = pkg.Context(Sn["n"], Sn["m"], Sn["num_linear"], Sn["jrow"], Sn["jcol"], Sn["hrow"], Sn["hcol"], Sn["xL"],
-                              Sn["xU"], Sn["gL"], Sn["gU"], pkg.default_options(kkt_tile_order=1))
+                              Sn["xU"], Sn["gL"], Sn["gU"], pkg.default_options(kkt_tile_order=1, kkt_mode=1))
             osolve = _oracle_qp(Pn, Sn, O.default_options())
             x = Pn.x0
             df, E, jv, hv = Pn.eval_grad_f(x), Pn.eval_g(x), Pn.eval_jac_g(x), Pn.eval_h(x, 1.0, np.zeros(Sn["m"]))
@@ -445,39 +445,120 @@ def test_tile_ordered_kkt_matches_oracle():
             O.set_kkt_order(None)
 
 
+def _run_batch(nets, lays, kw, **lin):
+    ctx = pkg.Context(lays[0].n, lays[0].m, lays[0].num_linear, lays[0].jrow, lays[0].jcol, lays[0].hrow, lays[0].hcol,
+                      lays[0].xL, lays[0].xU, lays[0].gL, lays[0].gU, pkg.default_options(**kw, **lin), batch=len(nets))
+    ctx.acopf_attach(nets[0], lays[0])
+    for b in range(len(nets)):
+        ctx.acopf_set_instance(b, nets[b], lays[b])
+    ctx.sqp_reset(); ctx.sqp_run(0)
+    return ctx
+
+
+def _same_decisions(ro, tr):
+    return [(a["iter"], a["accepted"], a["fr"], a["sub_status"]) for a in ro["trace"]] == \
+           [(t["iter"], t["accepted"], t["fr"], t["sub_status"]) for t in tr]
+
+
+# Interior-point iteration counts of two correct implementations of one method.  A sub-problem ends on "error <= tol"
+# or on the acceptable-termination counters (8 consecutive iterates within 100 x tol, 15 within 1000 x tol); near the
+# end of a solve the error sits within a small factor of those thresholds, and which iterate first crosses one depends
+# on the last digits of the Newton directions -- i.e. on the elimination order and the summation order of the
+# factorisation.  Measured on IEEE-118 (scripts/gpu_c118_counts.py): the ORACLE against ITSELF,
+# dense LDL^T in natural order vs its own sparse minimum-degree order, gives [5, 20, 17, 21, 23] / [5, 19, 17, 21, 23]
+# on the base case and [5, 29, 14, 20, 8] / [5, 28, 17, 21, 8] on contingency 7; the device (multifrontal order) gives
+# [5, 20, ...] and [5, 29, 14, 20, 8].  The second sub-problem of each run is a degenerate feasibility-restoration LP:
+# its optimal face is not a point, the two runs leave it at different points (|dx| = 3e-2) and every later count moves.
+# Allowed: two iterations or 20 % per sub-problem.
+def _ipm_counts_close(ro, tr):
+    return all(abs(a["ipm_iters"] - t["ipm_iters"]) <= max(2, 0.2 * a["ipm_iters"]) for a, t in zip(ro["trace"], tr))
+
+
 def test_case118_sqp_first_iterations_match_oracle():
     """The bench workload itself (IEEE-118 shape, the example's SQP options, the reference's Hessian sign, every
-    default of the linear algebra: condensed, 23 independent leading tiles + dense remainder): the first three outer
-    iterations of the base case and of one contingency against the oracle -- every accept / reject / restoration
-    decision and sub-problem status equal, iterates at the truncated-trajectory tolerance, interior-point iteration
-    counts within 30 % per sub-problem (ten in total): at this size the last iterations of a solve sit within a factor of a few of
-    the tolerance and the acceptable-termination counters (8 iterates within 100 x tol) tip on rounding -- the
-    oracle run against itself with a refinement step after every solve (ORA_REFINE_TOL=0) moves the same counts
-    by one or two (20/21, 29/28, 14/16, 22/21; scripts/gpu_c118_compare.py), and every re-ordering of the matrix
-    moves the count of one non-convex sub-problem of the contingency, on either side (26 / 30, 29 / 28, 29 / 36)."""
+    default of the linear algebra: condensed matrix of order 2069 through the multifrontal path): the first four outer
+    iterations of the base case and of two contingencies against the oracle, which factorises with its own sparse
+    LDL^T in its own minimum-degree order -- every accept / reject / restoration decision and sub-problem status
+    equal, interior-point iteration counts as above.  The iterates: a truncated trajectory that went through a
+    degenerate restoration LP is reproducible only as far as the oracle reproduces ITSELF under a re-ordering, so the
+    device is held to the spread between the oracle's sparse and dense runs (never tighter than the truncated-
+    trajectory tolerance); trajectories without that ambiguity agree to 1e-10."""
+    nb, ng, nl, seed = CASES["case118"]
+    base = acopf_synth(nb, ng, nl, seed)
+    nets = [base, contingency(base, 7, seed), contingency(base, 3, seed)]
+    lays = [acopf_layout(nt) for nt in nets]
+    kw = dict(max_iter=4, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=1)
+    ctx = _run_batch(nets, lays, kw)
+    c = ctx.counters()
+    assert c["sparse"] == 1 and c["kkt_order"] == 2069 and c["max_front"] < 128
+    tight = 0
+    for b in range(len(nets)):
+        ro = O.sqp_solve(O.problem_acopf(nets[b], lays[b]), O.default_options(kkt_mode=2, **kw))
+        rd = O.sqp_solve(O.problem_acopf(nets[b], lays[b]), O.default_options(kkt_mode=1, num_threads=host_threads(), **kw))
+        rg = ctx.sqp_get(b); tr = ctx.sqp_trace(b)
+        assert (rg["status"], rg["iter"]) == (ro["status"], ro["iter"]) == (rd["status"], rd["iter"])
+        assert _same_decisions(ro, tr) and _ipm_counts_close(ro, tr)
+        spread = rel(rd["x"], ro["x"])
+        assert rel(rg["x"], ro["x"]) <= max(TOL_TRAJ, 3.0 * spread), (b, spread)
+        tight += spread < 1e-8
+    assert tight >= 1                         # at least one of the three runs is unambiguous and compared at 1e-5
+    ctx.close()
+
+
+def test_case118_dense_tile_order_first_iterations_match_oracle():
+    """The same workload through the dense path (kkt_mode = 1: 23 independent leading tiles + dense remainder on the
+    MFMA kernels), the oracle factorising densely in the product's order (kkt_tile_order = 1) so that both sides stay
+    on one rounding trajectory."""
     nb, ng, nl, seed = CASES["case118"]
     base = acopf_synth(nb, ng, nl, seed)
     nets = [base, contingency(base, 7, seed)]
     lays = [acopf_layout(nt) for nt in nets]
-    kw = dict(max_iter=3, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=1)
-    ctx = pkg.Context(lays[0].n, lays[0].m, lays[0].num_linear, lays[0].jrow, lays[0].jcol, lays[0].hrow, lays[0].hcol,
-                      lays[0].xL, lays[0].xU, lays[0].gL, lays[0].gU, pkg.default_options(**kw), batch=2)
+    kw = dict(max_iter=2, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=1)
+    ctx = _run_batch(nets, lays, kw, kkt_mode=1)
     c = ctx.counters()
-    assert c["lead_tiles"] == 23 and c["kkt_order"] == 2145
-    ctx.acopf_attach(base, lays[0])
-    for b in range(2):
-        ctx.acopf_set_instance(b, nets[b], lays[b])
-    ctx.sqp_reset(); ctx.sqp_run(0)
-    for b in range(2):
-        ro = O.sqp_solve(O.problem_acopf(nets[b], lays[b]), O.default_options(num_threads=host_threads(), **kw))
-        rg = ctx.sqp_get(b); tr = ctx.sqp_trace(b)
-        assert (rg["status"], rg["iter"]) == (ro["status"], ro["iter"])
-        assert [(a["iter"], a["accepted"], a["fr"], a["sub_status"]) for a in ro["trace"]] == \
-               [(t["iter"], t["accepted"], t["fr"], t["sub_status"]) for t in tr]
-        assert all(abs(a["ipm_iters"] - t["ipm_iters"]) <= max(3, 0.3 * a["ipm_iters"]) for a, t in zip(ro["trace"], tr))
-        assert abs(sum(a["ipm_iters"] for a in ro["trace"]) - sum(t["ipm_iters"] for t in tr)) <= 10
-        assert rel(rg["x"], ro["x"]) < TOL_TRAJ and abs(rg["obj_val"] - ro["obj_val"]) <= TOL_TRAJ * abs(ro["obj_val"])
+    assert c["sparse"] == 0 and c["lead_tiles"] == 23 and c["kkt_order"] == 2145
+    try:
+        for b in range(2):
+            ro = O.sqp_solve(O.problem_acopf(nets[b], lays[b]),
+                             O.default_options(num_threads=host_threads(), kkt_mode=1, kkt_tile_order=1, **kw))
+            rg = ctx.sqp_get(b); tr = ctx.sqp_trace(b)
+            assert (rg["status"], rg["iter"]) == (ro["status"], ro["iter"])
+            assert _same_decisions(ro, tr) and _ipm_counts_close(ro, tr)
+            assert rel(rg["x"], ro["x"]) < TOL_TRAJ and abs(rg["obj_val"] - ro["obj_val"]) <= TOL_TRAJ * abs(ro["obj_val"])
+    finally:
+        O.set_kkt_order(None)
     ctx.close()
+
+
+def test_case118_scenarios_converge_like_the_oracle():
+    """IEEE-118 shape run TO CONVERGENCE (textbook Hessian sign, the example's SQP options): the base case, three
+    contingencies and the base case with its buses renumbered at random -- status, iteration count and every
+    accept / reject / restoration decision exact, the optimum at 1e-8 (objective) / 1e-8 relative (point) against the
+    oracle's independent sparse LDL^T.  Termination as /root/reference/src/algorithms/sqp_trust_region.jl:187-204."""
+    nb, ng, nl, seed = CASES["case118"]
+    base = acopf_synth(nb, ng, nl, seed)
+    kw = dict(max_iter=60, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=0)
+    groups = [[base] + [contingency(base, s, seed) for s in (3, 7, 11)], [renumber_buses(base, 5)]]
+    nconv = 0
+    for nets in groups:                                   # a renumbered network has its own sparsity structure
+        lays = [acopf_layout(nt) for nt in nets]
+        ctx = _run_batch(nets, lays, kw)
+        assert ctx.counters()["sparse"] == 1
+        for b in range(len(nets)):
+            ro = O.sqp_solve(O.problem_acopf(nets[b], lays[b]), O.default_options(kkt_mode=2, **kw))
+            rg = ctx.sqp_get(b); tr = ctx.sqp_trace(b)
+            assert (rg["status"], rg["iter"]) == (ro["status"], ro["iter"]), b
+            assert _same_decisions(ro, tr) and _ipm_counts_close(ro, tr), b
+            assert ro["status"] == 0, (b, ro["status"])
+            assert abs(rg["obj_val"] - ro["obj_val"]) <= TOL * abs(ro["obj_val"]), b
+            assert rel(rg["x"], ro["x"]) < TOL, b
+            nconv += 1
+        ctx.close()
+    assert nconv == 5
+    # the renumbered base case is the same optimisation problem: same optimal value as the base case
+    b0 = O.sqp_solve(O.problem_acopf(base, acopf_layout(base)), O.default_options(kkt_mode=2, **kw))
+    b1 = O.sqp_solve(O.problem_acopf(groups[1][0], acopf_layout(groups[1][0])), O.default_options(kkt_mode=2, **kw))
+    assert abs(b0["obj_val"] - b1["obj_val"]) <= 1e-7 * abs(b0["obj_val"])
 
 
 @pytest.mark.parametrize("name", ["hs035", "hs076"])
