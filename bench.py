@@ -313,6 +313,7 @@ def main():
                        "status_gather": "sqphip_gather_status (RCCL)" if use_lib_comm else
                                         ("local" if world == 1 else "torch.distributed " + args.backend),
                        "qp_solved": n_qp, "ipm_iterations": n_ipm, "kkt_factorisations": n_fac,
+                       "sweeps": int(c1["n_sweeps"] - c0["n_sweeps"]),
                        "ipm_iterations_per_qp": n_ipm / max(1.0, n_qp), "factorisations_per_qp": n_fac / max(1.0, n_qp),
                        "instances_done_in_timed_steps": int(np.sum(g_done)),
                        "note": "with literal_quirks = 1 (the reference's JuMP-sign Hessian, SURVEY.md App. C #2) the "

@@ -175,6 +175,13 @@ int sqphip_compute_qmodel(sqphip_ctx *ctx, const double *x, const double *p, con
 /* merit.jl:13-17 + sqp.jl:190-213 (scalar-mu form): D = df'p - mu * sum(viol(E)) */
 int sqphip_compute_derivative(sqphip_ctx *ctx, const double *df, const double *p,
                               const double *E, double mu, double *D);
+/* The whole compute_derivative(sqp) of sqp.jl:190-213 over merit.jl:13-17.  mu_vec (may be NULL): the vector-penalty
+ * forms D = dfp - mu_vec' cons_viol (merit.jl:14,17), else D = dfp - mu sum(cons_viol) (:15,:16).
+ * feasibility_restoration = 1 (sqp.jl:194-203): dfp = sum of the slack values of the last sub-problem (slack[2m] as
+ * sqphip_qp_solve returns them), cons_viol_i = violation of E_i - viol_i. */
+int sqphip_compute_derivative_full(sqphip_ctx *ctx, const double *df, const double *p, const double *E, double mu,
+                                   const double *mu_vec, int32_t feasibility_restoration, const double *slack,
+                                   double *D);
 /* sqp_trust_region.jl:529-538,:574-577: ratio test and radius update.
  * accept_out = 1 if ared > 0 and ared/pred > 0; delta_out the updated radius. */
 int sqphip_tr_update(double ared, double pred, double delta, double pnorm_inf,
@@ -195,6 +202,18 @@ int sqphip_armijo_alpha(double phi0, double D, double eta, double tau, double mi
  *   rule 3: mu_i = max(mu_i, |lambda_i|) */
 int sqphip_compute_mu_rule(int32_t rule, int64_t iter, double rho, double viol1, double dfp, double half_pHp,
                            int64_t m, const double *lambda, double *mu);
+/* The same rules with every reduction on the device (wave-level butterflies + LDS exchange): norm_violations(sqp, 1),
+ * df'p and p'Hp/2 from the iterate (x, E, df, p, Hval in the COO order of the structure; Hval may be NULL), then the
+ * element-wise update of mu[m] (in/out, host memory). */
+int sqphip_compute_mu_rule_dev(sqphip_ctx *ctx, int32_t rule, int64_t iter, double rho, const double *x, const double *E,
+                               const double *df, const double *p, const double *Hval, const double *lambda, double *mu);
+/* compute_alpha (sqp_line_search.jl:303-334) for an instance of the built-in ACOPF evaluator, entirely on the device:
+ * phi(alpha) = f(x + alpha p) + mu |viol(x + alpha p)|_1 (|viol|_1 alone under feasibility restoration,
+ * sqp.jl:170-183) is evaluated by the device callbacks, the backtracking loop alpha <- tau alpha runs inside the kernel
+ * and stops with is_valid = 0 once alpha < min_alpha.  n_eval = merit evaluations made. */
+int sqphip_acopf_armijo(sqphip_ctx *ctx, int32_t inst, const double *x, const double *p, double mu, double phi0,
+                        double D, double eta, double tau, double min_alpha, int32_t feasibility_restoration,
+                        double *alpha, int32_t *is_valid, int32_t *n_eval);
 
 /* ---- device-resident batched SQP-TR over the built-in ACOPF evaluator --------------------------
  * (sqp_trust_region.jl:98-223 for every instance of the batch; callbacks of
@@ -274,6 +293,8 @@ typedef struct {
     int64_t front_doubles;   /* doubles of front storage per instance (L + contribution blocks + right-hand-side rows) */
     int64_t cb_doubles;      /* ... of which contribution blocks (written once by the child, read once by the parent) */
     int64_t factor_launches, solve_launches;   /* kernel launches of one factorisation / of one forward + backward solve */
+    int64_t n_sweeps;        /* passes of the fixed kernel sequence (ipm_sweep) since create / reset: with continuous
+                              * batching the slowest instance of the batch decides this number */
 } sqphip_counters;
 int sqphip_get_counters(sqphip_ctx *ctx, sqphip_counters *c);
 int sqphip_reset_counters(sqphip_ctx *ctx);

@@ -118,6 +118,47 @@ double ora_compute_derivative(double dfp, double mu, int64_t m, const double *co
     return dfp - mu * s;
 }
 
+/* sqp.jl:190-213 (compute_derivative(sqp)) on top of merit.jl:13-17: the whole directional derivative from the
+ * SQP state.  mu_vec != NULL selects the vector-penalty forms (merit.jl:14,17: mu' * cons_viol), else the scalar ones.
+ * feasibility_restoration: dfp is the sum of the slack values of the last sub-problem (slack[0..nslack)), and
+ * cons_viol[i] is the violation of E[i] - viol[i] -- zero up to rounding, restated literally. */
+double ora_compute_derivative_full(int64_t n, int64_t m, const double *df, const double *p, const double *E,
+                                   const double *gL, const double *gU, double mu, const double *mu_vec,
+                                   int feasibility_restoration, const double *slack, int64_t nslack)
+{
+    double dfp = 0.0, acc = 0.0;
+    if (feasibility_restoration) {
+        for (int64_t k = 0; k < nslack; ++k) dfp += slack[k];
+        for (int64_t i = 0; i < m; ++i) {
+            double viol = fmax(0.0, fmax(E[i] - gU[i], gL[i] - E[i]));
+            double lhs = E[i] - viol;
+            double cv = fmax(0.0, fmax(lhs - gU[i], gL[i] - lhs));
+            acc += mu_vec ? mu_vec[i] * cv : cv;
+        }
+    } else {
+        for (int64_t j = 0; j < n; ++j) dfp += df[j] * p[j];
+        for (int64_t i = 0; i < m; ++i) {
+            double cv = fmax(0.0, fmax(E[i] - gU[i], gL[i] - E[i]));
+            acc += mu_vec ? mu_vec[i] * cv : cv;
+        }
+    }
+    return mu_vec ? dfp - acc : dfp - mu * acc;
+}
+
+/* sqp_line_search.jl:270-294: compute_mu_rule1! / rule2! / rule3! (vector penalty mu[m], updated in place).
+ * viol1 = norm_violations(sqp, 1), dfp = df'p, half_pHp = 0.5 p'Hp. */
+void ora_compute_mu_rule(int rule, int64_t iter, double rho, double viol1, double dfp, double half_pHp, int64_t m,
+                         const double *lambda, double *mu)
+{
+    double denom = fmax((1.0 - rho) * viol1, 1.0e-8);
+    double t = (dfp + fmax(half_pHp, 0.0)) / denom;
+    for (int64_t i = 0; i < m; ++i) {
+        if (rule == 1) { mu[i] = fmax(mu[i], t); mu[i] = fmax(mu[i], fabs(lambda[i])); }
+        else if (rule == 2) { if (iter == 1) mu[i] = t; else mu[i] = fmax(mu[i], fabs(lambda[i])); }
+        else mu[i] = fmax(mu[i], fabs(lambda[i]));
+    }
+}
+
 /* sqp_line_search.jl:303-334 */
 double ora_armijo_alpha(double phi0, double dir_deriv, double pnorm_inf, double tol_direction,
                         double eta, double tau, double min_alpha,

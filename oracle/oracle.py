@@ -82,6 +82,10 @@ def lib():
         L.ora_norm_complementarity.argtypes = [C.c_int64, dp, dp, dp, dp, C.c_int]
         L.ora_compute_derivative.restype = C.c_double
         L.ora_compute_derivative.argtypes = [C.c_double, C.c_double, C.c_int64, dp]
+        L.ora_compute_derivative_full.restype = C.c_double
+        L.ora_compute_derivative_full.argtypes = [C.c_int64, C.c_int64, dp, dp, dp, dp, dp, C.c_double, dp, C.c_int, dp, C.c_int64]
+        L.ora_compute_mu_rule.argtypes = [C.c_int, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, dp, dp]
+        L.ora_armijo_alpha.restype = C.c_double
         L.ora_isapprox.restype = C.c_int
         L.ora_isapprox.argtypes = [C.c_double, C.c_double]
         L.ora_qp_create.restype = C.c_void_p

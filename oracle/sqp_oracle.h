@@ -145,6 +145,11 @@ double ora_kt_residuals(int64_t m, int64_t n, const double *df, const double *la
 double ora_norm_complementarity(int64_t m, const double *E, const double *gL, const double *gU,
                                 const double *lambda, int pnorm);
 double ora_compute_derivative(double dfp, double mu, int64_t m, const double *cons_viol);
+double ora_compute_derivative_full(int64_t n, int64_t m, const double *df, const double *p, const double *E,
+                                   const double *gL, const double *gU, double mu, const double *mu_vec,
+                                   int feasibility_restoration, const double *slack, int64_t nslack);
+void ora_compute_mu_rule(int rule, int64_t iter, double rho, double viol1, double dfp, double half_pHp, int64_t m,
+                         const double *lambda, double *mu);
 int ora_isapprox(double a, double b);
 
 /* ---- the QP sub-problem (Ipopt's seat) ---------------------------------------------------- */

@@ -52,7 +52,7 @@ class Counters(C.Structure):
                 ("sparse", C.c_int64), ("nnz_k", C.c_int64), ("nnz_l", C.c_int64), ("n_supernodes", C.c_int64),
                 ("n_levels", C.c_int64), ("max_front", C.c_int64), ("factor_flops", C.c_double),
                 ("front_doubles", C.c_int64), ("cb_doubles", C.c_int64), ("factor_launches", C.c_int64),
-                ("solve_launches", C.c_int64)]
+                ("solve_launches", C.c_int64), ("n_sweeps", C.c_int64)]
 
 
 class SymbolicStats(C.Structure):
@@ -95,6 +95,9 @@ def lib():
             L.sqphip_compute_phi.argtypes = [vp, C.c_double, dp, dp, C.c_double, C.c_int32, dp]
             L.sqphip_compute_qmodel.argtypes = [vp, dp, dp, dp, dp, dp, dp, C.c_double, C.c_int32, dp]
             L.sqphip_compute_derivative.argtypes = [vp, dp, dp, dp, C.c_double, dp]
+            L.sqphip_compute_derivative_full.argtypes = [vp, dp, dp, dp, C.c_double, dp, C.c_int32, dp, dp]
+            L.sqphip_compute_mu_rule_dev.argtypes = [vp, C.c_int32, C.c_int64, C.c_double, dp, dp, dp, dp, dp, dp, dp]
+            L.sqphip_acopf_armijo.argtypes = [vp, C.c_int32, dp, dp] + [C.c_double] * 6 + [C.c_int32, dp, ip, ip]
             L.sqphip_tr_update.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double,
                                            C.c_double, C.c_double, ip, dp]
             L.sqphip_acopf_attach.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, ip, ip, ip, ip, ip,
@@ -130,7 +133,8 @@ EXPORTS = [
     "sqphip_default_options", "sqphip_create", "sqphip_destroy", "sqphip_last_error",
     "sqphip_set_bounds", "sqphip_qp_solve", "sqphip_qp_stats", "sqphip_norm_violations",
     "sqphip_kt_residuals", "sqphip_norm_complementarity", "sqphip_compute_phi",
-    "sqphip_compute_qmodel", "sqphip_compute_derivative", "sqphip_tr_update",
+    "sqphip_compute_qmodel", "sqphip_compute_derivative", "sqphip_compute_derivative_full", "sqphip_compute_mu_rule_dev",
+    "sqphip_acopf_armijo", "sqphip_tr_update",
     "sqphip_kkt_order", "sqphip_kkt_symbolic", "sqphip_mf_host_solve", "sqphip_mf_solve_test", "sqphip_acopf_attach", "sqphip_acopf_set_shunts", "sqphip_acopf_set_dclines", "sqphip_acopf_set_instance", "sqphip_acopf_eval", "sqphip_sqp_reset",
     "sqphip_sqp_run", "sqphip_sqp_get", "sqphip_sqp_status", "sqphip_sqp_trace",
     "sqphip_comm_unique_id", "sqphip_comm_init", "sqphip_gather_status", "sqphip_comm_destroy",

@@ -207,6 +207,7 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
                 M.ev_src_ptr = C.upload(P.ev_src_ptr); M.ev_src = C.upload(nz(P.ev_src));
                 M.level_ptr = C.upload(S.level_ptr); M.level_sn = C.upload(S.level_sn);
                 M.nlevels = S.nlevels; M.max_front = S.max_front;
+                M.sol_items = C.upload(nz(P.sol_items));
                 M.nnzK = (int)P.nnzK;
                 M.vals = C.dalloc<double>((size_t)B * P.nnzK);
                 M.fronts = C.dalloc<double>((size_t)B * P.stride);
@@ -483,6 +484,60 @@ extern "C" int sqphip_compute_derivative(sqphip_ctx *h, const double *df, const 
     });
 }
 
+extern "C" int sqphip_compute_derivative_full(sqphip_ctx *h, const double *df, const double *p, const double *E, double mu,
+                                              const double *mu_vec, int32_t feasibility_restoration, const double *slack,
+                                              double *D)
+{
+    if (!h || !E || !D) return SQPHIP_EINVAL;
+    if (feasibility_restoration ? !slack : (!df || !p)) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) {
+        DV &d = C.d;
+        h2d(C, d.E, E, d.m);
+        if (feasibility_restoration) h2d(C, d.oslack, slack, 2 * (size_t)d.m);
+        else { h2d(C, d.df, df, d.n); h2d(C, d.pstep, p, d.n); }
+        if (mu_vec) h2d(C, d.plam, mu_vec, d.m);
+        merit_eval(C, 6, 0.0, mu, (feasibility_restoration ? 1 : 0) | (mu_vec ? 2 : 0), D);
+        return SQPHIP_OK;
+    });
+}
+
+extern "C" int sqphip_compute_mu_rule_dev(sqphip_ctx *h, int32_t rule, int64_t iter, double rho, const double *x,
+                                          const double *E, const double *df, const double *p, const double *Hval,
+                                          const double *lambda, double *mu)
+{
+    if (!h || rule < 1 || rule > 3 || !x || !E || !df || !p || !lambda || !mu) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) {
+        DV &d = C.d;
+        h2d(C, d.x, x, d.n); h2d(C, d.E, E, d.m); h2d(C, d.df, df, d.n); h2d(C, d.pstep, p, d.n);
+        h2d(C, d.lambda, lambda, d.m); h2d(C, d.plam, mu, d.m);
+        SQPHIP_HIP_OK(hipMemsetAsync(d.jcoo, 0, sizeof(double) * (size_t)d.nnzj_coo, C.stream));
+        if (Hval) h2d(C, d.hcoo, Hval, d.nnzh_coo);
+        else SQPHIP_HIP_OK(hipMemsetAsync(d.hcoo, 0, sizeof(double) * (size_t)d.nnzh_coo, C.stream));
+        double t = 0.0;
+        merit_eval(C, 7, rho, 0.0, rule | ((iter == 1 ? 1 : 0) << 4), &t);
+        d2h(C, mu, d.plam, d.m);
+        SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        return SQPHIP_OK;
+    });
+}
+
+extern "C" int sqphip_acopf_armijo(sqphip_ctx *h, int32_t inst, const double *x, const double *p, double mu, double phi0,
+                                   double D, double eta, double tau, double min_alpha, int32_t feasibility_restoration,
+                                   double *alpha, int32_t *is_valid, int32_t *n_eval)
+{
+    if (!h || !h->c.acopf_attached || inst < 0 || inst >= h->c.d.B || !x || !p || !alpha || !is_valid) return SQPHIP_EINVAL;
+    if (!(tau > 0.0 && tau < 1.0)) return SQPHIP_EINVAL;        // the loop must terminate
+    return guarded(h, [&](Ctx &C) {
+        DV &d = C.d;
+        h2d(C, d.x + (size_t)inst * d.n, x, d.n); h2d(C, d.pstep + (size_t)inst * d.n, p, d.n);
+        double out[3];
+        armijo_eval(C, inst, mu, phi0, D, eta, tau, min_alpha, feasibility_restoration, out);
+        *alpha = out[0]; *is_valid = (int32_t)out[1];
+        if (n_eval) *n_eval = (int32_t)out[2];
+        return SQPHIP_OK;
+    });
+}
+
 extern "C" int sqphip_tr_update(double ared, double pred, double delta, double pnorm_inf, double delta_max,
                                 double tol_direction, int32_t *accept_out, double *delta_out)
 {
@@ -748,6 +803,7 @@ extern "C" int sqphip_get_counters(sqphip_ctx *h, sqphip_counters *c)
         c->ldlt_seconds = C.tm.factor_seconds; c->trailing_seconds = C.tm.trailing_seconds;
         c->solve_seconds = C.tm.solve_seconds; c->total_seconds = C.total_seconds;
         c->trailing_launches = C.tm.trailing_launches;
+        c->n_sweeps = C.n_sweeps;
         c->sparse = C.d.sparse; c->nnz_k = 0; c->nnz_l = 0; c->n_supernodes = 0; c->n_levels = 0; c->max_front = 0;
         c->factor_flops = 0; c->front_doubles = 0; c->cb_doubles = 0; c->factor_launches = 0; c->solve_launches = 0;
         if (C.d.sparse) {
@@ -772,7 +828,7 @@ extern "C" int sqphip_reset_counters(sqphip_ctx *h)
     C.tm.flush();
     C.tm.trailing_seconds = C.tm.factor_seconds = C.tm.solve_seconds = 0;
     C.tm.trailing_launches = 0; C.tm.n_factor = 0;
-    C.n_qp = C.n_ipm_iter = C.n_factor = 0; C.total_seconds = 0;
+    C.n_qp = C.n_ipm_iter = C.n_factor = 0; C.total_seconds = 0; C.n_sweeps = 0;
     return SQPHIP_OK;
 }
 

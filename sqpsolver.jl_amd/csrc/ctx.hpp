@@ -56,7 +56,7 @@ struct MfDev {
     const int *ev_ptr, *ev_idx, *ev_src_ptr, *ev_src;
     const int *level_ptr, *level_sn;      // supernodes by level of the assembly tree (leaves first)
     int nlevels, max_front;
-    const int *sched;
+    const int *sched, *sol_items;
     int nnzK;                             // destinations (structural entries of the lower triangle)
     double *vals;                         // [B][nnzK] assembled values of the destinations (k_mf_values)
 };
@@ -125,7 +125,7 @@ struct Ctx {
     DV d;                       // device view (pointers into the arenas below)
     LdltPlan plan;
     MfPlan mfp;                 // multifrontal plan (d.sparse)
-    long mf_factor_launches = 0;
+    long mf_factor_launches = 0, n_sweeps = 0;
     Timers tm;
     std::vector<void *> allocs;
     std::string err;
@@ -179,6 +179,8 @@ void launch_acopf_eval_point(Ctx &C, int inst, const double *x_dev, double sigma
 void sqp_reset(Ctx &C);
 void sqp_run(Ctx &C, int max_outer);
 void merit_eval(Ctx &C, int op, double a0, double a1, int flag, double *out_host);
+void armijo_eval(Ctx &C, int inst, double mu, double phi0, double D, double eta, double tau, double min_alpha, int fr,
+                 double *out3_host);
 
 }  // namespace sqphip
 

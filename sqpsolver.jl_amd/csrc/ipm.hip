@@ -820,6 +820,7 @@ void ipm_sweep(Ctx &C, bool sqp_level)
     DV &d = C.d;
     hipStream_t s = C.stream;
     const dim3 gB(d.B), bT(TPB);
+    C.n_sweeps++;
     hipLaunchKernelGGL(k_qp_finish, gB, bT, 0, s, d);
     if (sqp_level) sqp_stage_kernels(C);
     hipLaunchKernelGGL(k_qp_gather, gB, bT, 0, s, d);

@@ -169,14 +169,30 @@ MfPlan mf_build_plan(int n, int m, const std::vector<int> &kpos, int mk, const s
             P.fac.push_back(L);
         }
     }
-    // solves: one launch per level, one wave per front (the fronts of a level in one block of `sched`)
+    // solves: one launch per level; a workgroup of four waves takes one front of more than 64 rows or four smaller ones
+    const bool big_solve = !(getenv("SQPHIP_MF_BIG_SOLVE") && atoi(getenv("SQPHIP_MF_BIG_SOLVE")) == 0);   // experiment switch
     for (int l = 0; l < S.nlevels; ++l) {
-        MfLaunch L{(int)P.sched.size(), S.level_ptr[l + 1] - S.level_ptr[l], 64, 0, 0, 0};
+        MfLaunch L{(int)P.sol_items.size() / 2, 0, 256, 0, 0, 0};
+        int maxfs = 64;
+        std::vector<int> small;
         for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; ++q) {
-            const int s = S.level_sn[q];
-            P.sched.push_back(s);
-            L.lds_bytes = std::max(L.lds_bytes, (S.sn_nc[s] + S.sn_nr[s]) * 8);     // one vector of the front's height
+            const int s = S.level_sn[q], fs = S.sn_nc[s] + S.sn_nr[s];
+            if (!big_solve) maxfs = std::max(maxfs, fs);
+            if (fs > 64 && big_solve) {
+                P.sol_items.push_back((int)P.sched.size()); P.sol_items.push_back(1 | (1 << 8));
+                P.sched.push_back(s);
+                maxfs = std::max(maxfs, fs);
+            } else small.push_back(s);
         }
+        for (size_t q = 0; q < small.size(); q += 4) {
+            const int cnt = (int)std::min<size_t>(4, small.size() - q);
+            P.sol_items.push_back((int)P.sched.size()); P.sol_items.push_back(cnt);
+            for (int t = 0; t < cnt; ++t) P.sched.push_back(small[q + t]);
+        }
+        L.count = (int)P.sol_items.size() / 2 - L.begin;
+        // four wave vectors, or one front vector + 16 block sums; tiles = doubles per wave vector
+        L.tiles = big_solve ? 64 : maxfs;
+        L.lds_bytes = 8 * std::max(4 * L.tiles, maxfs + 16);
         P.fwd.push_back(L);
     }
     P.bwd.assign(P.fwd.rbegin(), P.fwd.rend());

@@ -414,21 +414,111 @@ __device__ __forceinline__ void mf_front_bwd(const DV &d, int inst, int s, doubl
     }
 }
 
-// level-by-level launches: one wave per (front of the level, instance) -- few instances, wide levels
-__global__ __launch_bounds__(64) void k_mf_fwd(DV d, int sbegin, int want, int generic)
+// A front of more than 64 rows, by the four waves of a workgroup: 16 columns at a time, the 16 x 16 diagonal block by a
+// shuffle chain in wave 0 (its column loads are independent of the chain and issued up front), the rows below the
+// block by all 256 threads.  Two barriers per 16 columns instead of one dependent step per column.
+__device__ __forceinline__ void mf_front_fwd_big(const DV &d, int inst, int s, double *y, int tid)
 {
-    const int inst = blockIdx.y;
-    if (d.phase[inst] != want) return;
-    extern __shared__ double mf_lds[];
-    mf_front_fwd(d, inst, d.mf.sched[sbegin + blockIdx.x], mf_lds, threadIdx.x, generic);
+    const MfDev &M = d.mf;
+    const int nc = M.nc[s], nr = M.nr[s], fs = nc + nr, ld = fs + 1, f0 = M.first[s];
+    const double *arena = M.fronts + (long)inst * M.stride;
+    double *G = M.fronts + (long)inst * M.stride + M.off[s];
+    const double *b = d.xv + (long)inst * d.Fpad + f0, *dinv = d.dinv + (long)inst * d.Fpad + f0;
+    double *vv = d.vv + (long)inst * d.Fpad + f0;
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < fs; i += 256) y[i] = i < nc ? b[i] : 0.0;
+    __syncthreads();
+    for (int t = M.ev_ptr[s] + tid; t < M.ev_ptr[s + 1]; t += 256) {
+        double a = 0.0;
+        for (int q = M.ev_src_ptr[t]; q < M.ev_src_ptr[t + 1]; ++q) a += arena[M.ev_src[q]];
+        y[M.ev_idx[t]] += a;
+    }
+    __syncthreads();
+    for (int kb = 0; kb < nc; kb += 16) {
+        const int nb = nc - kb < 16 ? nc - kb : 16;
+        if (wave == 0) {
+            double l[15];
+#pragma unroll
+            for (int c = 0; c < 15; ++c) l[c] = (c < nb - 1 && lane > c && lane < nb) ? G[(long)(kb + c) * ld + kb + lane] : 0.0;
+            double yi = lane < nb ? y[kb + lane] : 0.0;
+#pragma unroll
+            for (int c = 0; c < 15; ++c) yi -= l[c] * __shfl(yi, c);
+            if (lane < nb) { y[kb + lane] = yi; vv[kb + lane] = yi * dinv[kb + lane]; }
+        }
+        __syncthreads();
+        for (int i = kb + nb + tid; i < fs; i += 256) {
+            double acc = 0.0;
+#pragma unroll 16
+            for (int c = 0; c < nb; ++c) acc += G[(long)(kb + c) * ld + i] * y[kb + c];
+            y[i] -= acc;
+        }
+        __syncthreads();
+    }
+    for (int i = nc + tid; i < fs; i += 256) G[(long)i * ld + fs] = y[i];
 }
 
-__global__ __launch_bounds__(64) void k_mf_bwd(DV d, int sbegin, int want, int generic)
+__device__ __forceinline__ void mf_front_bwd_big(const DV &d, int inst, int s, double *x, int tid)
+{
+    const MfDev &M = d.mf;
+    const int nc = M.nc[s], nr = M.nr[s], fs = nc + nr, ld = fs + 1, f0 = M.first[s];
+    const double *G = M.fronts + (long)inst * M.stride + M.off[s];
+    double *xg = d.xv + (long)inst * d.Fpad;
+    const double *vv = d.vv + (long)inst * d.Fpad + f0;
+    const int *rows = M.rows + M.rowptr[s];
+    const int lane = tid & 63, wave = tid >> 6;
+    double *part = x + fs;                       // 16 block sums behind the vector
+    for (int i = tid; i < fs; i += 256) x[i] = i < nc ? vv[i] : xg[rows[i - nc]];
+    __syncthreads();
+    for (int kb = ((nc - 1) >> 4) << 4; kb >= 0; kb -= 16) {
+        const int nb = nc - kb < 16 ? nc - kb : 16;
+        {   // column c of the block by 16 threads: its dot product with x below the block
+            const int c = tid >> 4, r = tid & 15;
+            double a = 0.0;
+            if (c < nb) {
+                const double *Gc = G + (long)(kb + c) * ld;
+                for (int i = kb + nb + r; i < fs; i += 16) a += Gc[i] * x[i];
+            }
+            a += __shfl_xor(a, 8); a += __shfl_xor(a, 4); a += __shfl_xor(a, 2); a += __shfl_xor(a, 1);
+            if (r == 0) part[c] = a;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            double l[15];
+#pragma unroll
+            for (int c = 1; c < 16; ++c) l[c - 1] = (c < nb && lane < c) ? G[(long)(kb + lane) * ld + kb + c] : 0.0;
+            double t = lane < nb ? x[kb + lane] - part[lane] : 0.0;
+#pragma unroll
+            for (int c = 15; c > 0; --c) t -= l[c - 1] * __shfl(t, c);
+            if (lane < nb) { x[kb + lane] = t; xg[f0 + kb + lane] = t; }
+        }
+        __syncthreads();
+    }
+}
+
+// level-by-level launches: a workgroup of four waves per work item = one front of more than 64 rows (all four waves)
+// or up to four smaller fronts (one wave each; nothing but wave-level synchronisation on that path)
+__global__ __launch_bounds__(256) void k_mf_fwd(DV d, int ibegin, int want, int generic, int wstride)
 {
     const int inst = blockIdx.y;
     if (d.phase[inst] != want) return;
     extern __shared__ double mf_lds[];
-    mf_front_bwd(d, inst, d.mf.sched[sbegin + blockIdx.x], mf_lds, threadIdx.x, generic);
+    const MfDev &M = d.mf;
+    const int q0 = M.sol_items[2 * (ibegin + blockIdx.x)], info = M.sol_items[2 * (ibegin + blockIdx.x) + 1];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (info >> 8) mf_front_fwd_big(d, inst, M.sched[q0], mf_lds, threadIdx.x);
+    else if (wave < (info & 255)) mf_front_fwd(d, inst, M.sched[q0 + wave], mf_lds + wstride * wave, threadIdx.x & 63, generic);
+}
+
+__global__ __launch_bounds__(256) void k_mf_bwd(DV d, int ibegin, int want, int generic, int wstride)
+{
+    const int inst = blockIdx.y;
+    if (d.phase[inst] != want) return;
+    extern __shared__ double mf_lds[];
+    const MfDev &M = d.mf;
+    const int q0 = M.sol_items[2 * (ibegin + blockIdx.x)], info = M.sol_items[2 * (ibegin + blockIdx.x) + 1];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (info >> 8) mf_front_bwd_big(d, inst, M.sched[q0], mf_lds, threadIdx.x);
+    else if (wave < (info & 255)) mf_front_bwd(d, inst, M.sched[q0 + wave], mf_lds + wstride * wave, threadIdx.x & 63, generic);
 }
 
 // whole solve of one instance by ONE workgroup of NWV waves: the waves deal out the fronts of a level, a workgroup
@@ -500,9 +590,9 @@ void mf_solve(Ctx &C, int want, bool skip_fwd)
     }
     if (!skip_fwd)
         for (const MfLaunch &L : C.mfp.fwd)
-            hipLaunchKernelGGL(k_mf_fwd, dim3(L.count, d.B), dim3(64), L.lds_bytes, s, d, L.begin, want, generic);
+            hipLaunchKernelGGL(k_mf_fwd, dim3(L.count, d.B), dim3(256), L.lds_bytes, s, d, L.begin, want, generic, L.tiles);
     for (const MfLaunch &L : C.mfp.bwd)
-        hipLaunchKernelGGL(k_mf_bwd, dim3(L.count, d.B), dim3(64), L.lds_bytes, s, d, L.begin, want, generic);
+        hipLaunchKernelGGL(k_mf_bwd, dim3(L.count, d.B), dim3(256), L.lds_bytes, s, d, L.begin, want, generic, L.tiles);
 }
 
 }  // namespace sqphip

@@ -98,6 +98,10 @@ struct MfPlan {
     // the same for vectors (forward solves): per front the local indices that receive a child's update
     // [ev_ptr[s], ev_ptr[s+1]), each with its sources (offsets of the children's update entries in the arena)
     std::vector<int> ev_ptr, ev_idx, ev_src_ptr, ev_src;
+    // solve launches: work items of one 256-thread workgroup each = one front of more than 64 rows (the four waves
+    // share it) or up to four smaller fronts (one wave each): sol_items[2 q] = first entry in `sched`,
+    // sol_items[2 q + 1] = count | big << 8
+    std::vector<int> sol_items;
     std::vector<int> sched;                      // fronts in launch order
     std::vector<MfLaunch> fac, fwd, bwd;
     long nnzK = 0;                               // structural entries of the lower triangle (destinations)

@@ -492,6 +492,8 @@ void sqp_run(Ctx &C, int max_outer)
     for (long sweep = 0; sweep < 100000000L; ++sweep) {
         ipm_sweep(C, /*sqp_level=*/true);
         read_sqp_counters(C);
+        static const bool sweep_log = getenv("SQPHIP_SWEEP_LOG") != nullptr;    // instances with work left, per sweep
+        if (sweep_log) fprintf(stderr, "%d%c", C.h_counters[2], (sweep % 32) == 31 ? '\n' : ' ');
         if (C.tm.pending_trailing.size() > 4096) C.tm.flush();
         if (C.h_counters[2] == 0) break;
     }
@@ -568,8 +570,84 @@ __global__ __launch_bounds__(TPB) void k_merit(DV d, int op, double a0, double a
         for (int i = threadIdx.x; i < d.m; i += TPB) cv += fmax(0.0, fmax(E[i] - gU[i], gL[i] - E[i]));
         dfp = block_reduce<OpSum>(dfp); cv = block_reduce<OpSum>(cv);
         r = dfp - a1 * cv;
+    } else if (op == 6) {
+        // compute_derivative(sqp), sqp.jl:190-213 over merit.jl:13-17.  flag bit 0: feasibility restoration (dfp =
+        // sum of the slacks staged in oslack), bit 1: vector penalty staged in plam
+        const bool fr = flag & 1, vec = flag & 2;
+        const double *slack = d.oslack;
+        double dfp = 0.0, cv = 0.0;
+        if (fr) { for (int k = threadIdx.x; k < 2 * d.m; k += TPB) dfp += slack[k]; }
+        else for (int j = threadIdx.x; j < d.n; j += TPB) dfp += df[j] * ps[j];
+        for (int i = threadIdx.x; i < d.m; i += TPB) {
+            double v = fmax(0.0, fmax(E[i] - gU[i], gL[i] - E[i]));
+            if (fr) { const double lhs = E[i] - v; v = fmax(0.0, fmax(lhs - gU[i], gL[i] - lhs)); }
+            cv += vec ? plam[i] * v : v;
+        }
+        dfp = block_reduce<OpSum>(dfp); cv = block_reduce<OpSum>(cv);
+        r = vec ? dfp - cv : dfp - a1 * cv;
+    } else if (op == 7) {
+        // compute_mu_rule1! / 2! / 3! (sqp_line_search.jl:270-294): a0 = rho, flag = rule | (iter == 1) << 4;
+        // mu[m] staged in plam (updated in place), lambda in lam
+        const int rule = flag & 15, first = flag >> 4;
+        double dfp = 0.0, php = 0.0;
+        gather_csc(d, jcoo, hcoo, jv, d.nnzh_coo ? hv : nullptr);
+        __syncthreads();
+        for (int j = threadIdx.x; j < d.n; j += TPB) {
+            double hp = 0.0;
+            for (int k = d.hcolptr[j]; k < d.hcolptr[j + 1]; ++k) hp += hv[k] * ps[d.hrowval[k]];
+            dfp += df[j] * ps[j]; php += 0.5 * ps[j] * hp;
+        }
+        dfp = block_reduce<OpSum>(dfp); php = block_reduce<OpSum>(php);
+        const double v1 = viol1(d, E, gL, gU, x, xL, xU);
+        const double t = (dfp + fmax(php, 0.0)) / fmax((1.0 - a0) * v1, 1.0e-8);
+        for (int i = threadIdx.x; i < d.m; i += TPB) {
+            double mu = plam[i];
+            if (rule == 1) { mu = fmax(mu, t); mu = fmax(mu, fabs(lam[i])); }
+            else if (rule == 2) mu = first ? t : fmax(mu, fabs(lam[i]));
+            else mu = fmax(mu, fabs(lam[i]));
+            plam[i] = mu;
+        }
+        r = t;
     }
     if (threadIdx.x == 0) *out = r;
+}
+
+// compute_alpha (sqp_line_search.jl:303-334) on the device: x and p of instance `inst` are staged in d.x / d.pstep;
+// out[0] = alpha, out[1] = is_valid, out[2] = merit evaluations.  One workgroup; the merit function is
+// compute_phi (sqp.jl:170-183) over the device callbacks, its norms reduced by wave butterflies + an LDS exchange.
+__global__ __launch_bounds__(TPB) void k_armijo(DV d, int inst, double mu, double phi0, double D, double eta, double tau,
+                                                double min_alpha, int fr, double *out)
+{
+    SQP_PTRS
+    const double pn = norm_inf(ps, d.n);
+    double alpha = 1.0;
+    int valid = 1, nev = 0;
+    if (!(pn <= d.tol_direction)) {
+        __shared__ double fsh;
+        for (;;) {
+            for (int j = threadIdx.x; j < d.n; j += TPB) tmpx[j] = x[j] + alpha * ps[j];
+            __syncthreads();
+            acopf_eval(d, inst, tmpx, 1.0, nullptr, &fsh, nullptr, tmpE, nullptr, nullptr);
+            __syncthreads();
+            const double v = viol1(d, tmpE, gL, gU, tmpx, xL, xU);
+            const double phi = fr ? v : fsh + mu * v;
+            ++nev;
+            if (!(phi > phi0 + eta * alpha * D)) break;
+            if (alpha < min_alpha) { valid = 0; break; }     // the step size can become too small
+            alpha *= tau;
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) { out[0] = alpha; out[1] = valid; out[2] = nev; }
+}
+
+void armijo_eval(Ctx &C, int inst, double mu, double phi0, double D, double eta, double tau, double min_alpha, int fr,
+                 double *out3_host)
+{
+    double *o = C.d.wN + (size_t)inst * C.d.Npad;     // scratch slots
+    hipLaunchKernelGGL(k_armijo, dim3(1), dim3(TPB), 0, C.stream, C.d, inst, mu, phi0, D, eta, tau, min_alpha, fr, o);
+    SQPHIP_HIP_OK(hipMemcpyAsync(out3_host, o, 3 * sizeof(double), hipMemcpyDeviceToHost, C.stream));
+    SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
 }
 
 void merit_eval(Ctx &C, int op, double a0, double a1, int flag, double *out_host)

@@ -153,6 +153,29 @@ class Context:
         return dict(p=p, lam=lam, mult_x_U=mu_u, mult_x_L=mu_l, slack=slack, status=st.value,
                     ipm_iters=it.value, n_factor=nf.value)
 
+    def compute_derivative_full(self, df, p, E, mu, mu_vec=None, feasibility_restoration=False, slack=None):
+        """compute_derivative(sqp) of sqp.jl:190-213 over merit.jl:13-17 (vector penalty, restoration branch)."""
+        out = C.c_double()
+        self._ck(self.L.sqphip_compute_derivative_full(self.h, _d(_f(df)), _d(_f(p)), _d(_f(E)), float(mu), _d(_f(mu_vec)),
+                                                       int(feasibility_restoration), _d(_f(slack)), C.byref(out)))
+        return out.value
+
+    def compute_mu_rule(self, rule, it, rho, x, E, df, p, hval, lam, mu):
+        """compute_mu_rule1! / 2! / 3! (sqp_line_search.jl:270-294) with the reductions on the device; returns mu."""
+        mu = _f(mu).copy()
+        self._ck(self.L.sqphip_compute_mu_rule_dev(self.h, int(rule), int(it), float(rho), _d(_f(x)), _d(_f(E)), _d(_f(df)),
+                                                   _d(_f(p)), _d(_f(hval)) if hval is not None and len(hval) else None,
+                                                   _d(_f(lam)), _d(mu)))
+        return mu
+
+    def acopf_armijo(self, inst, x, p, mu, phi0, D, eta=0.4, tau=0.9, min_alpha=1e-6, feasibility_restoration=False):
+        """compute_alpha (sqp_line_search.jl:303-334) on the device: (alpha, is_valid, merit evaluations)."""
+        al = C.c_double(); ok = C.c_int32(); ne = C.c_int32()
+        self._ck(self.L.sqphip_acopf_armijo(self.h, inst, _d(_f(x)), _d(_f(p)), float(mu), float(phi0), float(D), float(eta),
+                                            float(tau), float(min_alpha), int(feasibility_restoration), C.byref(al),
+                                            C.byref(ok), C.byref(ne)))
+        return al.value, bool(ok.value), ne.value
+
     def mf_solve_test(self, inst, jval, hval, Dd, sigp, hd, rtype, hsc, dw, rhs):
         """Kernel-level hook of the multifrontal path: (sol_fused, sol_standalone, dinv_by_unknown)."""
         rhs = _f(rhs); a = np.zeros_like(rhs); b = np.zeros_like(rhs); dv = np.zeros_like(rhs)

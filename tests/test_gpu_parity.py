@@ -169,6 +169,63 @@ def test_merit_kernels_match_oracle():
     ctx.close()
 
 
+def test_merit_remainders_match_oracle():
+    """The rest of the merit path against the oracle's restatements: compute_derivative(sqp) with scalar and vector
+    penalty and its feasibility-restoration branch (merit.jl:13-17, sqp.jl:190-213), the three penalty rules
+    (sqp_line_search.jl:270-294) and the Armijo backtracking loop (sqp_line_search.jl:303-334) -- all with their
+    reductions on the device, the Armijo loop with the device ACOPF callbacks inside the kernel."""
+    nb, ng, nl, seed = CASES["case14"]
+    net = acopf_synth(nb, ng, nl, seed); lay = acopf_layout(net)
+    P = O.problem_acopf(net, lay)
+    ctx = pkg.Context(lay.n, lay.m, lay.num_linear, lay.jrow, lay.jcol, lay.hrow, lay.hcol, lay.xL, lay.xU,
+                      lay.gL, lay.gU, batch=2)
+    ctx.acopf_attach(net, lay)
+    for b in range(2):
+        ctx.acopf_set_instance(b, net, lay)
+    L = O.lib()
+    gL, gU = O.f64(lay.gL), O.f64(lay.gU)
+    rng = np.random.default_rng(11)
+    x = np.clip(lay.x0 + 0.05 * rng.standard_normal(lay.n), lay.xL, lay.xU); p = 0.05 * rng.standard_normal(lay.n)
+    lam = rng.standard_normal(lay.m); muv = rng.random(lay.m) * 10; slack = rng.random(2 * lay.m)
+    E, df, hc = P.eval_g(x), P.eval_grad_f(x), P.eval_h(x, 1.0, lam)
+    for vec in (None, muv):
+        for fr in (0, 1):
+            want = L.ora_compute_derivative_full(lay.n, lay.m, O._d(df), O._d(p), O._d(E), O._d(gL), O._d(gU), 7.0,
+                                                 O._d(vec) if vec is not None else None, fr, O._d(slack), 2 * lay.m)
+            got = ctx.compute_derivative_full(df, p, E, 7.0, mu_vec=vec, feasibility_restoration=bool(fr), slack=slack)
+            assert math.isclose(got, want, rel_tol=1e-11, abs_tol=1e-12), (vec is not None, fr)
+    # penalty rules: the oracle gets the three reductions from numpy, the device computes them itself
+    Hl = sp.coo_matrix((hc, (lay.hrow - 1, lay.hcol - 1)), shape=(lay.n, lay.n)).toarray()
+    H = Hl + Hl.T - np.diag(np.diag(Hl))
+    v1 = O.norm_violations(E, lay.gL, lay.gU, x, lay.xL, lay.xU, 1)
+    for rule in (1, 2, 3):
+        for it in (1, 4):
+            want = muv.copy()
+            L.ora_compute_mu_rule(rule, it, 0.8, v1, float(df @ p), float(0.5 * p @ H @ p), lay.m, O._d(lam), O._d(want))
+            got = ctx.compute_mu_rule(rule, it, 0.8, x, E, df, p, hc, lam, muv)
+            assert rel(got, want) < 1e-11, (rule, it)
+    # Armijo: phi(alpha) of compute_phi (sqp.jl:170-183) through the oracle's callbacks vs. inside the kernel
+    import ctypes as C_
+    PHI = C_.CFUNCTYPE(C_.c_double, C_.c_void_p, C_.c_double)
+    for mu, fr, scale in ((50.0, False, 1.0), (50.0, False, 40.0), (1.0, True, 10.0)):
+        pp = scale * p
+        phi = lambda a: (0.0 if fr else P.eval_f(x + a * pp)) + (1.0 if fr else mu) * O.norm_violations(
+            P.eval_g(x + a * pp), lay.gL, lay.gU, x + a * pp, lay.xL, lay.xU, 1)
+        phi0 = phi(0.0)
+        D = L.ora_compute_derivative_full(lay.n, lay.m, O._d(df), O._d(pp), O._d(E), O._d(gL), O._d(gU), mu, None, 0, None, 0)
+        n_or = [0]
+
+        def cb(_, a):
+            n_or[0] += 1
+            return phi(a)
+        valid = C_.c_int()
+        L.ora_armijo_alpha.argtypes = [C_.c_double] * 7 + [PHI, C_.c_void_p, C_.POINTER(C_.c_int)]
+        a_or = L.ora_armijo_alpha(phi0, D, float(np.abs(pp).max()), 1e-8, 0.4, 0.9, 1e-6, PHI(cb), None, C_.byref(valid))
+        a_gp, ok, nev = ctx.acopf_armijo(1, x, pp, mu, phi0, D, 0.4, 0.9, 1e-6, fr)
+        assert (a_gp, ok, nev) == (a_or, bool(valid.value), n_or[0]), (mu, fr, scale)
+    ctx.close()
+
+
 # ------------------------------------------------------------------ Q1..Q7: sub-problem modes
 def _oracle_qp(P, S, opts=None):
     n = S["n"]
