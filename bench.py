@@ -69,6 +69,7 @@ def main():
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank flow "
                          "on a box with fewer GPUs than ranks, together with --one-device)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--dump-status", default=None, help="rank 0 writes the gathered (ret, iter, done) table to this JSON file")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -287,6 +288,9 @@ def main():
                          f"minimum-degree order), one scenario per thread on {cores} host threads, {tb - ta:.1f} s; CPU "
                          f"restatement (oracle/), not Julia/Ipopt"}
 
+    if rank == 0 and args.dump_status:
+        with open(args.dump_status, "w") as fh:
+            json.dump({"ret": g_ret.tolist(), "iter": g_it.tolist(), "done": g_done.tolist()}, fh)
     if rank == 0:
         out = {
             "metric": "QP subproblems/sec on batched ACOPF; fp64 KKT LDL^T TFLOPS vs MFMA peak",

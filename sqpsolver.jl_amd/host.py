@@ -67,7 +67,8 @@ def kkt_order(n, m, jrow, jcol, hrow, hcol, gL, gU, rows_last=True):
     """(pos, n_lead_tiles, order) of `sqphip_kkt_order`: host-only, works without a GPU."""
     L = _lib.lib()
     jr, jc, hr, hc = (np.ascontiguousarray(a, dtype=np.int64) for a in (jrow, jcol, hrow, hcol))
-    mk = int(np.sum(np.asarray(gL) == np.asarray(gU)))
+    # rows that stay in the condensed matrix: the equalities and rows with more than 32 entries (csrc/sparse.hpp)
+    mk = int(np.sum((np.asarray(gL) == np.asarray(gU)) | (np.bincount(jr - 1, minlength=m) > 32)))
     pos = np.zeros(n + mk, dtype=np.int32); ts = C.c_int32(); nf = C.c_int32()
     rc = L.sqphip_kkt_order(n, m, len(jr), jr.ctypes.data_as(C.POINTER(C.c_int64)), jc.ctypes.data_as(C.POINTER(C.c_int64)),
                             len(hr), hr.ctypes.data_as(C.POINTER(C.c_int64)), hc.ctypes.data_as(C.POINTER(C.c_int64)),

@@ -92,6 +92,130 @@ def test_ldlt_full_size_residuals():
     assert np.abs(Lm @ (Lm.T / dinv[0][:, None]) - As[0]).max() < 1e-10
 
 
+# ------------------------------------------------------------------ K6 / sparse K7: multifrontal LDL^T and solves
+def _newton_values(lay, seed, free_frac=0.1):
+    rng = np.random.default_rng(seed)
+    eq = lay.gL == lay.gU
+    Dd = rng.uniform(0.1, 10, lay.m); Dd[eq] = rng.uniform(0, 1e-3, eq.sum())
+    rt = np.ones(lay.m, dtype=np.int32); rt[rng.uniform(size=lay.m) < free_frac] = 0
+    return (rng.normal(size=len(lay.jrow)), 0.1 * rng.normal(size=len(lay.hrow)), Dd, rng.uniform(1, 20, lay.n),
+            rng.uniform(0, 1, lay.n), rt)
+
+
+def _sparse_newton(lay, Jv, Hv, Dd, sigp, hd, rt, hsc, dw):
+    """The condensed Newton matrix as a scipy sparse matrix (independent assembly), unknowns = variables, kept rows."""
+    n, m = lay.n, lay.m
+    J = sp.coo_matrix((Jv, (lay.jrow - 1, lay.jcol - 1)), shape=(m, n)).tocsr()
+    Hl = sp.coo_matrix((Hv, (lay.hrow - 1, lay.hcol - 1)), shape=(n, n)).tocsr()
+    H = Hl + Hl.T - sp.diags(Hl.diagonal())
+    kept = lay.gL == lay.gU
+    act = sp.diags((rt != 0).astype(float))
+    J = act @ J
+    el = np.flatnonzero(~kept & (rt != 0))
+    Je = J[el]
+    W = hsc * H + sp.diags(hd + sigp + dw + 1e-8) + Je.T @ sp.diags(1.0 / (Dd[el] + 1e-8)) @ Je
+    Jk = J[np.flatnonzero(kept)]
+    Dk = np.where(rt[kept] != 0, Dd[kept] + 1e-8, 1.0)
+    return sp.bmat([[W, Jk.T], [Jk, -sp.diags(Dk)]]).tocsr()
+
+
+@pytest.mark.parametrize("case,cond", [("case14", 1), ("case14", 0), ("case118", 1), ("case118", 0), ("case1354", 1),
+                                       ("case9241", 1)])
+def test_multifrontal_kernels_match_host_reference(case, cond):
+    """The device kernels of the sparse path (value assembly, MFMA front kernel with the fused forward elimination,
+    stand-alone forward / backward solves) on the plan of each case shape, against the library's host reference of
+    the same plan (1e-11) and -- through the residual of an independently assembled sparse matrix -- against the
+    mathematics; inertia from the pivot signs."""
+    nb, ng, nl, seed = CASES[case]
+    lay = acopf_layout(acopf_synth(nb, ng, nl, seed))
+    Jv, Hv, Dd, sigp, hd, rt = _newton_values(lay, 1)
+    ctx = pkg.Context(lay.n, lay.m, lay.num_linear, lay.jrow, lay.jcol, lay.hrow, lay.hcol, lay.xL, lay.xU, lay.gL,
+                      lay.gU, pkg.default_options(kkt_mode=2, kkt_condense=cond), batch=2)
+    c = ctx.counters()
+    mk = int((lay.gL == lay.gU).sum()) if cond else lay.m
+    assert c["sparse"] == 1 and c["kkt_order"] == lay.n + mk and c["nnz_l"] > 0
+    rhs = np.random.default_rng(2).normal(size=lay.n + mk)
+    ref, dref, npos = pkg.mf_host_solve(lay.n, lay.m, lay.jrow, lay.jcol, lay.hrow, lay.hcol, lay.gL, lay.gU, cond, Jv, Hv,
+                                        Dd, sigp, hd, rt, 0.7, 1e-3, rhs)
+    assert npos == lay.n
+    for inst in (0, 1):
+        fused, alone, dv = ctx.mf_solve_test(inst, Jv, Hv, Dd, sigp, hd, rt, 0.7, 1e-3, rhs)
+        assert rel(fused, ref) < 1e-11 and rel(alone, ref) < 1e-11 and rel(dv, dref) < 1e-11
+        assert int((dv > 0).sum()) == lay.n
+    if cond:
+        K = _sparse_newton(lay, Jv, Hv, Dd, sigp, hd, rt, 0.7, 1e-3)
+        assert np.abs(K @ fused - rhs).max() <= 1e-10 * np.abs(rhs).max()
+    ctx.close()
+
+
+def test_subproblems_on_case1354_match_oracle():
+    """BASELINE.json configs[2] (1354pegase shape, Newton matrix of order 29 829 condensed to 21 865): the first
+    sub-problems of an SQP run -- the linear-phase projection QP, the trust-region QP (infeasible: restoration is
+    entered) and the restoration LP -- solved by the device and by the oracle's independent sparse LDL^T."""
+    nb, ng, nl, seed = CASES["case1354"]
+    net = acopf_synth(nb, ng, nl, seed); lay = acopf_layout(net)
+    P = O.problem_acopf(net, lay); S = P.structure()
+    ctx = pkg.Context(lay.n, lay.m, lay.num_linear, lay.jrow, lay.jcol, lay.hrow, lay.hcol, lay.xL, lay.xU,
+                      lay.gL, lay.gU, pkg.default_options())
+    assert ctx.counters()["sparse"] == 1 and ctx.counters()["kkt_order"] == 21865
+    osolve = _oracle_qp(P, S, O.default_options(kkt_mode=2))
+    x = lay.x0
+    df, E, jv, hv = P.eval_grad_f(x), P.eval_g(x), P.eval_jac_g(x), P.eval_h(x, 1.0, np.zeros(lay.m))
+    for mode, delta in ((O.MODE_LP, 10.0), (O.MODE_QP, 10.0), (O.MODE_FR, 10.0)):
+        ro, rg = osolve(mode, x, delta, 1.0, df, E, jv, hv), ctx.qp_solve(mode, x, delta, 1.0, df, E, jv, hv)
+        assert rg["status"] == ro["status"], mode
+        assert abs(rg["ipm_iters"] - ro["ipm_iters"]) <= max(2, 0.2 * ro["ipm_iters"]), mode
+        if ro["status"] == O.MOI_LOCALLY_SOLVED:
+            if mode == O.MODE_FR:       # optimal face: the optimal value is what is unique
+                assert abs(rg["slack"].sum() - ro["slack"].sum()) <= 1e-7 * max(1.0, ro["slack"].sum())
+            else:
+                assert rel(rg["p"], ro["p"]) < TOL and rel(rg["lam"], ro["lam"]) < 1e-6
+    ctx.close()
+
+
+def test_status_gather_inside_the_library():
+    """sqphip_gather_status over an RCCL communicator the library owns (one rank here: the multi-rank exchange is a
+    single ncclAllGather of the same table) returns the per-instance (ret, iter, done) table of sqphip_sqp_status."""
+    nb, ng, nl, seed = CASES["case14"]
+    base = acopf_synth(nb, ng, nl, seed)
+    nets = [base] + [contingency(base, s, seed) for s in range(1, 6)]
+    lays = [acopf_layout(nt) for nt in nets]
+    ctx = _run_batch(nets, lays, dict(max_iter=8, tol_infeas=1e-6, tol_residual=1e-4, literal_quirks=0))
+    want = ctx.sqp_status()
+    got0 = ctx.gather_status(len(nets))                         # no communicator: the local table
+    ctx.comm_init(pkg.Context.comm_unique_id(), 1, 0)
+    got1 = ctx.gather_status(len(nets))
+    for a, b, c_ in zip(want, got0, got1):
+        assert np.array_equal(a, b) and np.array_equal(a, c_)
+    with pytest.raises(pkg.SqpHipError):
+        ctx.gather_status(len(nets) + 1)                        # the batch must be this rank's block of `total`
+    ctx.comm_destroy()
+    ctx.close()
+
+
+def test_two_rank_rehearsal_gathers_the_single_rank_table(tmp_path):
+    """bench.py launched as two fresh rank processes on the one GPU of the box (--backend gloo --one-device: RCCL
+    refuses two ranks on one device) against a single-rank run of the same 8 scenarios: same gathered table."""
+    import subprocess, sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--workload", "case14", "--batch", "8", "--steps", "3", "--warmup", "0", "--literal-quirks", "0",
+              "--no-cpu-baseline", "--no-termination", "--no-dense-ldlt", "--no-kernel-timing"]
+    one = tmp_path / "one.json"; two = tmp_path / "two.json"
+    subprocess.run([_sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dump-status", str(one)] + common,
+                   check=True, cwd=root, capture_output=True, timeout=600)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+        procs.append(subprocess.Popen([_sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                                       "--one-device", "--dump-status", str(two)] + common, cwd=root, env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-500:] for o in outs]
+    line = json.loads(outs[0][0].decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["instances_per_gpu"] == 4
+    assert json.load(open(one)) == json.load(open(two))
+
+
 # ------------------------------------------------------------------ K1: device ACOPF evaluator
 def _with_transformers(net, seed):
     """A third of the branches become transformers with off-nominal taps, a few of them phase shifters."""
