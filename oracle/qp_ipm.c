@@ -936,6 +936,7 @@ static int ipm_run(ora_qp *q, const double *p_start)
 #define RHO_BIG0 1e4
 #define RHO_BIG_MAX 1e10
 #define ELASTIC_TOL 1e-8
+#define RHO_CERT_FRAC 0.5
 
 static void set_weights(ora_qp *q, double rho_big, double soft_w, int phase1)
 {
@@ -1035,7 +1036,27 @@ int ora_qp_solve(ora_qp *q, int mode, const double *x_k, double delta, double mu
         if (rc == 2) { status = ORA_MOI_NUMERICAL_ERROR; break; }
         q->last_elastic = hard_elastic(q);
         if (q->last_elastic <= ELASTIC_TOL) { status = ORA_MOI_LOCALLY_SOLVED; break; }
-        if (!q->opt.ipm_phase1) { status = ORA_MOI_LOCALLY_INFEASIBLE; break; }
+        if (!q->opt.ipm_phase1) {
+            /* elastic mass on a hard row: infeasible, or penalty too small?  H p + c = J'y + zl - zu; for an infeasible
+             * programme the terms of the right-hand side (size rho) cancel down to the objective gradient (the scaled
+             * multipliers are an infeasibility certificate); no cancellation means the penalty only balances the
+             * objective: raise it and solve again (same rule as the product, ipm.hip k_qp_finish) */
+            double *g = (double *)malloc(sizeof(double) * (size_t)(n + 1));
+            hess_mul(q, NULL, q->p, g);
+            double gm = 0.0, am = 0.0;
+            for (int64_t j = 0; j < n; ++j) {
+                gm = fmax(gm, fabs(g[j] + q->c[j]));
+                double t = (isfinite(q->lb[j]) ? q->zl[j] : 0.0) + (isfinite(q->ub[j]) ? q->zu[j] : 0.0);
+                for (int64_t k = q->jcolptr[j]; k < q->jcolptr[j + 1]; ++k) {
+                    int64_t i = q->jrowval[k];
+                    if (q->rtype[i] != ROW_FREE) t += fabs(q->jv[k] * q->y[i]);
+                }
+                am = fmax(am, t);
+            }
+            free(g);
+            if (gm > RHO_CERT_FRAC * am && rho_big < RHO_BIG_MAX) { rho_big *= 100.0; continue; }
+            status = ORA_MOI_LOCALLY_INFEASIBLE; break;
+        }
         /* elastic mass on a hard row: infeasible, or penalty too small?  Phase 1 decides. */
         {
             size_t nb = sizeof(double) * (size_t)n, mb = sizeof(double) * (size_t)m;

@@ -6,5 +6,5 @@ fallback: every entry point raises if the library has not been built."""
 from . import acopf_synth  # noqa: F401
 from . import _lib  # noqa: F401
 from . import host  # noqa: F401
-from .host import (Context, QpData, QpHip, Model, Parameters, SqpTR, optimize,  # noqa: F401
-                   default_options, SqpHipError, kkt_order, kkt_symbolic, mf_host_solve)
+from .host import (Context, QpData, QpHip, default_options, SqpHipError, kkt_order,  # noqa: F401
+                   kkt_symbolic, mf_host_solve)

@@ -116,6 +116,8 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
                              const double *gU, const sqphip_options *opt, int32_t batch)
 {
     if (!out || n <= 0 || m < 0 || batch <= 0 || !opt || num_linear < 0 || num_linear > m) return SQPHIP_EINVAL;
+    if (nnzJ < 0 || nnzH < 0 || (nnzJ > 0 && (!jrow || !jcol)) || (nnzH > 0 && (!hrow || !hcol))) return SQPHIP_EINVAL;
+    if (!xL || !xU || (m > 0 && (!gL || !gU))) return SQPHIP_EINVAL;
     for (int64_t k = 0; k < nnzJ; ++k)
         if (jrow[k] < 1 || jrow[k] > m || jcol[k] < 1 || jcol[k] > n) return SQPHIP_EINVAL;
     for (int64_t k = 0; k < nnzH; ++k)
@@ -273,6 +275,8 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
         C.plan.N = d.Nf; C.plan.Npad = d.Fpad; C.plan.T = d.Fpad / 64; C.plan.ld = d.ld; C.plan.B = B;
         C.plan.Ts = d.Ts;
         C.plan.stream = C.stream;
+        if (opt->kkt_tile_order && !d.condense && !d.sparse)
+            C.err = "note: options.kkt_tile_order needs options.kkt_condense = 1 and was ignored";
         if (!d.sparse) {
             C.plan.Wbuf = C.dalloc<double>((size_t)std::max(2 * LdltPlan::MAX_R, d.Ts) * B * d.Fpad * 64);
             C.plan.init_lookahead();
@@ -301,7 +305,9 @@ extern "C" const char *sqphip_last_error(const sqphip_ctx *h) { return h ? h->c.
 extern "C" int sqphip_set_bounds(sqphip_ctx *h, int32_t inst, const double *xL, const double *xU,
                                  const double *gL, const double *gU)
 {
-    if (!h || inst < 0 || inst >= h->c.d.B) return SQPHIP_EINVAL;
+    if (!h || inst < 0 || inst >= h->c.d.B || !xL || !xU || (h->c.d.m > 0 && (!gL || !gU))) return SQPHIP_EINVAL;
+    for (int i = 0; i < h->c.d.m; ++i)          // as sqphip_create: a row unbounded on both sides is no constraint upstream
+        if (gL[i] == -INFINITY && gU[i] == INFINITY) { h->c.err = "sqphip_set_bounds: row " + std::to_string(i) + " is unbounded on both sides"; return SQPHIP_EINVAL; }
     return guarded(h, [&](Ctx &C) {
         DV &d = C.d;
         // condensed form: the kept-row set was fixed at creation; an instance may not turn an eliminated row into

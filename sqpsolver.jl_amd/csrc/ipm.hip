@@ -24,6 +24,7 @@ namespace sqphip {
 #define RHO_BIG0 1e4
 #define RHO_BIG_MAX 1e10
 #define ELASTIC_TOL 1e-8
+#define RHO_CERT_FRAC 0.5       // |H p + c| below this fraction of max_j (|J|'|y| + z)_j: the elastic solution certifies infeasibility
 // primal-dual regularisation of the Newton matrix (part of the method; residuals are unregularised)
 #define IPM_REG_P 1e-8
 #define IPM_REG_D 1e-8
@@ -732,11 +733,35 @@ __global__ __launch_bounds__(TPB) void k_qp_finish(DV d)
         if (rt[i] != ROW_FREE && hard[i]) el = fmax(el, fmax(tp[i], tm[i]));
     el = block_reduce<OpMax>(el);
     int status = -1;       // -1: another run requested
+    bool escalate = false;
     if (st.stage == 0) {
         if (st.rc == 1) status = SQPHIP_MOI_ITERATION_LIMIT;
         else if (st.rc == 2) status = SQPHIP_MOI_NUMERICAL_ERROR;
         else if (el <= ELASTIC_TOL) status = SQPHIP_MOI_LOCALLY_SOLVED;
-        else if (!d.ipm_phase1) status = SQPHIP_MOI_LOCALLY_INFEASIBLE;
+        else if (!d.ipm_phase1) {
+            // Elastic mass left on a hard row: infeasible, or is the exact-penalty weight rho too small?  At the
+            // solution H p + c = J'y + zl - zu.  For an infeasible programme the right-hand side is a sum of terms of
+            // size rho that CANCEL (J'ybar + zbar = 0 is the infeasibility certificate, ybar = y / rho), leaving only
+            // the objective gradient; if instead |H p + c| is as large as the terms themselves (no cancellation), the
+            // penalty is merely balancing the objective, i.e. rho is too small for this programme: raise it and solve
+            // again (oracle/qp_ipm.c has the same rule).  Scale-free: a row with tiny coefficients and a
+            // huge multiplier is recognised as such.
+            hess_mul(d, inst, st.hsc, p, wn);
+            __syncthreads();
+            double g = 0.0, a = 0.0;
+            for (int j = threadIdx.x; j < d.n; j += TPB) {
+                g = fmax(g, fabs(wn[j] + c[j]));
+                double t = (fin(lb[j]) ? zl[j] : 0.0) + (fin(ub[j]) ? zu[j] : 0.0);
+                for (int k = d.jcolptr[j]; k < d.jcolptr[j + 1]; ++k) {
+                    const int i = d.jrowval[k];
+                    if (rt[i] != ROW_FREE) t += fabs(jv[k] * y[i]);
+                }
+                a = fmax(a, t);
+            }
+            g = block_reduce<OpMax>(g); a = block_reduce<OpMax>(a);
+            if (g > RHO_CERT_FRAC * a && st.rho_big < RHO_BIG_MAX) escalate = true;
+            else status = SQPHIP_MOI_LOCALLY_INFEASIBLE;
+        }
         if (threadIdx.x == 0) st.elastic = el;
     } else {
         const bool infeasible = st.rc != 0 || el > ELASTIC_TOL;
@@ -745,7 +770,8 @@ __global__ __launch_bounds__(TPB) void k_qp_finish(DV d)
     __syncthreads();
     if (status < 0) {
         if (threadIdx.x == 0) {
-            if (st.stage == 0) st.stage = 1;
+            if (escalate) st.rho_big *= 100.0;
+            else if (st.stage == 0) st.stage = 1;
             else { st.stage = 0; st.rho_big *= 100.0; }
             st.start = 1;
             d.phase[inst] = PH_IDLE;
@@ -803,6 +829,7 @@ static void read_counters(Ctx &C)
     hipLaunchKernelGGL(k_count, dim3(1), dim3(64), 0, C.stream, C.d);
     SQPHIP_HIP_OK(hipMemcpyAsync(C.h_counters, C.d.counters, 2 * sizeof(int), hipMemcpyDeviceToHost, C.stream));
     SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+    SQPHIP_HIP_OK(hipGetLastError());       // a failed launch anywhere in the sweep surfaces here, not as a silent wrong answer
 }
 
 // One sweep = one pass of the fixed kernel sequence.  Every kernel is gated on per-instance state:

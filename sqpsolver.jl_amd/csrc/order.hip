@@ -196,7 +196,26 @@ KktOrder kkt_order(int n, int m, const std::vector<int> &kpos, int mk, const std
         else { for (int a = s; a < e; ++a) for (int b = a + 1; b < e; ++b) edge(jrcol[a], jrcol[b]); }
     }
     for (auto &l : adj) { std::sort(l.begin(), l.end()); l.erase(std::unique(l.begin(), l.end()), l.end()); }
-    return kkt_order_from_graph(n, nc, adj, rows_last, long_rows);
+    KktOrder o = kkt_order_from_graph(n, nc, adj, rows_last, long_rows);
+    // the factorisation treats the leading tiles as mutually independent: make sure they are.  Any structural entry
+    // between two DIFFERENT leading tiles would be assembled into a block nobody zeroes or factorises;
+    // the construction above cannot produce one, but a wrong answer is not an acceptable failure mode for a
+    // heuristic -- fall back to the plain order (no leading tiles) if it ever does.
+    const int lead_end = 64 * o.Ts;
+    for (int u = 0; u < nc && o.Ts > 0; ++u) {
+        if (o.pos[u] >= lead_end) continue;
+        for (int v : adj[u])
+            if (o.pos[v] < lead_end && o.pos[v] / 64 != o.pos[u] / 64) {
+                fprintf(stderr, "sqphip: kkt_order: unknowns %d and %d are coupled across leading tiles; using the plain order\n", u, v);
+                KktOrder plain;
+                plain.pos.resize(nc);
+                std::iota(plain.pos.begin(), plain.pos.end(), 0);
+                plain.Nf = nc; plain.Tr = (nc + 63) / 64;
+                plain.pair_ptr.assign(1, 0);
+                return plain;
+            }
+    }
+    return o;
 }
 
 }  // namespace sqphip

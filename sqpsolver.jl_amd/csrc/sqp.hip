@@ -470,6 +470,7 @@ static void read_sqp_counters(Ctx &C)
     hipLaunchKernelGGL(k_sqp_count, dim3(1), dim3(64), 0, C.stream, C.d);
     SQPHIP_HIP_OK(hipMemcpyAsync(C.h_counters + 2, C.d.counters + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, C.stream));
     SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+    SQPHIP_HIP_OK(hipGetLastError());       // a failed launch anywhere in the sweep surfaces here
 }
 
 void sqp_reset(Ctx &C)

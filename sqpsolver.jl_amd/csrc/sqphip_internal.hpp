@@ -86,7 +86,8 @@ struct LdltPlan {
         if (const char *e = getenv("SQPHIP_TRSM_MFMA")) trsm_mfma = atoi(e);
         if (const char *e = getenv("SQPHIP_SUPERTILE")) { supertile = atoi(e); if (supertile < 1) supertile = 1; }
         if (const char *e = getenv("SQPHIP_KC")) kc = atoi(e) == 32 ? 32 : 16;
-        if (const char *e = getenv("SQPHIP_TRAIL_PAD")) { trail_pad = atoi(e); if (trail_pad < 0) trail_pad = 0; }
+        // k_trailing holds 32 KB of static LDS; the pad may take it to at most 128 KB of the CU's 160 KB
+        if (const char *e = getenv("SQPHIP_TRAIL_PAD")) { trail_pad = atoi(e); if (trail_pad < 0) trail_pad = 0; if (trail_pad > 96 * 1024) trail_pad = 96 * 1024; }
         if (const char *e = getenv("SQPHIP_TPB")) { tpb_max = atoi(e); if (tpb_max < 1) tpb_max = 1; }
         for (auto &e : ev) hipEventCreateWithFlags(&e, hipEventDisableTiming);
     }

@@ -131,3 +131,31 @@ def test_armijo_and_mu_rules_host_logic():
     assert L.sqphip_compute_mu_rule(1, 1, 0.5, 0.0, 2.0, -9.0, 3, lam.ctypes.data_as(dp), mu.ctypes.data_as(dp)) == 0
     assert mu[0] == 2.0 / 1e-8                                                   # denominator floor, negative curvature dropped
     assert L.sqphip_compute_mu_rule(4, 1, 0.5, 1.0, 1.0, 1.0, 3, lam.ctypes.data_as(dp), mu.ctypes.data_as(dp)) != 0
+
+
+def test_plain_c_caller_sees_the_same_abi(tmp_path):
+    """tests/c_abi_smoke.c (gcc, dlopen, no Python): struct sizes and option defaults field by field, the host-only
+    entry points.  Its GPU part (the toy NLP through sqphip_qp_solve) runs under -m gpu."""
+    import subprocess
+    from sqpsolver_jl_amd import _lib
+    exe = tmp_path / "c_abi_smoke"
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "c_abi_smoke.c")
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-Werror", "-o", str(exe), src, "-ldl", "-lm"])
+    out = subprocess.run([str(exe), _lib.SO_PATH], capture_output=True, text=True)
+    assert out.returncode == 0 and "c_abi_smoke: ok" in out.stdout, out.stderr
+
+
+def test_julia_shim_mirrors_the_options_struct():
+    """julia/SqpHip.jl cannot run here (no Julia); at least its SqpHipOptions must list the fields of sqphip_options in
+    order with matching widths, and every symbol it ccalls must be exported."""
+    import re
+    from sqpsolver_jl_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    jl = open(os.path.join(root, "julia", "SqpHip.jl")).read()
+    body = jl[jl.index("struct SqpHipOptions"):jl.index("end", jl.index("struct SqpHipOptions"))]
+    fields = re.findall(r"(\w+)::(Cdouble|Int32)", body)
+    want = [(k, "Cdouble" if t is C.c_double else "Int32") for k, t in _lib.Options._fields_]
+    assert fields == want
+    L = _lib.lib()
+    for sym in set(re.findall(r"\(:(sqphip_\w+), LIBSQPHIP\)", jl)):
+        assert hasattr(L, sym), sym

@@ -17,6 +17,7 @@ import sqpsolver_jl_amd as pkg
 from sqpsolver_jl_amd import _lib
 from sqpsolver_jl_amd.acopf_synth import acopf_synth, acopf_layout, contingency, renumber_buses, CASES
 from oracle import oracle as O
+import host_mirror as HM          # tests/host_mirror.py: stand-in for the Julia host of the drop-in seat (test harness)
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -1022,12 +1023,12 @@ def test_dropin_seat_reproduces_reference_answers(name):
     """Host run! mirror (what the Julia host would do over ccall) with every numerical step on the GPU."""
     pins = json.load(open(os.path.join(GOLD, "reference_pins.json")))["reference_pins"][name]
     P = getattr(O, "problem_" + name)(); S = P.structure()
-    model = pkg.Model(S["n"], S["m"], S["xL"], S["xU"], S["gL"], S["gU"],
+    model = HM.Model(S["n"], S["m"], S["xL"], S["xU"], S["gL"], S["gU"],
                       list(zip(S["jrow"].tolist(), S["jcol"].tolist())), list(zip(S["hrow"].tolist(), S["hcol"].tolist())),
                       P.eval_f, P.eval_g, P.eval_grad_f, P.eval_jac_g, P.eval_h, S["num_linear"],
-                      pkg.Parameters(max_iter=200))
+                      HM.Parameters(max_iter=200))
     model.x[:] = P.x0
-    sqp = pkg.optimize(model)
+    sqp = HM.optimize(model)
     ro = O.sqp_solve(P, O.default_options(max_iter=200))
     assert model.status == ro["status"] == 0
     assert np.allclose(model.x, pins["x"], rtol=pins["rtol"], atol=1e-8)      # the reference's own pins
@@ -1035,6 +1036,63 @@ def test_dropin_seat_reproduces_reference_answers(name):
     assert [(t["iter"], t["accepted"], t["fr"], t["sub_status"]) for t in sqp.trace] == \
            [(t["iter"], t["accepted"], t["fr"], t["sub_status"]) for t in ro["trace"]]
     assert rel(model.mult_g, ro["mult_g"]) < 1e-6
+
+
+class _OracleSeat:
+    """The QpJuMP methods compute_step_Sl1QP calls, served by the oracle's sub-problem solver."""
+
+    def __init__(self, osolve, sqp):
+        self.osolve, self.sqp = osolve, sqp
+
+    def _s(self, mode, x, delta, mu=1.0):
+        q = self.sqp
+        r = self.osolve(mode, x, delta, mu, q.df, q.E, q.dE, q.h_val)
+        return r["p"], r["lam"], r["mult_x_U"], r["mult_x_L"], r["slack"], r["status"]
+
+    def sub_optimize(self, x, delta):
+        return self._s(O.MODE_QP, x, delta)
+
+    def sub_optimize_L1QP(self, x, delta, mu):
+        return self._s(O.MODE_L1QP, x, delta, mu)
+
+    def sub_optimize_infeas(self, x, delta):
+        p, _, _, _, slack, st = self._s(O.MODE_INFEAS, x, delta)
+        return p, (float(slack.sum()) if st in (1, 7, 10, 4) else math.inf)
+
+
+@pytest.mark.parametrize("name,delta", [("hs071", 0.5), ("hs071", 10.0), ("toy", 0.5)])
+def test_elastic_step_driver_over_the_seat(name, delta):
+    """compute_step_Sl1QP! (sqp_trust_region.jl:393-471, unused upstream) is host control flow over the seat's
+    sub_optimize / sub_optimize_infeas / sub_optimize_L1QP: the mirror of it run over the device seat and over the
+    oracle's solver takes the same branches, raises the penalty the same number of times and returns the same step."""
+    P = getattr(O, "problem_" + name)(); S = P.structure()
+    mk = lambda: HM.SqpTR(HM.Model(S["n"], S["m"], S["xL"], S["xU"], S["gL"], S["gU"],
+                                   list(zip(S["jrow"].tolist(), S["jcol"].tolist())),
+                                   list(zip(S["hrow"].tolist(), S["hcol"].tolist())),
+                                   P.eval_f, P.eval_g, P.eval_grad_f, P.eval_jac_g, P.eval_h, S["num_linear"], HM.Parameters()))
+    res = []
+    for use_oracle in (False, True):
+        q = mk()
+        q.problem.x[:] = P.x0; q.x = np.asarray(P.x0, dtype=float).copy(); q.Delta = delta; q.mu = 1.0
+        q.eval_functions()
+        log = []
+        seat = _OracleSeat(_oracle_qp(P, S, O.default_options()), q) if use_oracle else None
+        p, lam, mu_u, mu_l, st = q.compute_step_Sl1QP(seat=seat, log=log)
+        res.append((p, lam, st, q.mu, log))
+    (p0, l0, s0, m0, g0), (p1, l1, s1, m1, g1) = res
+    assert s0 == s1 and m0 == m1 and [(a, b, c) for a, b, c, _ in g0] == [(a, b, c) for a, b, c, _ in g1]
+    assert rel(p0, p1) < 1e-6 and all(abs(a[3] - b[3]) <= 1e-7 * max(1.0, abs(b[3])) for a, b in zip(g0, g1))
+
+
+def test_plain_c_caller_solves_the_toy_subproblems(tmp_path):
+    """tests/c_abi_smoke.c with its GPU part: sqphip_create / sqphip_qp_solve / counters / status gather called from
+    plain C through dlopen -- the call sequence of the Julia shim without any Python in between."""
+    import subprocess
+    exe = tmp_path / "c_abi_smoke"
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "c_abi_smoke.c")
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-Werror", "-o", str(exe), src, "-ldl", "-lm"])
+    out = subprocess.run([str(exe), _lib.SO_PATH, "gpu"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "gpu part ok" in out.stdout, out.stderr + out.stdout
 
 
 # ------------------------------------------------------------------ input side: MATPOWER file -> device evaluator
@@ -1136,11 +1194,31 @@ def test_batch_of_eight_matches_oracle_instance_by_instance():
     ctx.close()
 
 
+def test_penalty_escalation_on_the_device():
+    """The device twin of test_oracle_kat.py::test_penalty_escalation_on_a_badly_scaled_feasible_row: a feasible
+    sub-problem with a multiplier of 1e5 (above the exact-penalty weight 1e4) is solved, not declared infeasible;
+    0 x = 1 stays LOCALLY_INFEASIBLE; both like the oracle."""
+    one = np.array([1], dtype=np.int64)
+    for gL, gU, delta, c, jv, want in ((-np.inf, 1.0, 1e4, -100.0, 1e-3, O.MOI_LOCALLY_SOLVED),
+                                       (1.0, 1.0, 10.0, 1.0, 0.0, O.MOI_LOCALLY_INFEASIBLE)):
+        ctx = pkg.Context(1, 1, 0, one, one, one, one, [-np.inf], [np.inf], [gL], [gU])
+        q = O.QpSolver(1, 1, 0, np.array([0, 1], dtype=np.int64), np.array([0], dtype=np.int64), np.array([0, 1], dtype=np.int64),
+                       np.array([0], dtype=np.int64), np.array([-np.inf]), np.array([np.inf]), np.array([gL]), np.array([gU]),
+                       O.default_options())
+        hv = np.array([1e-9 if jv else 1.0])
+        rg = ctx.qp_solve(O.MODE_QP, np.zeros(1), delta, 1.0, np.array([c]), np.zeros(1), np.array([jv]), hv)
+        ro = q.solve(O.MODE_QP, np.zeros(1), delta, 1.0, np.array([c]), np.zeros(1), np.array([jv]), hv)
+        assert rg["status"] == ro["status"] == want
+        if want == O.MOI_LOCALLY_SOLVED:
+            assert abs(rg["p"][0] - 1000.0) < 0.1 and rel(rg["p"], ro["p"]) < 1e-6 and rel(rg["lam"], ro["lam"]) < 1e-6
+        ctx.close()
+
+
 # ------------------------------------------------------------------ edge: a problem without constraint rows
 def test_bound_constrained_problem_without_rows():
     """m = 0 (empty Jacobian, no multipliers): min (x0-3)^2 + (x1+1)^2 + x0 x1 on [0,2]^2 -> x* = (2, 0), f* = 2,
     through the drop-in seat (host `SqpTR` + `sqphip_qp_solve`)."""
-    from sqpsolver_jl_amd import host as H
+    H = HM
     f = lambda x: (x[0] - 3) ** 2 + (x[1] + 1) ** 2 + x[0] * x[1]
     gr = lambda x: np.array([2 * (x[0] - 3) + x[1], 2 * (x[1] + 1) + x[0]])
     hs = lambda x, s, lam: np.array([2.0 * s, 1.0 * s, 2.0 * s])

@@ -402,3 +402,21 @@ def test_published_qp_optima_through_the_subproblem_seat(name):
         assert np.abs(r["p"] - q["x"]).max() < 1e-7
         assert abs(q["f0"] + q["c"] @ r["p"] + 0.5 * r["p"] @ q["H"] @ r["p"] - q["f"]) < 1e-8
         assert np.abs(r["lam"] - q["lam"]).max() < 1e-6
+
+
+def test_penalty_escalation_on_a_badly_scaled_feasible_row():
+    """a FEASIBLE sub-problem whose multiplier exceeds the exact-penalty weight rho = 1e4 used to be
+    reported LOCALLY_INFEASIBLE.  min -100 x s.t. 1e-3 x <= 1 inside a trust region of 1e4 has x* = 1000 with
+    multiplier 1e5: the elastic solution balances objective against penalty without any cancellation, the solver
+    raises rho and finds the optimum.  A genuinely infeasible programme (0 x = 1) keeps its verdict."""
+    n, m = 1, 1
+    q = O.QpSolver(n, m, 0, np.array([0, 1], dtype=np.int64), np.array([0], dtype=np.int64), np.array([0, 1], dtype=np.int64),
+                   np.array([0], dtype=np.int64), np.array([-np.inf]), np.array([np.inf]), np.array([-np.inf]),
+                   np.array([1.0]), O.default_options())
+    r = q.solve(O.MODE_QP, np.zeros(1), 1e4, 1.0, np.array([-100.0]), np.zeros(1), np.array([1e-3]), np.array([1e-9]))
+    assert r["status"] == O.MOI_LOCALLY_SOLVED and abs(r["p"][0] - 1000.0) < 1e-4 * 1000 and abs(r["lam"][0] + 1e5) < 1.0
+    q2 = O.QpSolver(n, m, 0, np.array([0, 1], dtype=np.int64), np.array([0], dtype=np.int64), np.array([0, 1], dtype=np.int64),
+                    np.array([0], dtype=np.int64), np.array([-np.inf]), np.array([np.inf]), np.array([1.0]),
+                    np.array([1.0]), O.default_options())
+    r2 = q2.solve(O.MODE_QP, np.zeros(1), 10.0, 1.0, np.array([1.0]), np.zeros(1), np.array([0.0]), np.array([1.0]))
+    assert r2["status"] == O.MOI_LOCALLY_INFEASIBLE
