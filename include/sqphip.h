@@ -295,6 +295,8 @@ typedef struct {
     int64_t factor_launches, solve_launches;   /* kernel launches of one factorisation / of one forward + backward solve */
     int64_t n_sweeps;        /* passes of the fixed kernel sequence (ipm_sweep) since create / reset: with continuous
                               * batching the slowest instance of the batch decides this number */
+    int64_t n_solve;         /* forward + backward solves with the factors, summed over the instances (first solve of a
+                              * factorisation, corrector, refinement steps) */
 } sqphip_counters;
 int sqphip_get_counters(sqphip_ctx *ctx, sqphip_counters *c);
 int sqphip_reset_counters(sqphip_ctx *ctx);

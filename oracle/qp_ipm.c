@@ -539,7 +539,7 @@ static void kkt_apply(ora_qp *q, const double *rhs, double *sol)
 }
 
 /* solve, residual against the sparse operator; returns |res|/max(1,|rhs|) */
-static double kkt_solve(ora_qp *q, double delta_w, const double *rhs, double *sol)
+static double kkt_solve(ora_qp *q, double delta_w, const double *rhs, double *sol, int no_refine)
 {
     int64_t N = q->N;
     kkt_apply(q, rhs, sol);
@@ -557,7 +557,7 @@ static double kkt_solve(ora_qp *q, double delta_w, const double *rhs, double *so
     en = kkt_residual(q, delta_w, rhs, sol, q->res);
     const char *rt_env = getenv("ORA_REFINE_TOL");
     const double rtol = rt_env ? atof(rt_env) : 1e-11;
-    if (q->opt.kkt_condense && en > rtol * rn) {
+    if (q->opt.kkt_condense && !no_refine && en > rtol * rn) {
         double *corr = (double *)malloc(sizeof(double) * (size_t)N);
         double *r0 = (double *)malloc(sizeof(double) * (size_t)N);
         memcpy(r0, q->res, sizeof(double) * (size_t)N);
@@ -656,8 +656,10 @@ static double ipm_compl_err(const ora_qp *q, double mu)
  * of the linear solve after refinement. */
 /* soc (may be NULL): per-pair second-order terms dz_aff * dx_aff of the predictor, laid out
  * [zl n | zu n | zp m | zm m | vl m | vu m]; the complementarity targets become tgt - soc */
+/* predictor != 0: the affine-scaling direction of the predictor-corrector mode -- it only feeds the centring parameter
+ * and the second-order terms, so it is not refined (the corrector, the direction actually taken, is) */
 static double ipm_direction(ora_qp *q, double delta_w, double tgt,
-                            const double *rd_vec, const double *rp_vec, const double *soc)
+                            const double *rd_vec, const double *rp_vec, const double *soc, int predictor)
 {
     int64_t n = q->n, m = q->m;
     const int64_t oZL = 0, oZU = n, oZP = 2 * n, oZM = 2 * n + m, oVL = 2 * n + 2 * m, oVU = 2 * n + 3 * m;
@@ -681,7 +683,7 @@ static double ipm_direction(ora_qp *q, double delta_w, double tgt,
         }
         q->rhs[n + i] = b;
     }
-    double relres = kkt_solve(q, delta_w, q->rhs, q->sol);
+    double relres = kkt_solve(q, delta_w, q->rhs, q->sol, predictor);
     for (int64_t j = 0; j < n; ++j) {
         double dp = q->sol[j];
         q->dp[j] = dp;
@@ -867,7 +869,7 @@ static int ipm_run(ora_qp *q, const double *p_start)
             }
             if (mpc) {
                 /* predictor: affine-scaling direction (target 0), largest steps to the boundary */
-                relres = ipm_direction(q, dw, 0.0, rd, rp, NULL);
+                relres = ipm_direction(q, dw, 0.0, rd, rp, NULL, 1);
                 ipm_max_steps(q, &apm, &adm);
                 const double ap1 = fmin(1.0, apm), ad1 = fmin(1.0, adm);
                 double csum = 0.0;
@@ -896,9 +898,9 @@ static int ipm_run(ora_qp *q, const double *p_start)
                 mu = fmax(mu_min, sigma * ms.cavg);
                 tau = fmax(0.99, 1.0 - mu);
                 /* corrector: centring target mu with the second-order terms, same factorisation */
-                relres = ipm_direction(q, dw, mu, rd, rp, soc);
+                relres = ipm_direction(q, dw, mu, rd, rp, soc, 0);
             } else {
-                relres = ipm_direction(q, dw, mu, rd, rp, NULL);
+                relres = ipm_direction(q, dw, mu, rd, rp, NULL, 0);
             }
             ipm_max_steps(q, &apm, &adm);
             alpha = fmin(1.0, tau * apm);

@@ -85,7 +85,7 @@ __global__ void k_qp_request(DV d, int inst, int mode, double delta, double mu_p
     if (threadIdx.x == 0) {
         IpmState &I = d.ist[inst];
         I.mode = mode; I.delta = delta; I.mu_pen = mu_pen;
-        I.stage = 0; I.rho_big = 1e4; I.start = 1; I.ipm_iters = 0; I.n_factor = 0; I.status = 0;
+        I.stage = 0; I.rho_big = 1e4; I.start = 1; I.ipm_iters = 0; I.n_factor = 0; I.n_solve = 0; I.status = 0;
     }
 }
 
@@ -210,6 +210,9 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
                 M.level_ptr = C.upload(S.level_ptr); M.level_sn = C.upload(S.level_sn);
                 M.nlevels = S.nlevels; M.max_front = S.max_front;
                 M.sol_items = C.upload(nz(P.sol_items));
+                M.desc = C.upload(P.desc);
+                M.ea_ent = C.upload(P.ea_ent.empty() ? std::vector<MfGather>(1) : P.ea_ent);
+                M.ev_ent = C.upload(P.ev_ent.empty() ? std::vector<MfGather>(1) : P.ev_ent);
                 M.nnzK = (int)P.nnzK;
                 M.vals = C.dalloc<double>((size_t)B * P.nnzK);
                 M.fronts = C.dalloc<double>((size_t)B * P.stride);
@@ -354,7 +357,7 @@ extern "C" int sqphip_qp_solve(sqphip_ctx *h, int32_t mode, const double *x_k, d
         SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
         *moi_status = st.status;
         C.last_ipm_iters = st.ipm_iters; C.last_n_factor = st.n_factor;
-        C.n_qp += 1; C.n_ipm_iter += st.ipm_iters; C.n_factor += st.n_factor;
+        C.n_qp += 1; C.n_ipm_iter += st.ipm_iters; C.n_factor += st.n_factor; C.n_solve += st.n_solve;
         C.total_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         return SQPHIP_OK;
     });
@@ -798,8 +801,8 @@ extern "C" int sqphip_get_counters(sqphip_ctx *h, sqphip_counters *c)
         SQPHIP_HIP_OK(hipMemcpyAsync(S.data(), C.d.sst, sizeof(SqpState) * C.d.B, hipMemcpyDeviceToHost, C.stream));
         SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
         C.tm.flush();
-        int64_t nqp = C.n_qp, nip = C.n_ipm_iter, nf = C.n_factor;
-        for (auto &s : S) { nqp += s.n_qp; nip += s.tot_ipm; nf += s.tot_fac; }
+        int64_t nqp = C.n_qp, nip = C.n_ipm_iter, nf = C.n_factor, nsol = C.n_solve;
+        for (auto &s : S) { nqp += s.n_qp; nip += s.tot_ipm; nf += s.tot_fac; nsol += s.tot_sol; }
         c->n_qp = nqp; c->n_ipm_iter = nip; c->n_factor = nf;
         const double N = (double)C.d.Nf;
         c->kkt_order = C.d.Nf;
@@ -809,7 +812,7 @@ extern "C" int sqphip_get_counters(sqphip_ctx *h, sqphip_counters *c)
         c->ldlt_seconds = C.tm.factor_seconds; c->trailing_seconds = C.tm.trailing_seconds;
         c->solve_seconds = C.tm.solve_seconds; c->total_seconds = C.total_seconds;
         c->trailing_launches = C.tm.trailing_launches;
-        c->n_sweeps = C.n_sweeps;
+        c->n_sweeps = C.n_sweeps; c->n_solve = nsol;
         c->sparse = C.d.sparse; c->nnz_k = 0; c->nnz_l = 0; c->n_supernodes = 0; c->n_levels = 0; c->max_front = 0;
         c->factor_flops = 0; c->front_doubles = 0; c->cb_doubles = 0; c->factor_launches = 0; c->solve_launches = 0;
         if (C.d.sparse) {
@@ -834,7 +837,7 @@ extern "C" int sqphip_reset_counters(sqphip_ctx *h)
     C.tm.flush();
     C.tm.trailing_seconds = C.tm.factor_seconds = C.tm.solve_seconds = 0;
     C.tm.trailing_launches = 0; C.tm.n_factor = 0;
-    C.n_qp = C.n_ipm_iter = C.n_factor = 0; C.total_seconds = 0; C.n_sweeps = 0;
+    C.n_qp = C.n_ipm_iter = C.n_factor = C.n_solve = 0; C.total_seconds = 0; C.n_sweeps = 0;
     return SQPHIP_OK;
 }
 

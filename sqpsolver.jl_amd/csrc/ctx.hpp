@@ -10,7 +10,9 @@
 namespace sqphip {
 
 // interior-point phases of one instance (kernels act only on instances in the phase they serve)
-enum { PH_IDLE = 0, PH_PREP = 1, PH_FACTOR = 2, PH_SOLVE = 3, PH_STEP = 4, PH_MPC = 5, PH_SOLVE2 = 6, PH_DONE = 9 };
+// PH_SOLVE: first solve behind a factorisation (its forward half is fused into the factorisation); PH_RESOLVE: a
+// further right-hand side through the same factors -- the corrector of the predictor-corrector mode or a refinement step
+enum { PH_IDLE = 0, PH_PREP = 1, PH_FACTOR = 2, PH_SOLVE = 3, PH_STEP = 4, PH_MPC = 5, PH_RESOLVE = 6, PH_DONE = 9 };
 enum { ROW_FREE = 0, ROW_EQ = 1, ROW_INEQ = 2 };
 
 struct IpmState {
@@ -25,7 +27,7 @@ struct IpmState {
     int mpc, use_soc;              // predictor-corrector mode of this solve; second-order terms valid for the step
     double cavg;                   // average complementarity at the top of the iteration
     // outcome
-    int status, ipm_iters, n_factor;
+    int status, ipm_iters, n_factor, n_solve;   // n_solve: forward + backward solves with the factors (incl. refinement)
     double elastic;
 };
 
@@ -36,7 +38,7 @@ struct SqpState {
     double f_trial, phi_k, q0, ared, pred;
     int iter, ret, step_acceptance, fr, sub_status, done, stage, need_qp, qp_mode, want_eval;
     int n_qp, trace_len, it_ipm, soc_pending, lp_pending, started;
-    long tot_ipm, tot_fac;
+    long tot_ipm, tot_fac, tot_sol;
     int budget;          // outer iterations this instance may still start in the current sqp_run call
 };
 
@@ -54,6 +56,8 @@ struct MfDev {
     const MfItem *items;
     const int *ea_ptr, *ea_rc, *ea_src_ptr, *ea_src;
     const int *ev_ptr, *ev_idx, *ev_src_ptr, *ev_src;
+    const MfFrontDesc *desc;              // packed per-front records
+    const MfGather *ea_ent, *ev_ent;      // packed gather entries (extend-add of fronts / of update vectors)
     const int *level_ptr, *level_sn;      // supernodes by level of the assembly tree (leaves first)
     int nlevels, max_front;
     const int *sched, *sol_items;
@@ -139,7 +143,7 @@ struct Ctx {
     // host copies of structure for misc use
     int64_t n = 0, m = 0;
     // counters
-    int64_t n_qp = 0, n_ipm_iter = 0, n_factor = 0;
+    int64_t n_qp = 0, n_ipm_iter = 0, n_factor = 0, n_solve = 0;
     double total_seconds = 0;
     int last_ipm_iters = 0, last_n_factor = 0;
 

@@ -229,7 +229,8 @@ __global__ __launch_bounds__(TPB) void k_ipm_start(DV d)
     }
     if (threadIdx.x == 0) {
         st.sf = sf; st.soft_w = soft_w; st.hsc = (st.stage == 0 && use_obj) ? sf : 0.0;
-        st.mu = 1.0; st.iter = 0; st.rc = -1; st.dw_last = 0.0; st.dw = 0.0; st.dw_floor = 0.0; st.n_acc = 0; st.n_acc2 = 0;
+        st.mu = 1.0; st.iter = 0; st.rc = -1; st.dw = 0.0; st.dw_floor = 0.0; st.n_acc = 0; st.n_acc2 = 0;
+        st.dw_last = 0.0;
         st.cn = 0.0;
         st.mpc = d.ipm_corrector != 0; st.use_soc = 0; st.cavg = 0.0;
         st.start = 0;
@@ -567,13 +568,17 @@ __global__ __launch_bounds__(TPB) void k_refine(DV d, int last, int want)
         wN[d.n + i] = r; en = fmax(en, fabs(r));
     }
     en = block_reduce<OpMax>(en);            // (its barriers publish wN)
-    const bool stop = last || refine_it >= 1 || !(en > d.refine_tol * st.rn);
+    // no refinement for a predictor (affine-scaling) direction: it only feeds Mehrotra's centring parameter and the
+    // second-order terms, the direction that is actually taken -- the corrector -- is refined (oracle: ipm_direction)
+    const bool predictor = want == PH_SOLVE && st.mpc;
+    const bool stop = last || predictor || refine_it >= 1 || !(en > d.refine_tol * st.rn);
     if (!stop) load_solve_vector(d, inst, wN, xv);
     if (threadIdx.x == 0) {
+        st.n_solve++;
         st.relres = en / st.rn;
         // predictor-corrector mode: the first solve was the predictor, k_mpc builds the corrector's system
         if (stop) d.phase[inst] = (want == PH_SOLVE && st.mpc) ? PH_MPC : PH_STEP;
-        else { st.refine_it++; d.counters[4] = 1; }       // tells the host that a refinement pass is wanted
+        else { st.refine_it++; d.phase[inst] = PH_RESOLVE; }  // the residual is the next right-hand side (second solve slot)
     }
 }
 
@@ -678,7 +683,7 @@ __global__ __launch_bounds__(TPB) void k_mpc(DV d)
         st.mu = mu; st.tau = fmax(0.99, 1.0 - mu); st.use_soc = corr ? 1 : 0;
         if (!corr) st.mpc = 0;
         st.rn = fmax(1.0, rn); st.refine_it = 0;
-        d.phase[inst] = PH_SOLVE2;
+        d.phase[inst] = PH_RESOLVE;
     }
 }
 
@@ -871,31 +876,20 @@ void ipm_sweep(Ctx &C, bool sqp_level)
     // the sparse operator.  No iterative refinement: one step of it (the policy until late in round 1, two more
     // launch chains per sweep) changed no iteration count on any test problem -- see oracle/qp_ipm.c, kkt_solve.
     lin_solve(PH_SOLVE, true);
-    // condensed form: one conditional refinement step per direction.  Whether any instance wants it is read back
-    // (4 bytes + a stream synchronise, the sweep loop synchronises once per sweep anyway): on most sweeps none
-    // does, and 2 x 33 gated-off launches per skipped pass cost more than the round trip.
-    const bool refine = d.condense != 0;
-    auto refine_pass = [&](int want) {
-        if (!refine) { hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, 1, want); return; }
-        static const bool readback = !getenv("SQPHIP_NO_REFINE_READBACK");
-        if (readback) hipMemsetAsync(d.counters + 4, 0, sizeof(int), s);
-        hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, 0, want);
-        if (readback) {
-            SQPHIP_HIP_OK(hipMemcpyAsync(C.h_counters + 4, d.counters + 4, sizeof(int), hipMemcpyDeviceToHost, s));
-            SQPHIP_HIP_OK(hipStreamSynchronize(s));
-            if (C.h_counters[4] == 0) return;
-        }
-        lin_solve(want, false);
-        hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, 1, want);
-    };
-    refine_pass((int)PH_SOLVE);
-    if (d.ipm_corrector) {
-        // predictor-corrector mode: centring parameter + second-order terms, then the corrector's right-hand side
-        // through the same factors (full forward + backward solve)
-        hipLaunchKernelGGL(k_mpc, gB, bT, 0, s, d);
-        lin_solve(PH_SOLVE2, false);
-        refine_pass((int)PH_SOLVE2);
-    }
+    // Two solve slots per sweep, no host round trip in between.  Slot A (above) is the first solve behind the
+    // factorisation; k_refine accumulates it, measures the residual against the sparse operator and sends the instance
+    // on: to its step, to k_mpc (a predictor), or -- condensed form, residual above refine_tol -- to a refinement solve.
+    // Slot B is one stand-alone forward + backward solve for every instance that has a right-hand side pending
+    // (PH_RESOLVE): the corrector of the predictor-corrector mode, or a refinement step.  An instance that needs yet
+    // another solve (a refined corrector) keeps PH_RESOLVE and is served by slot B of the next sweep.  (Round 1 read a
+    // flag back after each k_refine and launched up to three further solve chains per sweep: two host synchronisations
+    // and, with hundreds of instances in flight, 2 forward + 3 backward passes nearly every sweep, each as long as its
+    // slowest front chain however few instances took part.)
+    const int last = d.condense != 0 ? 0 : 1;          // full form: no refinement
+    hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, last, (int)PH_SOLVE);
+    if (d.ipm_corrector) hipLaunchKernelGGL(k_mpc, gB, bT, 0, s, d);
+    lin_solve(PH_RESOLVE, false);
+    hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, last, (int)PH_RESOLVE);
     if (C.tm.enabled) { hipEventRecord(ev.second, s); C.tm.pending_solve.push_back(ev); }
     hipLaunchKernelGGL(k_ipm_step, gB, bT, 0, s, d);
     hipLaunchKernelGGL(k_ipm_prepare, gB, bT, 0, s, d);

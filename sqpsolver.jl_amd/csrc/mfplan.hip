@@ -172,30 +172,35 @@ MfPlan mf_build_plan(int n, int m, const std::vector<int> &kpos, int mk, const s
     // solves: one launch per level; a workgroup of four waves takes one front of more than 64 rows or four smaller ones
     const bool big_solve = !(getenv("SQPHIP_MF_BIG_SOLVE") && atoi(getenv("SQPHIP_MF_BIG_SOLVE")) == 0);   // experiment switch
     for (int l = 0; l < S.nlevels; ++l) {
-        MfLaunch L{(int)P.sol_items.size() / 2, 0, 256, 0, 0, 0};
+        MfLaunch L{(int)P.sol_items.size() / 4, 0, 256, 0, 0, 0};
         int maxfs = 64;
         std::vector<int> small;
         for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; ++q) {
             const int s = S.level_sn[q], fs = S.sn_nc[s] + S.sn_nr[s];
             if (!big_solve) maxfs = std::max(maxfs, fs);
             if (fs > 64 && big_solve) {
-                P.sol_items.push_back((int)P.sched.size()); P.sol_items.push_back(1 | (1 << 8));
-                P.sched.push_back(s);
+                for (int t : {s, -2, -2, -2}) P.sol_items.push_back(t);
                 maxfs = std::max(maxfs, fs);
             } else small.push_back(s);
         }
-        for (size_t q = 0; q < small.size(); q += 4) {
-            const int cnt = (int)std::min<size_t>(4, small.size() - q);
-            P.sol_items.push_back((int)P.sched.size()); P.sol_items.push_back(cnt);
-            for (int t = 0; t < cnt; ++t) P.sched.push_back(small[q + t]);
-        }
-        L.count = (int)P.sol_items.size() / 2 - L.begin;
+        for (size_t q = 0; q < small.size(); q += 4)
+            for (size_t t = q; t < q + 4; ++t) P.sol_items.push_back(t < small.size() ? small[t] : -1);
+        L.count = (int)P.sol_items.size() / 4 - L.begin;
         // four wave vectors, or one front vector + 16 block sums; tiles = doubles per wave vector
         L.tiles = big_solve ? 64 : maxfs;
         L.lds_bytes = 8 * std::max(4 * L.tiles, maxfs + 16);
         P.fwd.push_back(L);
     }
     P.bwd.assign(P.fwd.rbegin(), P.fwd.rend());
+    // packed records for the kernels
+    P.desc.resize(S.ns);
+    for (int s = 0; s < S.ns; ++s)
+        P.desc[s] = {S.sn_nc[s], S.sn_nr[s], S.sn_first[s], S.sn_rowptr[s], (int)P.off[s], P.asm_ptr[s], P.asm_ptr[s + 1],
+                     P.ea_ptr[s], P.ea_ptr[s + 1], P.ev_ptr[s], P.ev_ptr[s + 1], 0};
+    P.ea_ent.resize(P.ea_rc.size());
+    for (size_t t = 0; t < P.ea_rc.size(); ++t) P.ea_ent[t] = {P.ea_rc[t], P.ea_src_ptr[t], P.ea_src_ptr[t + 1], P.ea_src[P.ea_src_ptr[t]]};
+    P.ev_ent.resize(P.ev_idx.size());
+    for (size_t t = 0; t < P.ev_idx.size(); ++t) P.ev_ent[t] = {P.ev_idx[t], P.ev_src_ptr[t], P.ev_src_ptr[t + 1], P.ev_src[P.ev_src_ptr[t]]};
     return P;
 }
 

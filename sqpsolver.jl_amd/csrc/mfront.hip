@@ -60,8 +60,9 @@ __global__ __launch_bounds__(NT) void k_mf_factor(DV d, int sbegin, int want, in
     if (d.phase[inst] != want) return;
     const MfDev &M = d.mf;
     const int s = M.sched[sbegin + blockIdx.x];
-    const int nc = M.nc[s], nr = M.nr[s], fs = nc + nr, ld = fs + 1, f0 = M.first[s];
-    double *G = M.fronts + (long)inst * M.stride + M.off[s];
+    const MfFrontDesc Fd = M.desc[s];
+    const int nc = Fd.nc, nr = Fd.nr, fs = nc + nr, ld = fs + 1, f0 = Fd.first;
+    double *G = M.fronts + (long)inst * M.stride + Fd.off;
     extern __shared__ double mf_lds[];
     double *F = INPLACE ? G : mf_lds;
     const int tid = threadIdx.x;
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(NT) void k_mf_factor(DV d, int sbegin, int want, in
         const double *hv = d.hv + (long)inst * d.nnzhc, *jv = d.jv + (long)inst * d.nnzjc;
         const double *Dd = d.Dd + (long)inst * d.m, *sigp = d.sigp + (long)inst * d.n, *hd = d.hd + (long)inst * d.n;
         const int *rt = d.rtype + (long)inst * d.m;
-        for (int e = M.asm_ptr[s] + tid; e < M.asm_ptr[s + 1]; e += NT) {
+        for (int e = Fd.asm_begin + tid; e < Fd.asm_end; e += NT) {
             double a = 0.0;
             for (int k = M.item_ptr[e]; k < M.item_ptr[e + 1]; ++k) a += mf_item_value(M.items[k], hv, jv, Dd, sigp, hd, rt, hsc, dw);
             F[M.dest_loc[e]] = a;
@@ -186,9 +187,10 @@ __global__ __launch_bounds__(64 * NW) void k_mf_factor2(DV d, int sbegin, int wa
     if (d.phase[inst] != want) return;
     const MfDev &M = d.mf;
     const int s = M.sched[sbegin + blockIdx.x];
-    const int nc = M.nc[s], nr = M.nr[s], fs = nc + nr, ld = fs + 1, f0 = M.first[s];
+    const MfFrontDesc Fd = M.desc[s];
+    const int nc = Fd.nc, nr = Fd.nr, fs = nc + nr, ld = fs + 1, f0 = Fd.first;
     const double *arena = M.fronts + (long)inst * M.stride;
-    double *G = M.fronts + (long)inst * M.stride + M.off[s];
+    double *G = M.fronts + (long)inst * M.stride + Fd.off;
     extern __shared__ double mf_lds[];
     const int R = 16 * Tl;
     double *Xp = mf_lds + (LDSIMG ? R * R : 0), *Lp = Xp + 4 * R, *blk = Lp + 4 * R, *dl = blk + 16;
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(64 * NW) void k_mf_factor2(DV d, int sbegin, int wa
     MF_TR(1)
     {
         const double *vals = M.vals + (long)inst * M.nnzK;
-        for (int e = M.asm_ptr[s] + tid; e < M.asm_ptr[s + 1]; e += NT) {
+        for (int e = Fd.asm_begin + tid; e < Fd.asm_end; e += NT) {
             const int rc = M.dest_rc[e];
             F[(rc >> 16) * LD + (rc & 0xffff)] = vals[e];
         }
@@ -219,10 +221,11 @@ __global__ __launch_bounds__(64 * NW) void k_mf_factor2(DV d, int sbegin, int wa
     }
     __syncthreads();
     MF_TR(2)
-    for (int t = M.ea_ptr[s] + tid; t < M.ea_ptr[s + 1]; t += NT) {
-        double a = 0.0;
-        for (int q = M.ea_src_ptr[t]; q < M.ea_src_ptr[t + 1]; ++q) a += arena[M.ea_src[q]];
-        const int rc = M.ea_rc[t];
+    for (int t = Fd.ea_begin + tid; t < Fd.ea_end; t += NT) {
+        const MfGather g = M.ea_ent[t];
+        double a = arena[g.src0];
+        for (int q = g.src_begin + 1; q < g.src_end; ++q) a += arena[M.ea_src[q]];
+        const int rc = g.where;
         F[(rc >> 16) * LD + (rc & 0xffff)] += a;
     }
     __syncthreads();
@@ -332,17 +335,19 @@ __device__ __forceinline__ void wave_sync()
 __device__ __forceinline__ void mf_front_fwd(const DV &d, int inst, int s, double *y, int lane, int generic)
 {
     const MfDev &M = d.mf;
-    const int nc = M.nc[s], nr = M.nr[s], fs = nc + nr, ld = fs + 1, f0 = M.first[s];
+    const MfFrontDesc Fd = M.desc[s];
+    const int nc = Fd.nc, nr = Fd.nr, fs = nc + nr, ld = fs + 1, f0 = Fd.first;
     const double *arena = M.fronts + (long)inst * M.stride;
-    double *G = M.fronts + (long)inst * M.stride + M.off[s];
+    double *G = M.fronts + (long)inst * M.stride + Fd.off;
     const double *b = d.xv + (long)inst * d.Fpad + f0;
     for (int i = lane; i < fs; i += 64) y[i] = i < nc ? b[i] : 0.0;
     wave_sync();
     // updates of the children through the gather lists (one lane per receiving entry, sources in fixed order)
-    for (int t = M.ev_ptr[s] + lane; t < M.ev_ptr[s + 1]; t += 64) {
-        double a = 0.0;
-        for (int q = M.ev_src_ptr[t]; q < M.ev_src_ptr[t + 1]; ++q) a += arena[M.ev_src[q]];
-        y[M.ev_idx[t]] += a;
+    for (int t = Fd.ev_begin + lane; t < Fd.ev_end; t += 64) {
+        const MfGather g = M.ev_ent[t];
+        double a = arena[g.src0];
+        for (int q = g.src_begin + 1; q < g.src_end; ++q) a += arena[M.ev_src[q]];
+        y[g.where] += a;
     }
     wave_sync();
     const double *dinv = d.dinv + (long)inst * d.Fpad + f0;
@@ -379,11 +384,12 @@ __device__ __forceinline__ void mf_front_fwd(const DV &d, int inst, int s, doubl
 __device__ __forceinline__ void mf_front_bwd(const DV &d, int inst, int s, double *x, int lane, int generic)
 {
     const MfDev &M = d.mf;
-    const int nc = M.nc[s], nr = M.nr[s], fs = nc + nr, ld = fs + 1, f0 = M.first[s];
-    const double *G = M.fronts + (long)inst * M.stride + M.off[s];
+    const MfFrontDesc Fd = M.desc[s];
+    const int nc = Fd.nc, nr = Fd.nr, fs = nc + nr, ld = fs + 1, f0 = Fd.first;
+    const double *G = M.fronts + (long)inst * M.stride + Fd.off;
     double *xg = d.xv + (long)inst * d.Fpad;
     const double *vv = d.vv + (long)inst * d.Fpad + f0;
-    const int *rows = M.rows + M.rowptr[s];
+    const int *rows = M.rows + Fd.rowptr;
     for (int i = lane; i < fs; i += 64) x[i] = i < nc ? vv[i] : xg[rows[i - nc]];
     wave_sync();
     if (nc <= 64 && !generic) {
@@ -420,18 +426,20 @@ __device__ __forceinline__ void mf_front_bwd(const DV &d, int inst, int s, doubl
 __device__ __forceinline__ void mf_front_fwd_big(const DV &d, int inst, int s, double *y, int tid)
 {
     const MfDev &M = d.mf;
-    const int nc = M.nc[s], nr = M.nr[s], fs = nc + nr, ld = fs + 1, f0 = M.first[s];
+    const MfFrontDesc Fd = M.desc[s];
+    const int nc = Fd.nc, nr = Fd.nr, fs = nc + nr, ld = fs + 1, f0 = Fd.first;
     const double *arena = M.fronts + (long)inst * M.stride;
-    double *G = M.fronts + (long)inst * M.stride + M.off[s];
+    double *G = M.fronts + (long)inst * M.stride + Fd.off;
     const double *b = d.xv + (long)inst * d.Fpad + f0, *dinv = d.dinv + (long)inst * d.Fpad + f0;
     double *vv = d.vv + (long)inst * d.Fpad + f0;
     const int lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < fs; i += 256) y[i] = i < nc ? b[i] : 0.0;
     __syncthreads();
-    for (int t = M.ev_ptr[s] + tid; t < M.ev_ptr[s + 1]; t += 256) {
-        double a = 0.0;
-        for (int q = M.ev_src_ptr[t]; q < M.ev_src_ptr[t + 1]; ++q) a += arena[M.ev_src[q]];
-        y[M.ev_idx[t]] += a;
+    for (int t = Fd.ev_begin + tid; t < Fd.ev_end; t += 256) {
+        const MfGather g = M.ev_ent[t];
+        double a = arena[g.src0];
+        for (int q = g.src_begin + 1; q < g.src_end; ++q) a += arena[M.ev_src[q]];
+        y[g.where] += a;
     }
     __syncthreads();
     for (int kb = 0; kb < nc; kb += 16) {
@@ -460,11 +468,12 @@ __device__ __forceinline__ void mf_front_fwd_big(const DV &d, int inst, int s, d
 __device__ __forceinline__ void mf_front_bwd_big(const DV &d, int inst, int s, double *x, int tid)
 {
     const MfDev &M = d.mf;
-    const int nc = M.nc[s], nr = M.nr[s], fs = nc + nr, ld = fs + 1, f0 = M.first[s];
-    const double *G = M.fronts + (long)inst * M.stride + M.off[s];
+    const MfFrontDesc Fd = M.desc[s];
+    const int nc = Fd.nc, nr = Fd.nr, fs = nc + nr, ld = fs + 1, f0 = Fd.first;
+    const double *G = M.fronts + (long)inst * M.stride + Fd.off;
     double *xg = d.xv + (long)inst * d.Fpad;
     const double *vv = d.vv + (long)inst * d.Fpad + f0;
-    const int *rows = M.rows + M.rowptr[s];
+    const int *rows = M.rows + Fd.rowptr;
     const int lane = tid & 63, wave = tid >> 6;
     double *part = x + fs;                       // 16 block sums behind the vector
     for (int i = tid; i < fs; i += 256) x[i] = i < nc ? vv[i] : xg[rows[i - nc]];
@@ -502,11 +511,11 @@ __global__ __launch_bounds__(256) void k_mf_fwd(DV d, int ibegin, int want, int 
     const int inst = blockIdx.y;
     if (d.phase[inst] != want) return;
     extern __shared__ double mf_lds[];
-    const MfDev &M = d.mf;
-    const int q0 = M.sol_items[2 * (ibegin + blockIdx.x)], info = M.sol_items[2 * (ibegin + blockIdx.x) + 1];
+    const int4 it = reinterpret_cast<const int4 *>(d.mf.sol_items)[ibegin + blockIdx.x];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (info >> 8) mf_front_fwd_big(d, inst, M.sched[q0], mf_lds, threadIdx.x);
-    else if (wave < (info & 255)) mf_front_fwd(d, inst, M.sched[q0 + wave], mf_lds + wstride * wave, threadIdx.x & 63, generic);
+    if (it.y == -2) { mf_front_fwd_big(d, inst, it.x, mf_lds, threadIdx.x); return; }
+    const int s = wave == 0 ? it.x : (wave == 1 ? it.y : (wave == 2 ? it.z : it.w));
+    if (s >= 0) mf_front_fwd(d, inst, s, mf_lds + wstride * wave, threadIdx.x & 63, generic);
 }
 
 __global__ __launch_bounds__(256) void k_mf_bwd(DV d, int ibegin, int want, int generic, int wstride)
@@ -514,11 +523,11 @@ __global__ __launch_bounds__(256) void k_mf_bwd(DV d, int ibegin, int want, int 
     const int inst = blockIdx.y;
     if (d.phase[inst] != want) return;
     extern __shared__ double mf_lds[];
-    const MfDev &M = d.mf;
-    const int q0 = M.sol_items[2 * (ibegin + blockIdx.x)], info = M.sol_items[2 * (ibegin + blockIdx.x) + 1];
+    const int4 it = reinterpret_cast<const int4 *>(d.mf.sol_items)[ibegin + blockIdx.x];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (info >> 8) mf_front_bwd_big(d, inst, M.sched[q0], mf_lds, threadIdx.x);
-    else if (wave < (info & 255)) mf_front_bwd(d, inst, M.sched[q0 + wave], mf_lds + wstride * wave, threadIdx.x & 63, generic);
+    if (it.y == -2) { mf_front_bwd_big(d, inst, it.x, mf_lds, threadIdx.x); return; }
+    const int s = wave == 0 ? it.x : (wave == 1 ? it.y : (wave == 2 ? it.z : it.w));
+    if (s >= 0) mf_front_bwd(d, inst, s, mf_lds + wstride * wave, threadIdx.x & 63, generic);
 }
 
 // whole solve of one instance by ONE workgroup of NWV waves: the waves deal out the fronts of a level, a workgroup

@@ -78,6 +78,14 @@ enum { MF_ITEM_H = 0,        // hsc * hv[a]
        MF_ITEM_RDIAG = 4 };  // -(Dd[row] + reg_d), or -1 for a free row
 struct MfItem { int type, row, a, b; };
 
+// everything a kernel needs to know about a front, in one 48-byte record (three 16-byte loads instead of a chain of
+// dependent look-ups): columns, rows, first position, offsets into rows[] / the front arena, and its ranges in the
+// destination, extend-add and vector-gather lists
+struct MfFrontDesc { int nc, nr, first, rowptr, off, asm_begin, asm_end, ea_begin, ea_end, ev_begin, ev_end, pad; };
+// one receiving entry of an extend-add / vector gather: where it goes (row | column << 16, or the local index), its
+// sources [src_begin, src_end) in ea_src / ev_src and, inline, the first of them (most entries have exactly one)
+struct MfGather { int where, src_begin, src_end, src0; };
+
 // one kernel launch of the factorisation / of a solve sweep: fronts [begin, begin + count) of `sched`, all of one
 // size class.  Factorisation: cls = kernel variant (mfront.hip, mf_factor), tiles = 16-row tiles of the largest front
 // of the launch (sizes the LDS image), lds_bytes = dynamic LDS.
@@ -98,10 +106,11 @@ struct MfPlan {
     // the same for vectors (forward solves): per front the local indices that receive a child's update
     // [ev_ptr[s], ev_ptr[s+1]), each with its sources (offsets of the children's update entries in the arena)
     std::vector<int> ev_ptr, ev_idx, ev_src_ptr, ev_src;
-    // solve launches: work items of one 256-thread workgroup each = one front of more than 64 rows (the four waves
-    // share it) or up to four smaller fronts (one wave each): sol_items[2 q] = first entry in `sched`,
-    // sol_items[2 q + 1] = count | big << 8
+    // solve launches: work items of one 256-thread workgroup each, four ints per item = one front of more than 64
+    // rows, shared by the four waves: {front, -2, -2, -2}, or up to four smaller fronts, one wave each (-1: none)
     std::vector<int> sol_items;
+    std::vector<MfFrontDesc> desc;               // packed per-front records (device copies of the arrays above)
+    std::vector<MfGather> ea_ent, ev_ent;
     std::vector<int> sched;                      // fronts in launch order
     std::vector<MfLaunch> fac, fwd, bwd;
     long nnzK = 0;                               // structural entries of the lower triangle (destinations)

@@ -127,7 +127,7 @@ static __device__ void push_trace(const DV &d, int inst, SqpState &S, double pn)
 static __device__ void qp_request(IpmState &I, int mode, double delta, double mu_pen)
 {
     I.mode = mode; I.delta = delta; I.mu_pen = mu_pen;
-    I.stage = 0; I.rho_big = 1e4; I.start = 1; I.ipm_iters = 0; I.n_factor = 0; I.status = 0;
+    I.stage = 0; I.rho_big = 1e4; I.start = 1; I.ipm_iters = 0; I.n_factor = 0; I.n_solve = 0; I.status = 0;
 }
 
 // sqp_trust_region.jl:215-222
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(TPB) void k_sqp_reset(DV d)
         z.prim_infeas = INFINITY; z.dual_infeas = INFINITY;
         z.step_acceptance = 1; z.fr = 0; z.iter = 1; z.ret = -5;
         S = z;
-        I.start = 0;
+        I.start = 0; I.dw_last = 0.0;
         d.phase[inst] = PH_IDLE;
     }
 }
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(TPB) void k_sqp_lp_finish(DV d)
     for (int i = threadIdx.x; i < d.m; i += TPB) lam[i] = dz(ol[i]);
     if (threadIdx.x == 0) {
         S.sub_status = I.status; S.stage = ST_TOP; S.n_qp++; S.it_ipm = I.ipm_iters;
-        S.tot_ipm += I.ipm_iters; S.tot_fac += I.n_factor;
+        S.tot_ipm += I.ipm_iters; S.tot_fac += I.n_factor; S.tot_sol += I.n_solve;
     }
     __syncthreads();
     push_trace(d, inst, S, norm_inf(ps, d.n));            // print(sqp, "LP")
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(TPB) void k_sqp_mid(DV d)
     if (threadIdx.x == 0) {
         S.mu = fmax(fmax(S.mu, nl_), fmax(nL, nU));
         S.sub_status = st; S.n_qp++; S.it_ipm += I.ipm_iters;
-        S.tot_ipm += I.ipm_iters; S.tot_fac += I.n_factor;
+        S.tot_ipm += I.ipm_iters; S.tot_fac += I.n_factor; S.tot_sol += I.n_solve;
     }
     __syncthreads();
     if (st == SQPHIP_MOI_LOCALLY_SOLVED) {
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(TPB) void k_sqp_soc_finish(DV d)
     const double qs = qmodel_step(d, inst, S, psoc, x, df, E, jv, hv, gL, gU, xL, xU, tmpx, tmpE);
     const double pred = S.q0 - qs;
     const double rho = ared / pred;
-    if (threadIdx.x == 0) { S.n_qp++; S.it_ipm += I.ipm_iters; S.tot_ipm += I.ipm_iters; S.tot_fac += I.n_factor; }
+    if (threadIdx.x == 0) { S.n_qp++; S.it_ipm += I.ipm_iters; S.tot_ipm += I.ipm_iters; S.tot_fac += I.n_factor; S.tot_sol += I.n_solve; }
     if (ared > 0 && rho > 0) {
         accept_step(d, x, lam, mxL, mxU, psoc, plam, pmxL, pmxU);
         if (threadIdx.x == 0) S.step_acceptance = 1;
