@@ -36,5 +36,19 @@ print(f"{case} B={B}: {ns} fronts; sum over fronts (us):", {n: round(float(v), 1
 print("slowest fronts: idx total | " + " ".join(names))
 for s in order[:12]:
     print(f"  {s:5d} {tot[s]:8.1f} | " + " ".join(f"{v:7.1f}" for v in d[s]))
+# per size class (16-row tiles of the front): fronts, mean microseconds per phase
+L.sqphip_kkt_symbolic  # (library loaded)
+import collections
+pos, st = pkg.kkt_symbolic(lay0.n, lay0.m, lay0.jrow, lay0.jcol, lay0.hrow, lay0.hcol, lay0.gL, lay0.gU)
+print("symbolic:", {k: st[k] for k in ("n_supernodes", "n_levels", "max_front", "nnz_l")})
+tot_by = collections.defaultdict(list)
+for srow in range(ns):
+    tot_by[int(round(tot[srow] // 5) * 5)].append(srow)
+q = np.percentile(tot, [10, 50, 90, 99])
+print("front time percentiles (us): p10 %.1f p50 %.1f p90 %.1f p99 %.1f" % tuple(q))
+for lo, hi in ((0, 8), (8, 15), (15, 30), (30, 1e9)):
+    sel = (tot >= lo) & (tot < hi)
+    if sel.any():
+        print(f"  fronts with total in [{lo},{hi}) us: {int(sel.sum()):4d}  mean phases " + " ".join(f"{n}={v:.1f}" for n, v in zip(names, d[sel].mean(axis=0))))
 t0 = buf[:, 0].min()
 print("span of the last factorisation (us):", (buf[:, 5].max() - t0) * 10e-3)

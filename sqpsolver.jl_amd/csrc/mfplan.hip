@@ -173,7 +173,7 @@ MfPlan mf_build_plan(int n, int m, const std::vector<int> &kpos, int mk, const s
     const bool big_solve = !(getenv("SQPHIP_MF_BIG_SOLVE") && atoi(getenv("SQPHIP_MF_BIG_SOLVE")) == 0);   // experiment switch
     for (int l = 0; l < S.nlevels; ++l) {
         MfLaunch L{(int)P.sol_items.size() / 4, 0, 256, 0, 0, 0};
-        int maxfs = 64;
+        int maxfs = 64, lcap = 0;                       // lcap: doubles for the LDS image of a big front's triangular corner
         std::vector<int> small;
         for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; ++q) {
             const int s = S.level_sn[q], fs = S.sn_nc[s] + S.sn_nr[s];
@@ -181,6 +181,8 @@ MfPlan mf_build_plan(int n, int m, const std::vector<int> &kpos, int mk, const s
             if (fs > 64 && big_solve) {
                 for (int t : {s, -2, -2, -2}) P.sol_items.push_back(t);
                 maxfs = std::max(maxfs, fs);
+                const int nc = S.sn_nc[s];
+                if (nc <= 80) lcap = std::max(lcap, nc * nc);           // up to 51 KB; larger corners stay in the arena
             } else small.push_back(s);
         }
         for (size_t q = 0; q < small.size(); q += 4)
@@ -188,7 +190,8 @@ MfPlan mf_build_plan(int n, int m, const std::vector<int> &kpos, int mk, const s
         L.count = (int)P.sol_items.size() / 4 - L.begin;
         // four wave vectors, or one front vector + 16 block sums; tiles = doubles per wave vector
         L.tiles = big_solve ? 64 : maxfs;
-        L.lds_bytes = 8 * std::max(4 * L.tiles, maxfs + 16);
+        L.cls = std::max(4 * L.tiles, maxfs + 16);                     // doubles of the vector area (cls is free in solve launches)
+        L.lds_bytes = 8 * (L.cls + lcap);
         P.fwd.push_back(L);
     }
     P.bwd.assign(P.fwd.rbegin(), P.fwd.rend());

@@ -179,6 +179,21 @@ __global__ __launch_bounds__(256) void k_mf_values(DV d, int want)
 // Explicit zeros of the padding (rows / columns beyond the front) stay zero: an all-zero panel row updates nothing.
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// 1 / x by v_rcp_f64 and two Newton steps: a quarter of the dependent instructions of an IEEE division, within one ulp
+// (four of these sit on the critical path of every four-column block).  0 gives inf -> NaN, which k_inertia reports.
+__device__ __forceinline__ double mf_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+
+__device__ __forceinline__ double mf_readlane(double x, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane), hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
+
 template <int NW, int MAXT, bool LDSIMG>
 __global__ __launch_bounds__(64 * NW) void k_mf_factor2(DV d, int sbegin, int want, int with_rhs, int Tl)
 {
@@ -255,23 +270,38 @@ __global__ __launch_bounds__(64 * NW) void k_mf_factor2(DV d, int sbegin, int wa
             const int k0 = 16 * tk + 4 * rr0;
             if (k0 >= nc) break;
             const int bw = nc - k0 < 4 ? nc - k0 : 4;
+            // the 4 x 4 diagonal block to every lane: element (a, b) sits in lane (l15 = 4 rr0 + a, l4 = b) of the diagonal
+            // tile.  One wave per front: straight from the registers (v_readlane); several waves: through LDS.
+            double a00, a10, a11, a20, a21, a22, a30, a31, a32, a33;
+            if (NW == 1) {
+                double dv = 0.0;
 #pragma unroll
-            for (int q = 0; q < MAXT; ++q)
-                if (ti_[q] == tk && tj_[q] == tk) {
-                    const int a = l15 - 4 * rr0;
-                    if (a >= 0 && a < 4) blk[a * 4 + l4] = acc[q][rr0];
-                }
-            __syncthreads();
+                for (int q = 0; q < MAXT; ++q) if (ti_[q] == tk && tj_[q] == tk) dv = acc[q][rr0];
+                const int b0 = 4 * rr0;
+                a00 = mf_readlane(dv, b0);
+                a10 = mf_readlane(dv, b0 + 1); a11 = mf_readlane(dv, b0 + 1 + 16);
+                a20 = mf_readlane(dv, b0 + 2); a21 = mf_readlane(dv, b0 + 2 + 16); a22 = mf_readlane(dv, b0 + 2 + 32);
+                a30 = mf_readlane(dv, b0 + 3); a31 = mf_readlane(dv, b0 + 3 + 16); a32 = mf_readlane(dv, b0 + 3 + 32);
+                a33 = mf_readlane(dv, b0 + 3 + 48);
+            } else {
+#pragma unroll
+                for (int q = 0; q < MAXT; ++q)
+                    if (ti_[q] == tk && tj_[q] == tk) {
+                        const int a = l15 - 4 * rr0;
+                        if (a >= 0 && a < 4) blk[a * 4 + l4] = acc[q][rr0];
+                    }
+                __syncthreads();
+                a00 = blk[0]; a10 = blk[4]; a11 = blk[5]; a20 = blk[8]; a21 = blk[9]; a22 = blk[10]; a30 = blk[12]; a31 = blk[13];
+                a32 = blk[14]; a33 = blk[15];
+            }
             // the block's LDL^T, same numbers in every lane; columns beyond bw (a partial last block) eliminate nothing
-            double a10 = blk[4], a11 = blk[5], a20 = blk[8], a21 = blk[9], a22 = blk[10], a30 = blk[12], a31 = blk[13],
-                   a32 = blk[14], a33 = blk[15];
             double i1 = 0.0, i2 = 0.0, i3 = 0.0, l21 = 0.0, l31 = 0.0, l32 = 0.0;
-            const double i0 = 1.0 / blk[0];
+            const double i0 = mf_rcp(a00);
             const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
             a11 -= l10 * a10; a21 -= l10 * a20; a22 -= l20 * a20; a31 -= l10 * a30; a32 -= l20 * a30; a33 -= l30 * a30;
-            if (bw > 1) { i1 = 1.0 / a11; l21 = a21 * i1; l31 = a31 * i1; a22 -= l21 * a21; a32 -= l21 * a31; a33 -= l31 * a31; }
-            if (bw > 2) { i2 = 1.0 / a22; l32 = a32 * i2; a33 -= l32 * a32; }
-            if (bw > 3) i3 = 1.0 / a33;
+            if (bw > 1) { i1 = mf_rcp(a11); l21 = a21 * i1; l31 = a31 * i1; a22 -= l21 * a21; a32 -= l21 * a31; a33 -= l31 * a31; }
+            if (bw > 2) { i2 = mf_rcp(a22); l32 = a32 * i2; a33 -= l32 * a32; }
+            if (bw > 3) i3 = mf_rcp(a33);
             const double lc0 = l4 == 1 ? l10 : (l4 == 2 ? l20 : (l4 == 3 ? l30 : 0.0));
             const double lc1 = l4 == 2 ? l21 : (l4 == 3 ? l31 : 0.0);
             const double lc2 = l4 == 3 ? l32 : 0.0;
@@ -420,10 +450,12 @@ __device__ __forceinline__ void mf_front_bwd(const DV &d, int inst, int s, doubl
     }
 }
 
-// A front of more than 64 rows, by the four waves of a workgroup: 16 columns at a time, the 16 x 16 diagonal block by a
-// shuffle chain in wave 0 (its column loads are independent of the chain and issued up front), the rows below the
-// block by all 256 threads.  Two barriers per 16 columns instead of one dependent step per column.
-__device__ __forceinline__ void mf_front_fwd_big(const DV &d, int inst, int s, double *y, int tid)
+// A front of more than 64 rows, by the four waves of a workgroup.  The triangular part L11 (its nc x nc corner) is
+// staged in LDS with all loads in flight at once; the dependent chain -- 16 columns at a time, the 16 x 16 diagonal block
+// by a shuffle chain in wave 0, the rest of the triangle by all threads -- then runs at LDS latency.  The rectangular
+// part L21 is one fully parallel pass (its loads do not depend on the chain).  Ls == nullptr (corner too large for the
+// LDS of this launch): the same steps straight from the arena.
+__device__ __forceinline__ void mf_front_fwd_big(const DV &d, int inst, int s, double *y, double *Ls, int tid)
 {
     const MfDev &M = d.mf;
     const MfFrontDesc Fd = M.desc[s];
@@ -433,6 +465,9 @@ __device__ __forceinline__ void mf_front_fwd_big(const DV &d, int inst, int s, d
     const double *b = d.xv + (long)inst * d.Fpad + f0, *dinv = d.dinv + (long)inst * d.Fpad + f0;
     double *vv = d.vv + (long)inst * d.Fpad + f0;
     const int lane = tid & 63, wave = tid >> 6;
+    if (Ls)
+        for (int c = wave; c < nc; c += 4)
+            for (int r = c + 1 + lane; r < nc; r += 64) Ls[c * nc + r] = G[(long)c * ld + r];
     for (int i = tid; i < fs; i += 256) y[i] = i < nc ? b[i] : 0.0;
     __syncthreads();
     for (int t = Fd.ev_begin + tid; t < Fd.ev_end; t += 256) {
@@ -442,30 +477,37 @@ __device__ __forceinline__ void mf_front_fwd_big(const DV &d, int inst, int s, d
         y[g.where] += a;
     }
     __syncthreads();
+    const double *L = Ls ? Ls : G;
+    const int ll = Ls ? nc : ld;
     for (int kb = 0; kb < nc; kb += 16) {
         const int nb = nc - kb < 16 ? nc - kb : 16;
         if (wave == 0) {
             double l[15];
 #pragma unroll
-            for (int c = 0; c < 15; ++c) l[c] = (c < nb - 1 && lane > c && lane < nb) ? G[(long)(kb + c) * ld + kb + lane] : 0.0;
+            for (int c = 0; c < 15; ++c) l[c] = (c < nb - 1 && lane > c && lane < nb) ? L[(long)(kb + c) * ll + kb + lane] : 0.0;
             double yi = lane < nb ? y[kb + lane] : 0.0;
 #pragma unroll
             for (int c = 0; c < 15; ++c) yi -= l[c] * __shfl(yi, c);
             if (lane < nb) { y[kb + lane] = yi; vv[kb + lane] = yi * dinv[kb + lane]; }
         }
         __syncthreads();
-        for (int i = kb + nb + tid; i < fs; i += 256) {
+        for (int i = kb + nb + tid; i < nc; i += 256) {          // the rest of the triangle
             double acc = 0.0;
 #pragma unroll 16
-            for (int c = 0; c < nb; ++c) acc += G[(long)(kb + c) * ld + i] * y[kb + c];
+            for (int c = 0; c < nb; ++c) acc += L[(long)(kb + c) * ll + i] * y[kb + c];
             y[i] -= acc;
         }
         __syncthreads();
     }
-    for (int i = nc + tid; i < fs; i += 256) G[(long)i * ld + fs] = y[i];
+    for (int i = nc + tid; i < fs; i += 256) {                    // rows below the supernode: the update for the ancestors
+        double acc = y[i];
+#pragma unroll 8
+        for (int k = 0; k < nc; ++k) acc -= G[(long)k * ld + i] * y[k];
+        G[(long)i * ld + fs] = acc;
+    }
 }
 
-__device__ __forceinline__ void mf_front_bwd_big(const DV &d, int inst, int s, double *x, int tid)
+__device__ __forceinline__ void mf_front_bwd_big(const DV &d, int inst, int s, double *x, double *Ls, int tid)
 {
     const MfDev &M = d.mf;
     const MfFrontDesc Fd = M.desc[s];
@@ -476,16 +518,35 @@ __device__ __forceinline__ void mf_front_bwd_big(const DV &d, int inst, int s, d
     const int *rows = M.rows + Fd.rowptr;
     const int lane = tid & 63, wave = tid >> 6;
     double *part = x + fs;                       // 16 block sums behind the vector
+    if (Ls)
+        for (int c = wave; c < nc; c += 4)
+            for (int r = c + 1 + lane; r < nc; r += 64) Ls[c * nc + r] = G[(long)c * ld + r];
     for (int i = tid; i < fs; i += 256) x[i] = i < nc ? vv[i] : xg[rows[i - nc]];
     __syncthreads();
+    {   // x_cols -= L21' x_rows: column k by 16 threads, every column block independent of the others
+        const int c = tid >> 4, r = tid & 15;
+        for (int kb = 0; kb < nc; kb += 16) {
+            double a = 0.0;
+            if (kb + c < nc) {
+                const double *Gc = G + (long)(kb + c) * ld;
+#pragma unroll 4
+                for (int i = nc + r; i < fs; i += 16) a += Gc[i] * x[i];
+            }
+            a += __shfl_xor(a, 8); a += __shfl_xor(a, 4); a += __shfl_xor(a, 2); a += __shfl_xor(a, 1);
+            if (r == 0 && kb + c < nc) x[kb + c] -= a;
+        }
+    }
+    __syncthreads();
+    const double *L = Ls ? Ls : G;
+    const int ll = Ls ? nc : ld;
     for (int kb = ((nc - 1) >> 4) << 4; kb >= 0; kb -= 16) {
         const int nb = nc - kb < 16 ? nc - kb : 16;
-        {   // column c of the block by 16 threads: its dot product with x below the block
+        {   // column c of the block by 16 threads: its dot product with the finished x inside the triangle
             const int c = tid >> 4, r = tid & 15;
             double a = 0.0;
             if (c < nb) {
-                const double *Gc = G + (long)(kb + c) * ld;
-                for (int i = kb + nb + r; i < fs; i += 16) a += Gc[i] * x[i];
+                const double *Lc = L + (long)(kb + c) * ll;
+                for (int i = kb + nb + r; i < nc; i += 16) a += Lc[i] * x[i];
             }
             a += __shfl_xor(a, 8); a += __shfl_xor(a, 4); a += __shfl_xor(a, 2); a += __shfl_xor(a, 1);
             if (r == 0) part[c] = a;
@@ -494,7 +555,7 @@ __device__ __forceinline__ void mf_front_bwd_big(const DV &d, int inst, int s, d
         if (wave == 0) {
             double l[15];
 #pragma unroll
-            for (int c = 1; c < 16; ++c) l[c - 1] = (c < nb && lane < c) ? G[(long)(kb + lane) * ld + kb + c] : 0.0;
+            for (int c = 1; c < 16; ++c) l[c - 1] = (c < nb && lane < c) ? L[(long)(kb + lane) * ll + kb + c] : 0.0;
             double t = lane < nb ? x[kb + lane] - part[lane] : 0.0;
 #pragma unroll
             for (int c = 15; c > 0; --c) t -= l[c - 1] * __shfl(t, c);
@@ -506,26 +567,34 @@ __device__ __forceinline__ void mf_front_bwd_big(const DV &d, int inst, int s, d
 
 // level-by-level launches: a workgroup of four waves per work item = one front of more than 64 rows (all four waves)
 // or up to four smaller fronts (one wave each; nothing but wave-level synchronisation on that path)
-__global__ __launch_bounds__(256) void k_mf_fwd(DV d, int ibegin, int want, int generic, int wstride)
+__global__ __launch_bounds__(256) void k_mf_fwd(DV d, int ibegin, int want, int generic, int wstride, int vecsz, int lcap)
 {
     const int inst = blockIdx.y;
     if (d.phase[inst] != want) return;
     extern __shared__ double mf_lds[];
     const int4 it = reinterpret_cast<const int4 *>(d.mf.sol_items)[ibegin + blockIdx.x];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (it.y == -2) { mf_front_fwd_big(d, inst, it.x, mf_lds, threadIdx.x); return; }
+    if (it.y == -2) {
+        const int nc = d.mf.desc[it.x].nc;
+        mf_front_fwd_big(d, inst, it.x, mf_lds, nc * nc <= lcap ? mf_lds + vecsz : nullptr, threadIdx.x);
+        return;
+    }
     const int s = wave == 0 ? it.x : (wave == 1 ? it.y : (wave == 2 ? it.z : it.w));
     if (s >= 0) mf_front_fwd(d, inst, s, mf_lds + wstride * wave, threadIdx.x & 63, generic);
 }
 
-__global__ __launch_bounds__(256) void k_mf_bwd(DV d, int ibegin, int want, int generic, int wstride)
+__global__ __launch_bounds__(256) void k_mf_bwd(DV d, int ibegin, int want, int generic, int wstride, int vecsz, int lcap)
 {
     const int inst = blockIdx.y;
     if (d.phase[inst] != want) return;
     extern __shared__ double mf_lds[];
     const int4 it = reinterpret_cast<const int4 *>(d.mf.sol_items)[ibegin + blockIdx.x];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (it.y == -2) { mf_front_bwd_big(d, inst, it.x, mf_lds, threadIdx.x); return; }
+    if (it.y == -2) {
+        const int nc = d.mf.desc[it.x].nc;
+        mf_front_bwd_big(d, inst, it.x, mf_lds, nc * nc <= lcap ? mf_lds + vecsz : nullptr, threadIdx.x);
+        return;
+    }
     const int s = wave == 0 ? it.x : (wave == 1 ? it.y : (wave == 2 ? it.z : it.w));
     if (s >= 0) mf_front_bwd(d, inst, s, mf_lds + wstride * wave, threadIdx.x & 63, generic);
 }
@@ -599,9 +668,9 @@ void mf_solve(Ctx &C, int want, bool skip_fwd)
     }
     if (!skip_fwd)
         for (const MfLaunch &L : C.mfp.fwd)
-            hipLaunchKernelGGL(k_mf_fwd, dim3(L.count, d.B), dim3(256), L.lds_bytes, s, d, L.begin, want, generic, L.tiles);
+            hipLaunchKernelGGL(k_mf_fwd, dim3(L.count, d.B), dim3(256), L.lds_bytes, s, d, L.begin, want, generic, L.tiles, L.cls, L.lds_bytes / 8 - L.cls);
     for (const MfLaunch &L : C.mfp.bwd)
-        hipLaunchKernelGGL(k_mf_bwd, dim3(L.count, d.B), dim3(256), L.lds_bytes, s, d, L.begin, want, generic, L.tiles);
+        hipLaunchKernelGGL(k_mf_bwd, dim3(L.count, d.B), dim3(256), L.lds_bytes, s, d, L.begin, want, generic, L.tiles, L.cls, L.lds_bytes / 8 - L.cls);
 }
 
 }  // namespace sqphip
