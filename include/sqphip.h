@@ -297,6 +297,8 @@ typedef struct {
                               * batching the slowest instance of the batch decides this number */
     int64_t n_solve;         /* forward + backward solves with the factors, summed over the instances (first solve of a
                               * factorisation, corrector, refinement steps) */
+    int64_t n_groups;        /* instance groups of sqphip_sqp_run, each on its own HIP stream and host thread (1: none).
+                              * n_sweeps and the kernel seconds are summed over the groups */
 } sqphip_counters;
 int sqphip_get_counters(sqphip_ctx *ctx, sqphip_counters *c);
 int sqphip_reset_counters(sqphip_ctx *ctx);

@@ -52,7 +52,7 @@ class Counters(C.Structure):
                 ("sparse", C.c_int64), ("nnz_k", C.c_int64), ("nnz_l", C.c_int64), ("n_supernodes", C.c_int64),
                 ("n_levels", C.c_int64), ("max_front", C.c_int64), ("factor_flops", C.c_double),
                 ("front_doubles", C.c_int64), ("cb_doubles", C.c_int64), ("factor_launches", C.c_int64),
-                ("solve_launches", C.c_int64), ("n_sweeps", C.c_int64), ("n_solve", C.c_int64)]
+                ("solve_launches", C.c_int64), ("n_sweeps", C.c_int64), ("n_solve", C.c_int64), ("n_groups", C.c_int64)]
 
 
 class SymbolicStats(C.Structure):

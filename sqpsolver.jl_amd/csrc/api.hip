@@ -13,12 +13,13 @@ using namespace sqphip;
 
 Ctx::~Ctx()
 {
+    lanes.clear();              // before the arenas they point into
     tm.flush();
     comm_release(*this);
     plan.destroy_lookahead();
     for (void *p : allocs) hipFree(p);
     if (h_counters) hipHostFree(h_counters);
-    if (stream) hipStreamDestroy(stream);
+    if (stream && owns_stream) hipStreamDestroy(stream);
 }
 
 namespace {
@@ -76,6 +77,62 @@ void h2d(Ctx &C, double *dst, const double *src, size_t k)
 void d2h(Ctx &C, double *dst, const double *src, size_t k)
 {
     if (dst && k) SQPHIP_HIP_OK(hipMemcpyAsync(dst, src, sizeof(double) * k, hipMemcpyDeviceToHost, C.stream));
+}
+
+// the device view of instances [i0, i0 + Bg): every per-instance array advanced to the group's first instance, so that
+// the kernels see an ordinary (smaller) batch.  Shared structure arrays stay as they are.
+DV group_view(const DV &d, int i0, int Bg, int g)
+{
+    DV v = d;
+    v.B = Bg;
+    const long n = d.n, m = d.m, o = i0;
+    double **nv[] = { &v.xL, &v.xU, &v.xk, &v.cin, &v.c, &v.hd, &v.lb, &v.ub, &v.p, &v.zl, &v.zu, &v.dp, &v.dzl, &v.dzu, &v.rd,
+                      &v.sigp, &v.wn, &v.op, &v.omxU, &v.omxL, &v.x, &v.mxL, &v.mxU, &v.df, &v.pstep, &v.psoc, &v.pmxL,
+                      &v.pmxU, &v.tmpx, &v.x0, &v.socZL, &v.socZU };
+    for (auto pp : nv) *pp += o * n;
+    double **mv[] = { &v.gL, &v.gU, &v.bE, &v.lo, &v.hi, &v.wp, &v.wm, &v.s, &v.tp, &v.tm, &v.y, &v.vl, &v.vu, &v.ds, &v.dtp,
+                      &v.dtm, &v.dy, &v.dvl, &v.dvu, &v.rp, &v.Dd, &v.olam, &v.lambda, &v.E, &v.plam, &v.Esoc, &v.tmpE,
+                      &v.hlam, &v.zp, &v.zm, &v.rdir, &v.socZP, &v.socZM, &v.socVL, &v.socVU };
+    for (auto pp : mv) *pp += o * m;
+    v.oslack += 2 * o * m;
+    v.rtype += o * m; v.rbase += o * m; v.hard += o * m;
+    v.jcoo += o * d.nnzj_coo; v.hcoo += o * d.nnzh_coo; v.jv += o * d.nnzjc; v.hv += o * d.nnzhc;
+    v.rhs += o * d.Npad; v.sol += o * d.Npad; v.wN += o * d.Npad;
+    v.xv += o * d.Fpad; v.vv += o * d.Fpad; v.dinv += o * d.Fpad;
+    v.ist += o; v.sst += o; v.phase += o;
+    v.trace += o * SQPHIP_TRACE_CAP * SQPHIP_TRACE_COLS;
+    v.counters = d.counters + 8 * (g + 1);
+    if (v.br_ohm) { v.br_ohm += o * d.nl * 12; v.c2 += o * d.ng; v.c1 += o * d.ng; }
+    v.mf.fronts += o * d.mf.stride; v.mf.vals += o * (long)d.mf.nnzK;
+    return v;
+}
+
+// (re)build the lanes from the owner's current device view (after sqphip_create and after sqphip_acopf_attach)
+void make_lanes(Ctx &C)
+{
+    C.lanes.clear();
+    int G = 1;
+    if (C.d.sparse) G = C.d.B >= 256 ? 4 : (C.d.B >= 64 ? 2 : 1);
+    if (const char *e = getenv("SQPHIP_GROUPS")) G = atoi(e);
+    if (G > C.d.B) G = C.d.B;
+    if (G > 7) G = 7;                       // counter slots
+    if (!C.d.sparse || G < 2) return;
+    for (int g = 0; g < G; ++g) {
+        const int lo = (int)((long)C.d.B * g / G), hi = (int)((long)C.d.B * (g + 1) / G);
+        std::unique_ptr<Ctx> L(new Ctx());
+        L->is_lane = true;
+        L->opt = C.opt; L->n = C.n; L->m = C.m; L->acopf_attached = C.acopf_attached;
+        L->mfp_ = C.mfp_;
+        L->d = group_view(C.d, lo, hi - lo, g);
+        // the first group runs on the owner's stream (idle during sqphip_sqp_run): HIP maps streams onto four hardware
+        // queues by default, and a fifth stream would share one -- measured: 3131 QP/s with five streams against 5216
+        // with four (or with GPU_MAX_HW_QUEUES=8)
+        if (g == 0) { L->stream = C.stream; L->owns_stream = false; }
+        else SQPHIP_HIP_OK(hipStreamCreate(&L->stream));
+        SQPHIP_HIP_OK(hipHostMalloc((void **)&L->h_counters, 8 * sizeof(int)));
+        L->tm.enabled = C.tm.enabled;
+        C.lanes.push_back(std::move(L));
+    }
 }
 
 __global__ void k_qp_request(DV d, int inst, int mode, double delta, double mu_pen)
@@ -179,8 +236,8 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
                 if (const char *e = getenv("SQPHIP_MF_SMALL_FRONT")) so.small_front = atoi(e);
                 if (const char *e = getenv("SQPHIP_MF_ZERO_FRAC")) so.zero_frac = atof(e);
                 if (const char *e = getenv("SQPHIP_MF_ROWS_AFTER")) so.rows_after_vars = atoi(e);
-                C.mfp = mf_build_plan(d.n, (int)m, kp, d.condense ? d.mk : (int)m, PH.colptr, PH.rowval, rptr, rcol, rslot, so);
-                const SparseSym &S = C.mfp.S;
+                C.mfp_ = std::make_shared<MfPlan>(mf_build_plan(d.n, (int)m, kp, d.condense ? d.mk : (int)m, PH.colptr, PH.rowval, rptr, rcol, rslot, so));
+                const SparseSym &S = C.mfp().S;
                 // auto: the sparse factorisation when it does a quarter of the dense work or less and no front
                 // outgrows what one workgroup eliminates in reasonable time; a dense Hessian goes to the MFMA path
                 const double dense_flops = (double)nu * nu * nu / 3.0;
@@ -189,7 +246,7 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
                 d.sparse = opt->kkt_mode == 2 || (fits && S.max_front <= 512 && S.flops <= 0.25 * dense_flops);
             }
             if (d.sparse) {
-                const MfPlan &P = C.mfp;
+                const MfPlan &P = C.mfp();
                 const SparseSym &S = P.S;
                 upos = S.pos;
                 MfDev &M = d.mf;
@@ -268,7 +325,7 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
         d.xv = C.dalloc<double>(BF); d.vv = C.dalloc<double>(BF); d.dinv = C.dalloc<double>(BF);
         d.K = C.dalloc<double>(d.sparse ? 1 : (size_t)B * d.ld * d.Fpad);
         d.ist = C.dalloc<IpmState>(B); d.sst = C.dalloc<SqpState>(B);
-        d.phase = C.dalloc<int>(B); d.counters = C.dalloc<int>(8);
+        d.phase = C.dalloc<int>(B); d.counters = C.dalloc<int>(64);
         d.trace = C.dalloc<double>((size_t)B * SQPHIP_TRACE_CAP * SQPHIP_TRACE_COLS);
         d.ipm_tol = opt->ipm_tol; d.ipm_max_iter = opt->ipm_max_iter; d.ipm_phase1 = opt->ipm_phase1; d.ipm_corrector = opt->ipm_corrector;
         d.refine_tol = getenv("SQPHIP_REFINE_TOL") ? atof(getenv("SQPHIP_REFINE_TOL")) : 1e-11;
@@ -285,6 +342,7 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
             C.plan.init_lookahead();
         }
         SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        make_lanes(C);
         return SQPHIP_OK;
     });
     if (rc != SQPHIP_OK) {
@@ -376,7 +434,7 @@ extern "C" int sqphip_mf_solve_test(sqphip_ctx *h, int32_t inst, const double *J
     if (!h->c.d.sparse) { h->c.err = "sqphip_mf_solve_test: the context does not use the sparse solver"; return SQPHIP_ESTATE; }
     return guarded(h, [&](Ctx &C) {
         DV &d = C.d;
-        const SparseSym &S = C.mfp.S;
+        const SparseSym &S = C.mfp().S;
         const size_t on = (size_t)inst * d.n, om = (size_t)inst * d.m;
         h2d(C, d.jcoo + (size_t)inst * d.nnzj_coo, Jval, d.nnzj_coo);
         if (Hval) h2d(C, d.hcoo + (size_t)inst * d.nnzh_coo, Hval, d.nnzh_coo);
@@ -644,6 +702,7 @@ extern "C" int sqphip_acopf_attach(sqphip_ctx *h, int32_t nb, int32_t ng, int32_
         d.c2 = C.dalloc<double>((size_t)d.B * ng); d.c1 = C.dalloc<double>((size_t)d.B * ng);
         SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
         C.acopf_attached = true;
+        make_lanes(C);
         return SQPHIP_OK;
     });
 }
@@ -669,6 +728,7 @@ extern "C" int sqphip_acopf_set_shunts(sqphip_ctx *h, int32_t nsh, const int32_t
         d.sh_gs = C.upload(std::vector<double>(gs, gs + nsh));
         d.sh_bs = C.upload(std::vector<double>(bs, bs + nsh));
         SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        make_lanes(C);
         return SQPHIP_OK;
     });
 }
@@ -680,6 +740,7 @@ extern "C" int sqphip_acopf_set_dclines(sqphip_ctx *h, int32_t ndc, const double
     return guarded(h, [&](Ctx &C) {
         C.d.dc_loss1 = C.upload(std::vector<double>(loss1, loss1 + ndc));
         SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        make_lanes(C);
         return SQPHIP_OK;
     });
 }
@@ -801,6 +862,13 @@ extern "C" int sqphip_get_counters(sqphip_ctx *h, sqphip_counters *c)
         SQPHIP_HIP_OK(hipMemcpyAsync(S.data(), C.d.sst, sizeof(SqpState) * C.d.B, hipMemcpyDeviceToHost, C.stream));
         SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
         C.tm.flush();
+        double lane_factor = 0, lane_trailing = 0, lane_solve = 0;
+        long lane_sweeps = 0;
+        for (auto &L : C.lanes) {
+            L->tm.flush();
+            lane_factor += L->tm.factor_seconds; lane_trailing += L->tm.trailing_seconds; lane_solve += L->tm.solve_seconds;
+            lane_sweeps += L->n_sweeps;
+        }
         int64_t nqp = C.n_qp, nip = C.n_ipm_iter, nf = C.n_factor, nsol = C.n_solve;
         for (auto &s : S) { nqp += s.n_qp; nip += s.tot_ipm; nf += s.tot_fac; nsol += s.tot_sol; }
         c->n_qp = nqp; c->n_ipm_iter = nip; c->n_factor = nf;
@@ -809,21 +877,21 @@ extern "C" int sqphip_get_counters(sqphip_ctx *h, sqphip_counters *c)
         c->lead_tiles = C.d.Ts;
         c->trailing_flops_per_factor = ldlt_trailing_flops(C.plan);
         c->ldlt_flops = (double)nf * N * N * N / 3.0;
-        c->ldlt_seconds = C.tm.factor_seconds; c->trailing_seconds = C.tm.trailing_seconds;
-        c->solve_seconds = C.tm.solve_seconds; c->total_seconds = C.total_seconds;
+        c->ldlt_seconds = C.tm.factor_seconds + lane_factor; c->trailing_seconds = C.tm.trailing_seconds + lane_trailing;
+        c->solve_seconds = C.tm.solve_seconds + lane_solve; c->total_seconds = C.total_seconds;
         c->trailing_launches = C.tm.trailing_launches;
-        c->n_sweeps = C.n_sweeps; c->n_solve = nsol;
+        c->n_sweeps = C.n_sweeps + lane_sweeps; c->n_solve = nsol; c->n_groups = C.lanes.empty() ? 1 : (int64_t)C.lanes.size();
         c->sparse = C.d.sparse; c->nnz_k = 0; c->nnz_l = 0; c->n_supernodes = 0; c->n_levels = 0; c->max_front = 0;
         c->factor_flops = 0; c->front_doubles = 0; c->cb_doubles = 0; c->factor_launches = 0; c->solve_launches = 0;
         if (C.d.sparse) {
-            const SparseSym &Y = C.mfp.S;
-            c->nnz_k = C.mfp.nnzK; c->nnz_l = Y.nnzL; c->n_supernodes = Y.ns; c->n_levels = Y.nlevels;
-            c->max_front = Y.max_front; c->factor_flops = Y.flops; c->front_doubles = C.mfp.stride;
+            const SparseSym &Y = C.mfp().S;
+            c->nnz_k = C.mfp().nnzK; c->nnz_l = Y.nnzL; c->n_supernodes = Y.ns; c->n_levels = Y.nlevels;
+            c->max_front = Y.max_front; c->factor_flops = Y.flops; c->front_doubles = C.mfp().stride;
             long cb = 0;
             for (int q = 0; q < Y.ns; ++q) cb += (long)(Y.sn_nr[q] + 1) * Y.sn_nr[q] - (long)Y.sn_nr[q] * (Y.sn_nr[q] - 1) / 2;
             c->cb_doubles = cb;
-            c->factor_launches = (int64_t)C.mfp.fac.size();
-            c->solve_launches = (int64_t)(C.mfp.fwd.size() + C.mfp.bwd.size());
+            c->factor_launches = (int64_t)C.mfp().fac.size();
+            c->solve_launches = (int64_t)(C.mfp().fwd.size() + C.mfp().bwd.size());
             c->ldlt_flops = (double)nf * Y.flops;
         }
         return SQPHIP_OK;
@@ -838,6 +906,11 @@ extern "C" int sqphip_reset_counters(sqphip_ctx *h)
     C.tm.trailing_seconds = C.tm.factor_seconds = C.tm.solve_seconds = 0;
     C.tm.trailing_launches = 0; C.tm.n_factor = 0;
     C.n_qp = C.n_ipm_iter = C.n_factor = C.n_solve = 0; C.total_seconds = 0; C.n_sweeps = 0;
+    for (auto &L : C.lanes) {
+        L->tm.flush();
+        L->tm.trailing_seconds = L->tm.factor_seconds = L->tm.solve_seconds = 0; L->tm.trailing_launches = 0; L->tm.n_factor = 0;
+        L->n_sweeps = 0;
+    }
     return SQPHIP_OK;
 }
 
@@ -847,5 +920,6 @@ extern "C" int sqphip_set_timing(sqphip_ctx *h, int32_t enabled)
     if (!h) return SQPHIP_EINVAL;
     h->c.tm.flush();
     h->c.tm.enabled = enabled != 0;
+    for (auto &L : h->c.lanes) { L->tm.flush(); L->tm.enabled = enabled != 0; }
     return SQPHIP_OK;
 }

@@ -636,7 +636,7 @@ void mf_factor(Ctx &C, int want, bool with_rhs)
     static const bool v1 = getenv("SQPHIP_MF_V1") != nullptr;      // cross-check: the plain rank-1 kernel for every front
     const int wr = (int)with_rhs;
     if (!v1) hipLaunchKernelGGL(k_mf_values, dim3((d.mf.nnzK + 255) / 256, d.B), dim3(256), 0, s, d, want);
-    for (const MfLaunch &L : C.mfp.fac) {
+    for (const MfLaunch &L : C.mfp().fac) {
         const dim3 grid(L.count, d.B);
         const int cls = v1 ? 5 : L.cls;
         switch (cls) {
@@ -648,7 +648,7 @@ void mf_factor(Ctx &C, int want, bool with_rhs)
         default: hipLaunchKernelGGL((k_mf_factor<256, true>), grid, dim3(256), 0, s, d, L.begin, want, wr); break;
         }
     }
-    C.mf_factor_launches += (long)C.mfp.fac.size();
+    C.mf_factor_launches += (long)C.mfp().fac.size();
 }
 
 // x (d.xv) <- K^-1 x through the factors; skip_fwd: d.vv already holds D^-1 L^-1 b (fused into mf_factor)
@@ -667,9 +667,9 @@ void mf_solve(Ctx &C, int want, bool skip_fwd)
         return;
     }
     if (!skip_fwd)
-        for (const MfLaunch &L : C.mfp.fwd)
+        for (const MfLaunch &L : C.mfp().fwd)
             hipLaunchKernelGGL(k_mf_fwd, dim3(L.count, d.B), dim3(256), L.lds_bytes, s, d, L.begin, want, generic, L.tiles, L.cls, L.lds_bytes / 8 - L.cls);
-    for (const MfLaunch &L : C.mfp.bwd)
+    for (const MfLaunch &L : C.mfp().bwd)
         hipLaunchKernelGGL(k_mf_bwd, dim3(L.count, d.B), dim3(256), L.lds_bytes, s, d, L.begin, want, generic, L.tiles, L.cls, L.lds_bytes / 8 - L.cls);
 }
 

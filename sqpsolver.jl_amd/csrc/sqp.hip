@@ -14,6 +14,7 @@
 #include "dev_util.hpp"
 #include "acopf_dev.hpp"
 #include <cmath>
+#include <thread>
 
 namespace sqphip {
 
@@ -483,7 +484,27 @@ void sqp_reset(Ctx &C)
 // Continuous batching: one fixed kernel sequence per sweep; every kernel is gated on the per-instance
 // stage / phase, so an instance whose sub-problem has converged goes through its merit step and into
 // its next sub-problem while the others are still iterating -- no instance waits for the slowest.
+static void sqp_run_lane(Ctx &C, int max_outer);
+
+// With instance groups (Ctx::lanes) every group runs the same loop on its own stream from its own host thread;
+// instances never interact, so the results do not depend on the grouping.
 void sqp_run(Ctx &C, int max_outer)
+{
+    if (C.lanes.empty()) { sqp_run_lane(C, max_outer); return; }
+    std::vector<std::thread> th;
+    std::vector<std::string> errs(C.lanes.size());
+    for (size_t g = 0; g < C.lanes.size(); ++g)
+        th.emplace_back([&, g] {
+            try {
+                SQPHIP_HIP_OK(hipSetDevice(C.opt.device));
+                sqp_run_lane(*C.lanes[g], max_outer);
+            } catch (const std::string &e) { errs[g] = e; }
+        });
+    for (auto &t : th) t.join();
+    for (auto &e : errs) if (!e.empty()) throw e;
+}
+
+static void sqp_run_lane(Ctx &C, int max_outer)
 {
     DV &d = C.d;
     hipStream_t s = C.stream;

@@ -1171,6 +1171,30 @@ def test_batched_run_is_reproducible_bit_for_bit():
         assert np.array_equal(x, y)
 
 
+def test_instance_groups_change_nothing_but_the_schedule():
+    """sqphip_sqp_run splits a large batch into instance groups, each on its own HIP stream and host thread (the level
+    launches of one group fill the chip while another's sit at the narrow top of the tree).  Instances never interact:
+    forcing three groups on a batch of eight must reproduce the single-stream run bit for bit."""
+    nb, ng, nl, seed = CASES["case14"]
+    base = acopf_synth(nb, ng, nl, seed)
+    nets = [base] + [contingency(base, s, seed) for s in range(1, 8)]
+    lays = [acopf_layout(nt) for nt in nets]
+    kw = dict(max_iter=12, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=1)
+    out = {}
+    for G in ("1", "3"):
+        os.environ["SQPHIP_GROUPS"] = G
+        try:
+            ctx = _run_batch(nets, lays, kw, kkt_mode=2)
+        finally:
+            del os.environ["SQPHIP_GROUPS"]
+        assert ctx.counters()["n_groups"] == int(G)
+        out[G] = [(ctx.sqp_get(b)["x"], ctx.sqp_get(b)["status"], ctx.sqp_get(b)["iter"], ctx.sqp_trace(b)) for b in range(8)]
+        ctx.close()
+    for a, b in zip(out["1"], out["3"]):
+        assert np.array_equal(a[0], b[0]) and a[1:3] == b[1:3]
+        assert [t["ipm_iters"] for t in a[3]] == [t["ipm_iters"] for t in b[3]]
+
+
 def test_batch_of_eight_matches_oracle_instance_by_instance():
     """Batch 8 (XCD-aware tile map, eight concurrent stage workgroups): every instance against the oracle."""
     nb, ng, nl, seed = CASES["case14"]
