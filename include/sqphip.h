@@ -68,6 +68,12 @@ typedef struct {
                               * 2: multifrontal LDL^T of the sparse matrix (mfront.hip: symbolic analysis once per
                               * structure, dense fronts in LDS); 0 (default): the sparse one when it does at most a
                               * quarter of the dense flops and no front exceeds 512 rows, else the dense one */
+    int32_t ipm_warm_start;  /* 1: the first interior-point run of a sub-problem starts from the step and the equality-row
+                              * multipliers of the instance's previous solved sub-problem of the same mode -- what
+                              * warm_start_init_point = "yes" asks of Ipopt (/root/reference/test/ext_solver.jl:5,
+                              * examples/acopf/opf.jl:62; upstream the model is rebuilt every iteration, so the option has
+                              * no effect there).  0 (default): centred cold start, fewer iterations on every workload
+                              * measured */
 } sqphip_options;
 
 void sqphip_default_options(sqphip_options *o);

@@ -21,7 +21,7 @@ struct SqpHipOptions
     max_iter::Int32; use_soc::Int32; literal_quirks::Int32
     ipm_tol::Cdouble
     ipm_max_iter::Int32; ipm_phase1::Int32; device::Int32; ipm_corrector::Int32
-    kkt_condense::Int32; kkt_tile_order::Int32; kkt_mode::Int32
+    kkt_condense::Int32; kkt_tile_order::Int32; kkt_mode::Int32; ipm_warm_start::Int32
 end
 
 function sqphip_default_options()
@@ -36,7 +36,7 @@ function SqpHipOptions(par; device::Integer = 0, literal_quirks::Integer = 1)
     return SqpHipOptions(par.tol_direction, par.tol_residual, par.tol_infeas, par.init_mu, par.max_mu, par.tr_size,
                          par.rho, par.eta, par.tau, par.min_alpha, par.max_iter, par.use_soc ? 1 : 0, literal_quirks,
                          d.ipm_tol, d.ipm_max_iter, d.ipm_phase1, device, d.ipm_corrector, d.kkt_condense,
-                         d.kkt_tile_order, d.kkt_mode)
+                         d.kkt_tile_order, d.kkt_mode, d.ipm_warm_start)
 end
 
 mutable struct QpHip{T,Tv<:AbstractArray{T},Tm<:AbstractMatrix{T}} <: AbstractSubOptimizer

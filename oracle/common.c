@@ -28,6 +28,7 @@ void ora_default_options(ora_options *o)
     o->kkt_condense = 1;
     o->kkt_tile_order = 0;
     o->kkt_mode = 0;
+    o->ipm_warm_start = 0;
 }
 
 /* Julia's isapprox(a, b) with default rtol = sqrt(eps), atol = 0

@@ -26,7 +26,7 @@ class Options(C.Structure):
                 ("ipm_tol", C.c_double),
                 ("ipm_max_iter", C.c_int), ("ipm_phase1", C.c_int), ("num_threads", C.c_int),
                 ("ipm_corrector", C.c_int), ("kkt_condense", C.c_int), ("kkt_tile_order", C.c_int),
-                ("kkt_mode", C.c_int)]
+                ("kkt_mode", C.c_int), ("ipm_warm_start", C.c_int)]
 
 
 class TraceRow(C.Structure):

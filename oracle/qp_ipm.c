@@ -67,6 +67,9 @@ struct ora_qp {
     int64_t nt;
     double *tv;
     double delta_w_last;
+    /* warm start (opt.ipm_warm_start): mode of the last solved sub-problem, -1 = none; its p and y are still in place */
+    int prev_mode;
+    double prev_sf;
     /* stats */
     int ipm_iters, n_factor;
     double last_elastic;
@@ -165,6 +168,7 @@ ora_qp *ora_qp_create(int64_t n, int64_t m, int64_t num_linear,
     }
     if (q->sparse) kkt_sparse_setup(q);
     else q->K = dalloc(q->ld * q->N);
+    q->prev_mode = -1;
     return q;
 }
 
@@ -751,7 +755,8 @@ static double nudge_inside(double v, double lo, double hi)
     return v;
 }
 
-static void ipm_init(ora_qp *q, const double *p_start)
+/* y_start (may be NULL): multipliers of the equality rows to start from (warm start); capped like the cold ones */
+static void ipm_init(ora_qp *q, const double *p_start, const double *y_start)
 {
     int64_t n = q->n, m = q->m;
     const double mu0 = 1.0;
@@ -778,6 +783,9 @@ static void ipm_init(ora_qp *q, const double *p_start)
                 double sc = cap / fabs(y);
                 q->vl[i] *= sc; q->vu[i] *= sc; y *= sc;
             }
+        } else if (y_start) {            /* equality row, warm start: the previous multiplier, inside the penalty box */
+            double cap = 0.5 * fmin(q->wp[i], q->wm[i]);
+            y = fmax(-cap, fmin(cap, y_start[i]));
         }
         q->s[i] = s; q->y[i] = y;
         q->zp[i] = q->wp[i] - y; q->zm[i] = q->wm[i] + y;
@@ -793,12 +801,12 @@ static void ipm_init(ora_qp *q, const double *p_start)
  * variables absorb every row residual).  Constants follow the published Ipopt defaults
  * (kappa_eps=10, kappa_mu=0.2, theta_mu=1.5, tau_min=0.99).
  * returns 0 converged, 1 iteration limit, 2 numerical failure */
-static int ipm_run(ora_qp *q, const double *p_start)
+static int ipm_run(ora_qp *q, const double *p_start, const double *y_start)
 {
     int64_t n = q->n, m = q->m;
     double *rd = (double *)malloc(sizeof(double) * (size_t)(n + 1));
     double *rp = (double *)malloc(sizeof(double) * (size_t)(m + 1));
-    ipm_init(q, p_start);
+    ipm_init(q, p_start, y_start);
     q->delta_w_last = 0.0;
     int rc = 1;
     const double tol = q->opt.ipm_tol;
@@ -1029,11 +1037,21 @@ int ora_qp_solve(ora_qp *q, int mode, const double *x_k, double delta, double mu
     }
     double soft_w = (mode == ORA_MODE_L1QP ? mu_pen : 1.0) * q->sf;
 
+    /* warm start: the first run starts from the step and equality multipliers of the previous solved sub-problem of
+     * the same mode (still in q->p / q->y); restarts with a larger penalty start cold */
+    double *ystart = NULL;
+    if (q->opt.ipm_warm_start && mode != ORA_MODE_LP && q->prev_mode == mode) {
+        pstart = (double *)malloc(sizeof(double) * (size_t)n);
+        memcpy(pstart, q->p, sizeof(double) * (size_t)n);
+        ystart = (double *)malloc(sizeof(double) * (size_t)(m + 1));
+        for (int64_t i = 0; i < m; ++i) ystart[i] = q->y[i] * (q->sf / q->prev_sf);   /* into this solve's objective scale */
+    }
     int status = ORA_MOI_OTHER_ERROR;
     double rho_big = RHO_BIG0;
-    for (;;) {
+    for (int run = 0;; ++run) {
         set_weights(q, rho_big, soft_w, 0);
-        int rc = ipm_run(q, pstart);
+        if (run > 0 && mode != ORA_MODE_LP) { free(pstart); pstart = NULL; free(ystart); ystart = NULL; }
+        int rc = ipm_run(q, pstart, ystart);
         if (rc == 1) { status = ORA_MOI_ITERATION_LIMIT; break; }
         if (rc == 2) { status = ORA_MOI_NUMERICAL_ERROR; break; }
         q->last_elastic = hard_elastic(q);
@@ -1077,7 +1095,7 @@ int ora_qp_solve(ora_qp *q, int mode, const double *x_k, double delta, double mu
             memset(q->hd, 0, nb);
             for (int64_t i = 0; i < m; ++i) if (!q->hard[i]) q->rtype[i] = ROW_FREE;
             set_weights(q, 1.0, 1.0, 1);
-            int rc1 = ipm_run(q, pstart);
+            int rc1 = ipm_run(q, pstart, NULL);
             double e1 = hard_elastic(q);
             memcpy(q->rtype, srt, sizeof(int) * (size_t)m);
             memcpy(q->c, sc, nb); memcpy(q->hv, shv, sizeof(double) * (size_t)q->nnzh);
@@ -1095,7 +1113,9 @@ int ora_qp_solve(ora_qp *q, int mode, const double *x_k, double delta, double mu
             rho_big *= 100.0;
         }
     }
-    free(pstart);
+    free(pstart); free(ystart);
+    q->prev_mode = status == ORA_MOI_LOCALLY_SOLVED ? mode : -1;
+    q->prev_sf = q->sf;
 
     /* collect_solution!: subproblem_JuMP.jl:514-563 */
     if (status == ORA_MOI_LOCALLY_SOLVED) {

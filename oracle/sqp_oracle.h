@@ -72,6 +72,9 @@ typedef struct {
                            not read this field */
     int kkt_mode;       /* linear algebra of the Newton systems: 1 dense LDL^T (above), 2 sparse LDL^T with the oracle's
                            own minimum-degree order (sparse_ldlt.c), 0 (default): sparse from order 3000 up, else dense */
+    int ipm_warm_start; /* 1: the first interior-point run of a sub-problem starts from the step and the equality-row
+                           multipliers of the previous solved sub-problem of the same mode (the reference passes
+                           warm_start_init_point = "yes" to Ipopt, test/ext_solver.jl:5); 0 (default): cold start */
 } ora_options;
 
 /* sparse_ldlt.c: sparse LDL^T without pivoting (ordering + up-looking factorisation), the checker of the product's

@@ -40,7 +40,8 @@ class Options(C.Structure):
                [("max_iter", C.c_int32), ("use_soc", C.c_int32), ("literal_quirks", C.c_int32),
                 ("ipm_tol", C.c_double), ("ipm_max_iter", C.c_int32), ("ipm_phase1", C.c_int32),
                 ("device", C.c_int32), ("ipm_corrector", C.c_int32),
-                ("kkt_condense", C.c_int32), ("kkt_tile_order", C.c_int32), ("kkt_mode", C.c_int32)]
+                ("kkt_condense", C.c_int32), ("kkt_tile_order", C.c_int32), ("kkt_mode", C.c_int32),
+                ("ipm_warm_start", C.c_int32)]
 
 
 class Counters(C.Structure):

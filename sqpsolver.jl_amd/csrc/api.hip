@@ -164,7 +164,7 @@ extern "C" void sqphip_default_options(sqphip_options *o)
     o->rho = 0.8; o->eta = 0.4; o->tau = 0.9; o->min_alpha = 1e-6;
     o->max_iter = 3000; o->use_soc = 0; o->literal_quirks = 1;
     o->ipm_tol = 1e-9; o->ipm_max_iter = 200; o->ipm_phase1 = 0; o->device = 0; o->ipm_corrector = 1; o->kkt_condense = 1; o->kkt_tile_order = 1;
-    o->kkt_mode = 0;
+    o->kkt_mode = 0; o->ipm_warm_start = 0;
 }
 
 extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num_linear, int64_t nnzJ,
@@ -327,7 +327,7 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
         d.ist = C.dalloc<IpmState>(B); d.sst = C.dalloc<SqpState>(B);
         d.phase = C.dalloc<int>(B); d.counters = C.dalloc<int>(64);
         d.trace = C.dalloc<double>((size_t)B * SQPHIP_TRACE_CAP * SQPHIP_TRACE_COLS);
-        d.ipm_tol = opt->ipm_tol; d.ipm_max_iter = opt->ipm_max_iter; d.ipm_phase1 = opt->ipm_phase1; d.ipm_corrector = opt->ipm_corrector;
+        d.ipm_tol = opt->ipm_tol; d.ipm_max_iter = opt->ipm_max_iter; d.ipm_phase1 = opt->ipm_phase1; d.ipm_corrector = opt->ipm_corrector; d.ipm_warm = opt->ipm_warm_start;
         d.refine_tol = getenv("SQPHIP_REFINE_TOL") ? atof(getenv("SQPHIP_REFINE_TOL")) : 1e-11;
         d.tol_direction = opt->tol_direction; d.tol_residual = opt->tol_residual;
         d.tol_infeas = opt->tol_infeas; d.init_mu = opt->init_mu; d.tr_size = opt->tr_size;

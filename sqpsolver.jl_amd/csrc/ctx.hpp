@@ -28,6 +28,7 @@ struct IpmState {
     int mpc, use_soc;              // predictor-corrector mode of this solve; second-order terms valid for the step
     double cavg;                   // average complementarity at the top of the iteration
     // outcome
+    int prev_mode;                 // 1 + mode of this instance's last solved sub-problem (options.ipm_warm_start), 0 none
     int status, ipm_iters, n_factor, n_solve;   // n_solve: forward + backward solves with the factors (incl. refinement)
     double elastic;
 };
@@ -106,7 +107,7 @@ struct DV {
     int *phase;
     int *counters;      // [0] instances iterating, [1] start flags, [2] SQP not done, [3] start flags
     double ipm_tol;
-    int ipm_max_iter, ipm_phase1, ipm_corrector;
+    int ipm_max_iter, ipm_phase1, ipm_corrector, ipm_warm;
     double refine_tol;                    // refinement step when the relative residual is above this (condensed form)
     // ---- SQP level
     double *x, *lambda, *mxL, *mxU, *df, *E, *pstep, *psoc, *plam, *pmxL, *pmxU, *Esoc, *tmpx, *tmpE,

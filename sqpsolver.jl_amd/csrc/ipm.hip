@@ -148,6 +148,10 @@ __global__ __launch_bounds__(TPB) void k_ipm_start(DV d)
     const double *xL = d.xL + on, *xU = d.xU + on, *gL = d.gL + om, *gU = d.gU + om;
     const bool use_obj = (mode == SQPHIP_MODE_QP || mode == SQPHIP_MODE_SOC || mode == SQPHIP_MODE_L1QP);
     const bool lp = mode == SQPHIP_MODE_LP;
+    // options.ipm_warm_start: the first run of a solve starts from the step and equality multipliers of the previous
+    // solved sub-problem of the same mode (still in p / y); restarts with a larger penalty, phase-1 runs start cold
+    const bool warm = d.ipm_warm && !lp && st.prev_mode == mode + 1 && st.stage == 0 && st.rho_big == RHO_BIG0;
+    const double ysc = warm ? 1.0 / st.sf : 0.0;        // previous objective scale (st.sf is overwritten below)
     // objective scale from the raw gradient
     double cm = 0.0;
     for (int j = threadIdx.x; j < d.n; j += TPB) {
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(TPB) void k_ipm_start(DV d)
     // interior start
     const double mu0 = 1.0;
     for (int j = threadIdx.x; j < d.n; j += TPB) {
-        const double pj = push_inside(lp ? xk[j] : 0.0, lb[j], ub[j]);
+        const double pj = push_inside(lp ? xk[j] : (warm ? p[j] : 0.0), lb[j], ub[j]);
         p[j] = pj;
         zl[j] = fin(lb[j]) ? mu0 / (pj - lb[j]) : 0.0;
         zu[j] = fin(ub[j]) ? mu0 / (ub[j] - pj) : 0.0;
@@ -218,6 +222,9 @@ __global__ __launch_bounds__(TPB) void k_ipm_start(DV d)
                 yi = vli - vui;
                 const double cap = 0.5 * fmin(wp[i], wm[i]);
                 if (fabs(yi) > cap) { const double sc = cap / fabs(yi); vli *= sc; vui *= sc; yi *= sc; }
+            } else if (warm) {       // equality row: the previous multiplier in this solve's objective scale, inside the penalty box
+                const double cap = 0.5 * fmin(wp[i], wm[i]);
+                yi = fmax(-cap, fmin(cap, y[i] * ysc * sf));
             }
             tpi = fmax(dd, 0.0) + mu0 / (wp[i] - yi);
             tmi = fmax(-dd, 0.0) + mu0 / (wm[i] + yi);
@@ -801,7 +808,7 @@ __global__ __launch_bounds__(TPB) void k_qp_finish(DV d)
         for (int j = threadIdx.x; j < d.n; j += TPB) { op[j] = 0.0; oL[j] = 0.0; oU[j] = 0.0; }
         for (int i = threadIdx.x; i < d.m; i += TPB) { olam[i] = 0.0; osl[i] = 0.0; osl[d.m + i] = 0.0; }
     }
-    if (threadIdx.x == 0) { st.status = status; d.phase[inst] = PH_IDLE; }
+    if (threadIdx.x == 0) { st.status = status; st.prev_mode = status == SQPHIP_MOI_LOCALLY_SOLVED ? st.mode + 1 : 0; d.phase[inst] = PH_IDLE; }
 }
 
 __global__ void k_count(DV d)

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(TPB) void k_sqp_reset(DV d)
         z.prim_infeas = INFINITY; z.dual_infeas = INFINITY;
         z.step_acceptance = 1; z.fr = 0; z.iter = 1; z.ret = -5;
         S = z;
-        I.start = 0; I.dw_last = 0.0;
+        I.start = 0; I.dw_last = 0.0; I.prev_mode = 0;
         d.phase[inst] = PH_IDLE;
     }
 }

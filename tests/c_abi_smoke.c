@@ -27,8 +27,8 @@ int main(int argc, char **argv)
     SYM(sqphip_default_options) SYM(sqphip_tr_update) SYM(sqphip_kkt_symbolic) SYM(sqphip_create) SYM(sqphip_qp_solve)
     SYM(sqphip_qp_stats) SYM(sqphip_destroy) SYM(sqphip_last_error) SYM(sqphip_get_counters) SYM(sqphip_gather_status)
 
-    /* struct layout: 10 doubles, 3 int32 (+ 4 bytes padding), 1 double, 7 int32 (+ padding to 8) */
-    CHECK(sizeof(sqphip_options) == 10 * 8 + 3 * 4 + 4 + 8 + 7 * 4 + 4);
+    /* struct layout: 10 doubles, 3 int32 (+ 4 bytes padding), 1 double, 8 int32 */
+    CHECK(sizeof(sqphip_options) == 10 * 8 + 3 * 4 + 4 + 8 + 8 * 4);
     CHECK(sizeof(sqphip_counters) == 26 * 8);                      /* 26 eight-byte fields */
     sqphip_options o;
     memset(&o, 0xff, sizeof o);
@@ -37,7 +37,7 @@ int main(int argc, char **argv)
     CHECK(o.init_mu == 1.0 && o.max_mu == 1e10 && o.tr_size == 10.0 && o.rho == 0.8 && o.eta == 0.4 && o.tau == 0.9);
     CHECK(o.min_alpha == 1e-6 && o.max_iter == 3000 && o.use_soc == 0 && o.literal_quirks == 1);
     CHECK(o.ipm_tol == 1e-9 && o.ipm_max_iter == 200 && o.ipm_phase1 == 0 && o.device == 0 && o.ipm_corrector == 1);
-    CHECK(o.kkt_condense == 1 && o.kkt_tile_order == 1 && o.kkt_mode == 0);
+    CHECK(o.kkt_condense == 1 && o.kkt_tile_order == 1 && o.kkt_mode == 0 && o.ipm_warm_start == 0);
 
     /* ratio test / radius update, sqp_trust_region.jl:529-538, :574-577 */
     int32_t acc; double dn;

@@ -1171,6 +1171,30 @@ def test_batched_run_is_reproducible_bit_for_bit():
         assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("quirks", [0, 1])
+def test_warm_started_subproblems_match_oracle(quirks):
+    """options.ipm_warm_start = 1 (what warm_start_init_point = "yes" asks of the reference's sub-solver,
+    /root/reference/test/ext_solver.jl:5): the first interior-point run of a sub-problem starts from the step and the
+    equality multipliers of the previous solved sub-problem of the same mode.  Same rule in the oracle: a batched run
+    to convergence takes the same decisions and reaches the same optimum; the cold start stays the default."""
+    nb, ng, nl, seed = CASES["case14"]
+    base = acopf_synth(nb, ng, nl, seed)
+    nets = [base, contingency(base, 2, seed), contingency(base, 5, seed)]
+    lays = [acopf_layout(nt) for nt in nets]
+    kw = dict(max_iter=40, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=quirks, ipm_warm_start=1)
+    ctx = _run_batch(nets, lays, kw)
+    for b in range(len(nets)):
+        ro = O.sqp_solve(O.problem_acopf(nets[b], lays[b]), O.default_options(**kw))
+        rg = ctx.sqp_get(b); tr = ctx.sqp_trace(b)
+        assert (rg["status"], rg["iter"]) == (ro["status"], ro["iter"]) and _same_decisions(ro, tr) and _ipm_counts_close(ro, tr)
+        tol = TOL if ro["status"] == 0 else TOL_TRAJ
+        assert rel(rg["x"], ro["x"]) < tol and abs(rg["obj_val"] - ro["obj_val"]) <= tol * abs(ro["obj_val"])
+        cold = O.sqp_solve(O.problem_acopf(nets[b], lays[b]), O.default_options(**dict(kw, ipm_warm_start=0)))
+        if ro["status"] == 0 and cold["status"] == 0:           # a different start, the same optimum
+            assert abs(ro["obj_val"] - cold["obj_val"]) <= 1e-7 * abs(cold["obj_val"])
+    ctx.close()
+
+
 def test_instance_groups_change_nothing_but_the_schedule():
     """sqphip_sqp_run splits a large batch into instance groups, each on its own HIP stream and host thread (the level
     launches of one group fill the chip while another's sit at the narrow top of the tree).  Instances never interact:
