@@ -36,7 +36,7 @@ sys.path.insert(0, _ROOT)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet fp64 matrix peak; MI355X_MICROARCH.md has no fp64 row.  The on-box
                                # register-resident MFMA probe (printed next to it) sustains 77.6 of it.
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~ 8 TB/s
-DEFAULT_BATCH = {"case14": 512, "case118": 512, "case1354": 32, "case9241": 4}
+DEFAULT_BATCH = {"case14": 512, "case118": 512, "case1354": 256, "case9241": 16}
 
 
 def host_cores():
@@ -283,7 +283,7 @@ def main():
         from concurrent.futures import ThreadPoolExecutor
         from oracle import oracle as O
         cores = host_cores()
-        n_s = min(total, {"case14": 512, "case118": 512, "case1354": 16, "case9241": 1}[args.workload])
+        n_s = min(total, {"case14": 512, "case118": 512, "case1354": 32, "case9241": 2}[args.workload])
         k_it = args.steps + args.warmup
         oo = O.default_options(max_iter=k_it, literal_quirks=args.literal_quirks, num_threads=1, kkt_mode=2,
                                ipm_corrector=args.ipm_corrector, **sqp_kw)
