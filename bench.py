@@ -52,6 +52,9 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="case118", choices=["case14", "case118", "case1354", "case9241"])
+    ap.add_argument("--formulation", default="polar", choices=["polar", "acr"],
+                    help="voltage coordinates of the ACOPF evaluator: polar (ACP, default) or rectangular (ACR, the one "
+                         "examples/acopf/opf.jl:46 runs)")
     ap.add_argument("--batch", type=int, default=None, help="instances of the whole job (default 512 for case118)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-termination", action="store_true", help="skip the run-to-termination legs")
@@ -97,7 +100,9 @@ def main():
     dev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")   # collective buffers
 
     import sqpsolver_jl_amd as pkg
-    from sqpsolver_jl_amd.acopf_synth import acopf_synth, acopf_layout, contingency, CASES
+    from sqpsolver_jl_amd.acopf_synth import acopf_synth, acopf_layout, acr_layout, contingency, CASES
+    if args.formulation == "acr":
+        acopf_layout = acr_layout
     from sqpsolver_jl_amd.shard import shard_range, gather_status
     from sqpsolver_jl_amd import _lib
 
@@ -169,6 +174,7 @@ def main():
     if args.warmup > 0:
         run_steps(args.warmup)
     c0 = ctx.counters()
+    m0 = ctx.mode_counters()
     ctx.set_timing(not args.no_kernel_timing)
     sync()
     t0 = time.perf_counter()
@@ -177,6 +183,14 @@ def main():
     t1 = time.perf_counter()
     ctx.set_timing(False)
     c1 = ctx.counters()
+    m1 = ctx.mode_counters()
+    # rank-local table of the timed steps by sub-problem mode (sub-problems, IPM iterations and factorisations per solve)
+    by_mode = {}
+    for k in m1:
+        q, i, f = (m1[k][j] - m0[k][j] for j in range(3))
+        if q > 0:
+            by_mode[k] = {"solved": int(q), "ipm_iterations_per_solve": i / q, "factorisations_per_solve": f / q,
+                          "share_of_factorisations": f / max(1, c1["n_factor"] - c0["n_factor"])}
 
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     stats = torch.tensor([c1["n_qp"] - c0["n_qp"], c1["n_ipm_iter"] - c0["n_ipm_iter"],
@@ -268,13 +282,16 @@ def main():
             torch.cuda.synchronize()
             tb = time.perf_counter()
             tc = tctx.counters()
+            tm = tctx.mode_counters()
             ret, it, done = tctx.sqp_status()
             termination[f"literal_quirks_{lq}"] = {
                 "seconds": tb - ta, "qp_solved": int(tc["n_qp"]), "qp_per_s": tc["n_qp"] / (tb - ta),
                 "instances_done": int(np.sum(done)), "converged_ret0": int(np.sum(ret == 0)),
                 "iteration_limit": int(np.sum(ret == -1)), "other": int(np.sum((ret != 0) & (ret != -1))),
                 "outer_iterations_median": float(np.median(it)), "ipm_iterations_per_qp": tc["n_ipm_iter"] / max(1, tc["n_qp"]),
-                "factorisations_per_qp": tc["n_factor"] / max(1, tc["n_qp"])}
+                "factorisations_per_qp": tc["n_factor"] / max(1, tc["n_qp"]),
+                "by_mode": {k: {"solved": int(v[0]), "ipm_iterations_per_solve": v[1] / v[0],
+                                "factorisations_per_solve": v[2] / v[0]} for k, v in tm.items() if v[0] > 0}}
             tctx.close()
 
     cpu = None
@@ -322,7 +339,7 @@ def main():
                                    + (", multifrontal LDL^T" if c1["sparse"] else ", dense MFMA LDL^T")
                                    + ", fp64, SQP-TR outer iterations",
                        "instances_total": total, "instances_per_gpu": B, "kkt_order": N, "kkt_order_full": N_full,
-                       "use_soc": use_soc, "sqp_options": args.sqp_options,
+                       "formulation": args.formulation, "use_soc": use_soc, "sqp_options": args.sqp_options,
                        "literal_quirks": args.literal_quirks, "ipm_corrector": args.ipm_corrector,
                        "kkt_mode": args.kkt_mode, "sparse_solver": int(c1["sparse"]), "kkt_condense": int(opts.kkt_condense),
                        "status_gather": "sqphip_gather_status (RCCL)" if use_lib_comm else
@@ -330,6 +347,7 @@ def main():
                        "qp_solved": n_qp, "ipm_iterations": n_ipm, "kkt_factorisations": n_fac,
                        "sweeps": int(c1["n_sweeps"] - c0["n_sweeps"]),
                        "ipm_iterations_per_qp": n_ipm / max(1.0, n_qp), "factorisations_per_qp": n_fac / max(1.0, n_qp),
+                       "by_mode": by_mode,
                        "instances_done_in_timed_steps": int(np.sum(g_done)),
                        "note": "with literal_quirks = 1 (the reference's JuMP-sign Hessian, SURVEY.md App. C #2) the "
                                "sub-problems are non-convex and most scenarios never meet the termination test; see "

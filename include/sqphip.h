@@ -229,6 +229,18 @@ int sqphip_acopf_attach(sqphip_ctx *ctx, int32_t nb, int32_t ng, int32_t nl,
                         const int32_t *f_bus, const int32_t *t_bus, const int32_t *gen_bus,
                         const int32_t *bal_ptr, const int32_t *bal_colP, const int32_t *bal_colQ,
                         const double *bal_coef, int32_t ref_bus);
+/* The same evaluator in rectangular voltage coordinates: PowerModels' ACRPowerModel under the build_opf of
+ * /root/reference/examples/acopf/opf.jl:12-43 -- the formulation run_sqp_opf instantiates (:46, :51).  Variables
+ * (vi, vr, pg, qg, flows, dc lines), rows vi[ref] = 0; power balance; vmin^2 <= vr^2 + vi^2 and vr^2 + vi^2 <= vmax^2 per
+ * bus (constraint_voltage_magnitude_bounds); thermal limits; Ohm's law with v_f v_t cos / sin written as
+ * vr_f vr_t + vi_f vi_t and vi_f vr_t - vr_f vi_t (same twelve coefficients per branch); dc-line losses; no
+ * angle-difference rows (opf.jl:33).  The context must have been created with the structure of
+ * sqpsolver.jl_amd/acopf_synth.py acr_layout; everything after the attach (set_shunts: four Jacobian and two Hessian
+ * entries per shunted bus, num_linear = 1; set_dclines; set_instance; eval; sqp_run) is shared with the polar form. */
+int sqphip_acopf_attach_acr(sqphip_ctx *ctx, int32_t nb, int32_t ng, int32_t nl,
+                            const int32_t *f_bus, const int32_t *t_bus, const int32_t *gen_bus,
+                            const int32_t *bal_ptr, const int32_t *bal_colP, const int32_t *bal_colQ,
+                            const double *bal_coef, int32_t ref_bus);
 /* Bus shunts (optional, after sqphip_acopf_attach): bus sh_bus[s] consumes gs[s] vm^2 of active and injects
  * bs[s] vm^2 of reactive power.  The context must have been created with the matching structure: two more Jacobian
  * COO entries (P row, Q row; column vm) and one more Hessian COO entry (vm, vm) per shunted bus at the END of the
@@ -307,6 +319,10 @@ typedef struct {
                               * n_sweeps and the kernel seconds are summed over the groups */
 } sqphip_counters;
 int sqphip_get_counters(sqphip_ctx *ctx, sqphip_counters *c);
+/* The work of the batched run since sqphip_sqp_reset, split by sub-problem mode: out[3 k + 0..2] = sub-problems solved,
+ * interior-point iterations, KKT factorisations of mode k = 0 QP (sub_optimize!, subproblem_JuMP.jl:127-183), 1 FR
+ * (:352-393), 2 SOC (sqp_trust_region.jl:341-360), 3 linear phase (:264-304).  12 values. */
+int sqphip_get_mode_counters(sqphip_ctx *ctx, int64_t *out12);
 int sqphip_reset_counters(sqphip_ctx *ctx);
 /* HIP-event timing of the factor / trailing-update / solve kernels (off by default) */
 int sqphip_set_timing(sqphip_ctx *ctx, int32_t enabled);

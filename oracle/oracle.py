@@ -102,10 +102,11 @@ def lib():
                                        C.POINTER(Result), C.POINTER(TraceRow), C.c_int]
         for nm in ("ora_problem_toy", "ora_problem_readme1", "ora_problem_hs071"):
             getattr(L, nm).restype = C.c_void_p
-        L.ora_problem_acopf.restype = C.c_void_p
-        L.ora_problem_acopf.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, dp, ip, dp, dp,
-                                        ip, ip, ip, dp, C.c_int64, lp, lp, C.c_int64, lp, lp,
-                                        dp, dp, dp, dp, C.c_int, ip, dp, dp, C.c_int, dp]
+        for ctor in (L.ora_problem_acopf, L.ora_problem_acopf_acr):
+            ctor.restype = C.c_void_p
+            ctor.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, dp, ip, dp, dp,
+                             ip, ip, ip, dp, C.c_int64, lp, lp, C.c_int64, lp, lp,
+                             dp, dp, dp, dp, C.c_int, ip, dp, dp, C.c_int, dp]
         L.ora_problem_nlp.restype = C.POINTER(Nlp)
         L.ora_problem_nlp.argtypes = [C.c_void_p]
         L.ora_problem_x0.restype = dp
@@ -247,7 +248,8 @@ def problem_acopf(net, lay):
     c2, c1, coef, xL, xU, gL, gU = args
     jr, jc, hr, hc = (np.ascontiguousarray(a, dtype=np.int64)
                       for a in (lay.jrow, lay.jcol, lay.hrow, lay.hcol))
-    h = lib().ora_problem_acopf(net.nb, net.ng, net.nl, _i(fb), _i(tb), _d(ohm),
+    ctor = lib().ora_problem_acopf_acr if getattr(lay, "form", "polar") == "acr" else lib().ora_problem_acopf
+    h = ctor(net.nb, net.ng, net.nl, _i(fb), _i(tb), _d(ohm),
                                 _i(gb), _d(c2), _d(c1), _i(bp), _i(bcp), _i(bcq), _d(coef),
                                 len(jr), _l(jr), _l(jc), len(hr), _l(hr), _l(hc),
                                 _d(xL), _d(xU), _d(gL), _d(gU), len(lay.sh_bus),

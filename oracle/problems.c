@@ -301,3 +301,145 @@ ora_problem *ora_problem_acopf(int nb, int ng, int nl, const int32_t *f_bus,
     P->nlp.eval_jac_g = ac_jac; P->nlp.eval_h = ac_h;
     return P;
 }
+
+/* ------------------------------------------------------------------ ACOPF (rectangular, ACR shape) */
+/* PowerModels ACRPowerModel under the build_opf of /root/reference/examples/acopf/opf.jl:12-43 (what run_sqp_opf
+ * instantiates, :46,:51), laid out by sqpsolver.jl_amd/acopf_synth.py, acr_layout: x = (vi, vr, pg, qg, flows, dc),
+ * rows = vi[ref]; balance; vmin^2 <= vr^2+vi^2 and vr^2+vi^2 <= vmax^2 per bus; thermal; Ohm; dc losses.
+ * F_k = A (vr_s^2 + vi_s^2) + Bc (vr_f vr_t + vi_f vi_t) + Bs (vi_f vr_t - vr_f vi_t): every row is quadratic. */
+#define RIDX(P) \
+    const int nb = (P)->nb, ng = (P)->ng, nl = (P)->nl; \
+    const int VI = 0, VR = nb, PG = 2 * nb, PF = 2 * nb + 2 * ng; \
+    const int PT = PF + nl, QF = PF + 2 * nl, QT = PF + 3 * nl; \
+    const int V0 = 1 + 2 * nb, T0 = V0 + 2 * nb, O0 = T0 + 2 * nl; \
+    (void)VI; (void)VR; (void)PG; (void)PT; (void)QF; (void)QT; (void)V0; (void)T0; (void)O0; (void)ng;
+
+static void acr_g(void *u, const double *x, double *gv)
+{
+    const ora_problem *P = (const ora_problem *)u; RIDX(P)
+    const int own[4] = { PF, QF, PT, QT };
+    gv[0] = x[VI + P->ref_bus];
+    for (int i = 0; i < nb; ++i) {
+        double sp = 0.0, sq = 0.0;
+        for (int k = P->bal_ptr[i]; k < P->bal_ptr[i + 1]; ++k) {
+            sp += P->bal_coef[k] * x[P->bal_colP[k]];
+            sq += P->bal_coef[k] * x[P->bal_colQ[k]];
+        }
+        gv[1 + 2 * i] = sp; gv[2 + 2 * i] = sq;
+        double w = x[VR + i] * x[VR + i] + x[VI + i] * x[VI + i];
+        gv[V0 + 2 * i] = w; gv[V0 + 2 * i + 1] = w;
+    }
+    for (int s = 0; s < P->nsh; ++s) {
+        int i = P->sh_bus[s]; double w = x[VR + i] * x[VR + i] + x[VI + i] * x[VI + i];
+        gv[1 + 2 * i] += P->sh_gs[s] * w; gv[2 + 2 * i] -= P->sh_bs[s] * w;
+    }
+    for (int l = 0; l < nl; ++l) {
+        gv[T0 + 2 * l] = x[PF + l] * x[PF + l] + x[QF + l] * x[QF + l];
+        gv[T0 + 2 * l + 1] = x[PT + l] * x[PT + l] + x[QT + l] * x[QT + l];
+        const int fb = P->f_bus[l], tb = P->t_bus[l];
+        double vrf = x[VR + fb], vif = x[VI + fb], vrt = x[VR + tb], vit = x[VI + tb];
+        double cc = vrf * vrt + vif * vit, ss = vif * vrt - vrf * vit;
+        for (int k = 0; k < 4; ++k) {
+            double A, Bc, Bs; int st; ohm_coef(P, l, k, &A, &Bc, &Bs, &st);
+            double w = st ? vrt * vrt + vit * vit : vrf * vrf + vif * vif;
+            gv[O0 + 4 * l + k] = x[own[k] + l] - (A * w + Bc * cc + Bs * ss);
+        }
+    }
+    for (int d = 0; d < P->ndc; ++d)
+        gv[O0 + 4 * nl + d] = (1.0 - P->dc_loss1[d]) * x[PF + 4 * nl + d] + x[PF + 4 * nl + P->ndc + d];
+}
+static void acr_jac(void *u, const double *x, double *v)
+{
+    const ora_problem *P = (const ora_problem *)u; RIDX(P)
+    int64_t o = 0;
+    v[o++] = 1.0;
+    for (int i = 0; i < nb; ++i) {
+        int s = P->bal_ptr[i], e = P->bal_ptr[i + 1];
+        for (int k = s; k < e; ++k) v[o++] = P->bal_coef[k];
+        for (int k = s; k < e; ++k) v[o++] = P->bal_coef[k];
+    }
+    for (int i = 0; i < nb; ++i) { v[o++] = 2 * x[VR + i]; v[o++] = 2 * x[VI + i]; }
+    for (int i = 0; i < nb; ++i) { v[o++] = 2 * x[VR + i]; v[o++] = 2 * x[VI + i]; }
+    for (int l = 0; l < nl; ++l) { v[o++] = 2 * x[PF + l]; v[o++] = 2 * x[QF + l]; }
+    for (int l = 0; l < nl; ++l) { v[o++] = 2 * x[PT + l]; v[o++] = 2 * x[QT + l]; }
+    for (int k = 0; k < 4; ++k)
+        for (int l = 0; l < nl; ++l) {
+            const int fb = P->f_bus[l], tb = P->t_bus[l];
+            double vrf = x[VR + fb], vif = x[VI + fb], vrt = x[VR + tb], vit = x[VI + tb];
+            double A, Bc, Bs; int st; ohm_coef(P, l, k, &A, &Bc, &Bs, &st);
+            v[o++] = 1.0;
+            v[o++] = -((st ? 0.0 : 2 * A * vif) + Bc * vit + Bs * vrt);      /* d/d vi_f */
+            v[o++] = -((st ? 2 * A * vit : 0.0) + Bc * vif - Bs * vrf);      /* d/d vi_t */
+            v[o++] = -((st ? 0.0 : 2 * A * vrf) + Bc * vrt - Bs * vit);      /* d/d vr_f */
+            v[o++] = -((st ? 2 * A * vrt : 0.0) + Bc * vrf + Bs * vif);      /* d/d vr_t */
+        }
+    for (int s = 0; s < P->nsh; ++s) {
+        int i = P->sh_bus[s];
+        v[o++] = 2 * P->sh_gs[s] * x[VR + i]; v[o++] = 2 * P->sh_gs[s] * x[VI + i];
+        v[o++] = -2 * P->sh_bs[s] * x[VR + i]; v[o++] = -2 * P->sh_bs[s] * x[VI + i];
+    }
+    for (int d = 0; d < P->ndc; ++d) { v[o++] = 1.0 - P->dc_loss1[d]; v[o++] = 1.0; }
+}
+static void acr_h(void *u, const double *x, double sig, const double *lam, double *v)
+{
+    const ora_problem *P = (const ora_problem *)u; RIDX(P)
+    (void)x;
+    int64_t o = 0;
+    for (int g = 0; g < ng; ++g) v[o++] = sig * 2 * P->c2[g];
+    for (int l = 0; l < nl; ++l) { double w = 2 * lam[T0 + 2 * l]; v[o++] = w; v[o++] = w; }
+    for (int l = 0; l < nl; ++l) { double w = 2 * lam[T0 + 2 * l + 1]; v[o++] = w; v[o++] = w; }
+    for (int i = 0; i < nb; ++i) {
+        double wl = 2 * lam[V0 + 2 * i], wu = 2 * lam[V0 + 2 * i + 1];
+        v[o++] = wl; v[o++] = wl; v[o++] = wu; v[o++] = wu;
+    }
+    for (int k = 0; k < 4; ++k) {
+        double *blk = v + o + (int64_t)k * 6 * nl;
+        for (int l = 0; l < nl; ++l) {
+            double A, Bc, Bs; int st; ohm_coef(P, l, k, &A, &Bc, &Bs, &st);
+            double w = -lam[O0 + 4 * l + k];
+            blk[0 * nl + l] = w * 2 * A;      /* vi_s vi_s */
+            blk[1 * nl + l] = w * 2 * A;      /* vr_s vr_s */
+            blk[2 * nl + l] = w * Bc;         /* vi_f vi_t */
+            blk[3 * nl + l] = w * Bc;         /* vr_f vr_t */
+            blk[4 * nl + l] = w * Bs;         /* vr_t vi_f */
+            blk[5 * nl + l] = -w * Bs;        /* vr_f vi_t */
+        }
+    }
+    o += (int64_t)24 * nl;
+    for (int s = 0; s < P->nsh; ++s) {
+        int i = P->sh_bus[s];
+        double w = lam[1 + 2 * i] * 2 * P->sh_gs[s] - lam[2 + 2 * i] * 2 * P->sh_bs[s];
+        v[o++] = w; v[o++] = w;
+    }
+}
+
+ora_problem *ora_problem_acopf_acr(int nb, int ng, int nl, const int32_t *f_bus,
+                                   const int32_t *t_bus, const double *ohm,
+                                   const int32_t *gen_bus, const double *c2,
+                                   const double *c1, const int32_t *bal_ptr, const int32_t *bal_colP,
+                                   const int32_t *bal_colQ, const double *bal_coef,
+                                   int64_t nnzj, const int64_t *jrow, const int64_t *jcol,
+                                   int64_t nnzh, const int64_t *hrow, const int64_t *hcol,
+                                   const double *xL, const double *xU, const double *gL,
+                                   const double *gU, int nsh, const int32_t *sh_bus, const double *sh_gs,
+                                   const double *sh_bs, int ndc, const double *dc_loss1)
+{
+    int64_t n = 2 * nb + 2 * ng + 4 * nl + 4 * ndc, m = 1 + 4 * nb + 6 * nl + ndc;
+    double *x0 = (double *)calloc((size_t)n, sizeof(double));
+    ora_problem *P = mk(n, m, nsh > 0 ? 1 : 1 + 2 * nb, nnzj, jrow, jcol, nnzh, hrow, hcol, xL, xU, gL, gU, x0);
+    free(x0);
+    P->nb = nb; P->ng = ng; P->nl = nl;
+    P->ref_bus = (int)(jcol[0] - 1);
+    P->f_bus = i32dup(f_bus, nl); P->t_bus = i32dup(t_bus, nl); P->gen_bus = i32dup(gen_bus, ng);
+    P->bal_ptr = i32dup(bal_ptr, nb + 1);
+    int64_t nbal = bal_ptr[nb];
+    P->bal_colP = i32dup(bal_colP, nbal); P->bal_colQ = i32dup(bal_colQ, nbal);
+    P->bal_coef = ddup(bal_coef, nbal);
+    P->ohm = ddup(ohm, 12 * (int64_t)nl);
+    P->ndc = ndc; P->dc_loss1 = ddup(dc_loss1, ndc);
+    P->nsh = nsh; P->sh_bus = i32dup(sh_bus, nsh); P->sh_gs = ddup(sh_gs, nsh); P->sh_bs = ddup(sh_bs, nsh);
+    P->c2 = ddup(c2, ng); P->c1 = ddup(c1, ng);
+    P->nlp.eval_f = ac_f; P->nlp.eval_grad_f = ac_df; P->nlp.eval_g = acr_g;
+    P->nlp.eval_jac_g = acr_jac; P->nlp.eval_h = acr_h;
+    return P;
+}

@@ -28,7 +28,7 @@ from __future__ import annotations
 import dataclasses
 import numpy as np
 
-__all__ = ["Network", "acopf_synth", "contingency", "renumber_buses", "NlpLayout", "acopf_layout",
+__all__ = ["Network", "acopf_synth", "contingency", "renumber_buses", "NlpLayout", "acopf_layout", "acr_layout",
            "CASES"]
 
 # nb, ng, nl per SURVEY.md section 8 table
@@ -290,6 +290,7 @@ class NlpLayout:
     sh_gs: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(0))
     sh_bs: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(0))
     dc_loss1: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(0))   # per dc line (empty: none)
+    form: str = "polar"   # "polar" (ACPPowerModel, acopf_layout) or "acr" (ACRPowerModel, acr_layout)
 
 
 def acopf_layout(net: Network) -> NlpLayout:
@@ -418,3 +419,131 @@ def acopf_layout(net: Network) -> NlpLayout:
                      bal_colQ=colQ.astype(np.int32), bal_coef=np.asarray(coef),
                      sh_bus=sh_bus, sh_gs=sh_gs, sh_bs=sh_bs,
                      dc_loss1=(np.zeros(0) if ndc == 0 else np.asarray(net.dcline["loss1"], dtype=np.float64)))
+
+
+def acr_layout(net: Network) -> NlpLayout:
+    """The same network in rectangular voltage coordinates: PowerModels' ACRPowerModel under the `build_opf` of
+    /root/reference/examples/acopf/opf.jl:12-43 (the formulation `run_sqp_opf` instantiates, :46,:51).
+
+    variables  vi[nb] (where the polar layout has va), vr[nb] (where it has vm), pg, qg, p_f, p_t, q_f, q_t, dc lines;
+               vr, vi in [-vmax, vmax] (variable_bus_voltage_real / _imaginary, bounded), start vr = 1, vi = 0
+    rows       0                vi[ref] = 0                                  (constraint_theta_ref, ACR form)
+               1 .. 2 nb        power balance, P then Q per bus              (linear without bus shunts)
+               V0 + 2 i, +1     vmin_i^2 <= vr_i^2 + vi_i^2,  vr_i^2 + vi_i^2 <= vmax_i^2
+                                                                             (constraint_voltage_magnitude_bounds: two rows)
+               T0 + 2 l, +1     p^2 + q^2 <= rate^2, from and to end         (constraint_thermal_limit_from / _to)
+               O0 + 4 l + k     flow_k - F_k = 0, F_k = A (vr_s^2 + vi_s^2) + Bc (vr_f vr_t + vi_f vi_t)
+                                                        + Bs (vi_f vr_t - vr_f vi_t)
+                                (constraint_ohms_yt_from / _to: the polar form with v_f v_t cos th and v_f v_t sin th written
+                                out; same twelve coefficients per branch, Network.branch_coeffs)
+               D0 + d           dc-line loss rows
+    The angle-difference rows are not part of this build (opf.jl:33 has them commented out)."""
+    nb, ng, nl, ndc = net.nb, net.ng, net.nl, net.ndc
+    n = 2 * nb + 2 * ng + 4 * nl + 4 * ndc
+    m = 1 + 4 * nb + 6 * nl + ndc
+    VI, VR, PG, QG = 0, nb, 2 * nb, 2 * nb + ng
+    PF = 2 * nb + 2 * ng
+    PT, QF, QT = PF + nl, PF + 2 * nl, PF + 3 * nl
+    DC = PF + 4 * nl
+    V0 = 1 + 2 * nb
+    T0 = V0 + 2 * nb
+    O0 = T0 + 2 * nl
+    D0 = O0 + 4 * nl
+    f, t = net.f_bus.astype(np.int64), net.t_bus.astype(np.int64)
+    L = np.arange(nl, dtype=np.int64)
+    I = np.arange(nb, dtype=np.int64)
+
+    jr, jc = [np.array([0])], [np.array([VI + net.ref_bus])]
+    inc = [[] for _ in range(nb)]
+    for l in range(nl):
+        inc[int(f[l])].append((PF + l, QF + l, 1.0))
+        inc[int(t[l])].append((PT + l, QT + l, 1.0))
+    for g in range(ng):
+        inc[int(net.gen_bus[g])].append((PG + g, QG + g, -1.0))
+    for d in range(ndc):
+        inc[int(net.dcline["f_bus"][d])].append((DC + d, DC + 2 * ndc + d, 1.0))
+        inc[int(net.dcline["t_bus"][d])].append((DC + ndc + d, DC + 3 * ndc + d, 1.0))
+    bal_ptr = np.zeros(nb + 1, dtype=np.int32)
+    colP, colQ, coef = [], [], []
+    for i in range(nb):
+        bal_ptr[i + 1] = bal_ptr[i] + len(inc[i])
+        for cp, cq, cf in inc[i]:
+            colP.append(cp); colQ.append(cq); coef.append(cf)
+    colP = np.asarray(colP, dtype=np.int64)
+    colQ = np.asarray(colQ, dtype=np.int64)
+    for i in range(nb):
+        s, e = bal_ptr[i], bal_ptr[i + 1]
+        jr.append(np.full(e - s, 1 + 2 * i)); jc.append(colP[s:e])
+        jr.append(np.full(e - s, 2 + 2 * i)); jc.append(colQ[s:e])
+    # voltage-magnitude rows: (vr_i, vi_i) for the lower row, then for the upper row
+    jr.append(np.repeat(V0 + 2 * I, 2)); jc.append(np.stack([VR + I, VI + I], 1).ravel())
+    jr.append(np.repeat(V0 + 2 * I + 1, 2)); jc.append(np.stack([VR + I, VI + I], 1).ravel())
+    jr.append(np.repeat(T0 + 2 * L, 2)); jc.append(np.stack([PF + L, QF + L], 1).ravel())
+    jr.append(np.repeat(T0 + 2 * L + 1, 2)); jc.append(np.stack([PT + L, QT + L], 1).ravel())
+    own = [PF, QF, PT, QT]
+    for k in range(4):
+        jr.append(np.repeat(O0 + 4 * L + k, 5))
+        jc.append(np.stack([own[k] + L, VI + f, VI + t, VR + f, VR + t], 1).ravel())
+    sh_bus, sh_gs, sh_bs = net.shunts()
+    if len(sh_bus):                            # gs (vr^2 + vi^2) in the P row, -bs (vr^2 + vi^2) in the Q row
+        sb = sh_bus.astype(np.int64)
+        jr.append(np.stack([1 + 2 * sb, 1 + 2 * sb, 2 + 2 * sb, 2 + 2 * sb], 1).ravel())
+        jc.append(np.stack([VR + sb, VI + sb, VR + sb, VI + sb], 1).ravel())
+    if ndc:
+        D = np.arange(ndc, dtype=np.int64)
+        jr.append(np.repeat(D0 + D, 2)); jc.append(np.stack([DC + D, DC + ndc + D], 1).ravel())
+    jrow = np.concatenate(jr).astype(np.int64) + 1
+    jcol = np.concatenate(jc).astype(np.int64) + 1
+
+    # Hessian COO, lower triangle (vr sits behind vi, so a (vr, vi) pair is (row, col)): every entry is a constant
+    # times a multiplier -- the rows are quadratic
+    hr, hc = [], []
+    G = np.arange(ng, dtype=np.int64)
+    hr.append(PG + G); hc.append(PG + G)
+    for base_p, base_q in ((PF, QF), (PT, QT)):
+        hr.append(np.stack([base_p + L, base_q + L], 1).ravel()); hc.append(np.stack([base_p + L, base_q + L], 1).ravel())
+    hr.append(np.stack([VR + I, VI + I, VR + I, VI + I], 1).ravel()); hc.append(np.stack([VR + I, VI + I, VR + I, VI + I], 1).ravel())
+    for k in range(4):
+        s_ = f if k < 2 else t
+        ents = [(VI + s_, VI + s_), (VR + s_, VR + s_),
+                (np.maximum(VI + f, VI + t), np.minimum(VI + f, VI + t)),
+                (np.maximum(VR + f, VR + t), np.minimum(VR + f, VR + t)),
+                (VR + t, VI + f), (VR + f, VI + t)]
+        for a, b in ents:                      # entry-major inside the block of row kind k, like the polar layout
+            hr.append(a); hc.append(b)
+    if len(sh_bus):
+        sb = sh_bus.astype(np.int64)
+        hr.append(np.stack([VR + sb, VI + sb], 1).ravel()); hc.append(np.stack([VR + sb, VI + sb], 1).ravel())
+    hrow = np.concatenate(hr).astype(np.int64) + 1
+    hcol = np.concatenate(hc).astype(np.int64) + 1
+
+    inf = np.inf
+    xL = np.concatenate([-net.vmax, -net.vmax, net.pmin, net.qmin, -net.rate_a, -net.rate_a, -net.rate_a, -net.rate_a])
+    xU = np.concatenate([net.vmax, net.vmax, net.pmax, net.qmax, net.rate_a, net.rate_a, net.rate_a, net.rate_a])
+    if ndc:
+        dc = net.dcline
+        a = dc["loss0"] - (1.0 - dc["loss1"]) * dc["pmaxf"]; b = dc["loss0"] - (1.0 - dc["loss1"]) * dc["pminf"]
+        xL = np.concatenate([xL, dc["pminf"], np.minimum(a, b), dc["qminf"], dc["qmint"]])
+        xU = np.concatenate([xU, dc["pmaxf"], np.maximum(a, b), dc["qmaxf"], dc["qmaxt"]])
+    gL = np.empty(m); gU = np.empty(m)
+    gL[0] = gU[0] = 0.0
+    gL[1:V0:2] = -net.pd; gU[1:V0:2] = -net.pd
+    gL[2:V0:2] = -net.qd; gU[2:V0:2] = -net.qd
+    gL[V0:T0:2] = net.vmin ** 2; gU[V0:T0:2] = inf
+    gL[V0 + 1:T0:2] = -inf; gU[V0 + 1:T0:2] = net.vmax ** 2
+    gL[T0:O0] = -inf
+    gU[T0:O0:2] = net.rate_a ** 2; gU[T0 + 1:O0:2] = net.rate_a ** 2
+    gL[O0:D0] = 0.0; gU[O0:D0] = 0.0
+    if ndc:
+        gL[D0:] = net.dcline["loss0"]; gU[D0:] = net.dcline["loss0"]
+    boxed = np.isfinite(xL) & np.isfinite(xU)
+    x0 = np.zeros(n)
+    x0[boxed] = 0.5 * (xL[boxed] + xU[boxed])
+    x0[VI:VI + nb] = 0.0
+    x0[VR:VR + nb] = 1.0
+    return NlpLayout(n=n, m=m, num_linear=V0 if len(sh_bus) == 0 else 1,
+                     jrow=jrow, jcol=jcol, hrow=hrow, hcol=hcol, xL=xL, xU=xU, gL=gL, gU=gU, x0=x0,
+                     bal_ptr=bal_ptr, bal_colP=colP.astype(np.int32), bal_colQ=colQ.astype(np.int32),
+                     bal_coef=np.asarray(coef), sh_bus=sh_bus, sh_gs=sh_gs, sh_bs=sh_bs,
+                     dc_loss1=(np.zeros(0) if ndc == 0 else np.asarray(net.dcline["loss1"], dtype=np.float64)),
+                     form="acr")

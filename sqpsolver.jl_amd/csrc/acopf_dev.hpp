@@ -14,11 +14,142 @@ static __device__ __forceinline__ Ohm ohm_coef(const double *__restrict__ oc, in
     return {oc[3 * k], oc[3 * k + 1], oc[3 * k + 2], k >= 2};
 }
 
+// Rectangular voltage coordinates (PowerModels ACRPowerModel under the build_opf of
+// /root/reference/examples/acopf/opf.jl:12-43, the formulation run_sqp_opf instantiates at :46,:51), laid out by
+// sqpsolver.jl_amd/acopf_synth.py acr_layout: x = (vi, vr, pg, qg, flows, dc lines); rows = vi[ref]; balance;
+// vmin^2 <= vr^2 + vi^2 and vr^2 + vi^2 <= vmax^2 per bus; thermal limits; Ohm's law; dc-line losses.
+//   F_k = A (vr_s^2 + vi_s^2) + Bc (vr_f vr_t + vi_f vi_t) + Bs (vi_f vr_t - vr_f vi_t)
+// (the polar F_k with v_f v_t cos th and v_f v_t sin th written out, same twelve coefficients per branch): every row is
+// quadratic, no trigonometry, the Hessian entries are multipliers times constants.
+static __device__ void acr_eval(const DV &d, int inst, const double *__restrict__ x, double sigma,
+                         const double *__restrict__ lam, double *f_out, double *grad, double *gv,
+                         double *jv, double *hv)
+{
+    const int nb = d.nb, ng = d.ng, nl = d.nl;
+    const int VI = 0, VR = nb, PG = 2 * nb, PF = 2 * nb + 2 * ng;
+    const int PT = PF + nl, QF = PF + 2 * nl, QT = PF + 3 * nl, DCV = PF + 4 * nl;
+    const int V0 = 1 + 2 * nb, T0 = V0 + 2 * nb, O0 = T0 + 2 * nl, D0 = O0 + 4 * nl;
+    const int nbal = d.bal_ptr[nb];
+    const int JV = 1 + 2 * nbal, JT = JV + 4 * nb, JO = JT + 4 * nl, JS = JO + 20 * nl, JD = JS + 4 * d.nsh;
+    const int HT = ng, HV = ng + 4 * nl, HO = HV + 4 * nb, HS = HO + 24 * nl;
+    const double *ohm = d.br_ohm + (long)inst * nl * 12;
+    const double *c2 = d.c2 + (long)inst * ng, *c1 = d.c1 + (long)inst * ng;
+    if (f_out) {
+        double f = 0.0;
+        for (int g = threadIdx.x; g < ng; g += TPB) f += c2[g] * x[PG + g] * x[PG + g] + c1[g] * x[PG + g];
+        f = block_reduce<OpSum>(f);
+        if (threadIdx.x == 0) *f_out = f;
+    }
+    if (grad) {
+        for (int j = threadIdx.x; j < d.n; j += TPB) grad[j] = 0.0;
+        __syncthreads();
+        for (int g = threadIdx.x; g < ng; g += TPB) grad[PG + g] = 2 * c2[g] * x[PG + g] + c1[g];
+    }
+    if (hv) {
+        for (int g = threadIdx.x; g < ng; g += TPB) hv[g] = sigma * 2 * c2[g];
+    }
+    if (threadIdx.x == 0) {
+        if (gv) gv[0] = x[VI + d.ref_bus];
+        if (jv) jv[0] = 1.0;
+    }
+    // bus rows: balance (+ shunt), voltage magnitude
+    for (int i = threadIdx.x; i < nb; i += TPB) {
+        const double vr = x[VR + i], vi = x[VI + i], w2 = vr * vr + vi * vi;
+        const int s = d.bal_ptr[i], e = d.bal_ptr[i + 1];
+        if (gv) {
+            double sp = 0.0, sq = 0.0;
+            for (int k = s; k < e; ++k) {
+                sp += d.bal_coef[k] * x[d.bal_colP[k]];
+                sq += d.bal_coef[k] * x[d.bal_colQ[k]];
+            }
+            if (d.nsh > 0 && d.sh_of_bus[i] >= 0) {
+                const int sh = d.sh_of_bus[i];
+                sp += d.sh_gs[sh] * w2; sq -= d.sh_bs[sh] * w2;
+            }
+            gv[1 + 2 * i] = sp; gv[2 + 2 * i] = sq;
+            gv[V0 + 2 * i] = w2; gv[V0 + 2 * i + 1] = w2;
+        }
+        if (jv) {
+            double *dst = jv + 1 + 2 * s;
+            for (int k = s; k < e; ++k) { dst[k - s] = d.bal_coef[k]; dst[(e - s) + (k - s)] = d.bal_coef[k]; }
+            jv[JV + 2 * i] = 2 * vr; jv[JV + 2 * i + 1] = 2 * vi;
+            jv[JV + 2 * nb + 2 * i] = 2 * vr; jv[JV + 2 * nb + 2 * i + 1] = 2 * vi;
+        }
+        if (hv) {
+            const double wl = 2 * lam[V0 + 2 * i], wu = 2 * lam[V0 + 2 * i + 1];
+            hv[HV + 4 * i] = wl; hv[HV + 4 * i + 1] = wl; hv[HV + 4 * i + 2] = wu; hv[HV + 4 * i + 3] = wu;
+        }
+    }
+    for (int sh = threadIdx.x; sh < d.nsh; sh += TPB) {
+        const int i = d.sh_bus[sh];
+        if (jv) {
+            jv[JS + 4 * sh] = 2 * d.sh_gs[sh] * x[VR + i]; jv[JS + 4 * sh + 1] = 2 * d.sh_gs[sh] * x[VI + i];
+            jv[JS + 4 * sh + 2] = -2 * d.sh_bs[sh] * x[VR + i]; jv[JS + 4 * sh + 3] = -2 * d.sh_bs[sh] * x[VI + i];
+        }
+        if (hv) {
+            const double w = lam[1 + 2 * i] * 2 * d.sh_gs[sh] - lam[2 + 2 * i] * 2 * d.sh_bs[sh];
+            hv[HS + 2 * sh] = w; hv[HS + 2 * sh + 1] = w;
+        }
+    }
+    for (int dl = threadIdx.x; dl < d.ndc; dl += TPB) {
+        if (gv) gv[D0 + dl] = (1.0 - d.dc_loss1[dl]) * x[DCV + dl] + x[DCV + d.ndc + dl];
+        if (jv) { jv[JD + 2 * dl] = 1.0 - d.dc_loss1[dl]; jv[JD + 2 * dl + 1] = 1.0; }
+    }
+    // branch rows
+    for (int l = threadIdx.x; l < nl; l += TPB) {
+        const int fb = d.f_bus[l], tb = d.t_bus[l];
+        const double vrf = x[VR + fb], vif = x[VI + fb], vrt = x[VR + tb], vit = x[VI + tb];
+        const double pf = x[PF + l], qf = x[QF + l], pt = x[PT + l], qt = x[QT + l];
+        const double cc = vrf * vrt + vif * vit, ss = vif * vrt - vrf * vit;
+        if (gv) {
+            gv[T0 + 2 * l] = pf * pf + qf * qf;
+            gv[T0 + 2 * l + 1] = pt * pt + qt * qt;
+        }
+        if (jv) {
+            jv[JT + 2 * l] = 2 * pf; jv[JT + 2 * l + 1] = 2 * qf;
+            jv[JT + 2 * nl + 2 * l] = 2 * pt; jv[JT + 2 * nl + 2 * l + 1] = 2 * qt;
+        }
+        if (hv) {
+            const double wf = 2 * lam[T0 + 2 * l], wt = 2 * lam[T0 + 2 * l + 1];
+            hv[HT + 2 * l] = wf; hv[HT + 2 * l + 1] = wf;
+            hv[HT + 2 * nl + 2 * l] = wt; hv[HT + 2 * nl + 2 * l + 1] = wt;
+        }
+        const double own[4] = {pf, qf, pt, qt};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const Ohm o = ohm_coef(ohm + 12 * l, k);
+            if (gv) {
+                const double w2 = o.self_t ? vrt * vrt + vit * vit : vrf * vrf + vif * vif;
+                gv[O0 + 4 * l + k] = own[k] - (o.A * w2 + o.Bc * cc + o.Bs * ss);
+            }
+            if (jv) {
+                double *e = jv + JO + (long)k * 5 * nl + 5 * l;
+                e[0] = 1.0;
+                e[1] = -((o.self_t ? 0.0 : 2 * o.A * vif) + o.Bc * vit + o.Bs * vrt);
+                e[2] = -((o.self_t ? 2 * o.A * vit : 0.0) + o.Bc * vif - o.Bs * vrf);
+                e[3] = -((o.self_t ? 0.0 : 2 * o.A * vrf) + o.Bc * vrt - o.Bs * vit);
+                e[4] = -((o.self_t ? 2 * o.A * vrt : 0.0) + o.Bc * vrf + o.Bs * vif);
+            }
+            if (hv) {
+                double *blk = hv + HO + (long)k * 6 * nl;
+                const double w = -lam[O0 + 4 * l + k];
+                blk[0 * nl + l] = w * 2 * o.A;
+                blk[1 * nl + l] = w * 2 * o.A;
+                blk[2 * nl + l] = w * o.Bc;
+                blk[3 * nl + l] = w * o.Bc;
+                blk[4 * nl + l] = w * o.Bs;
+                blk[5 * nl + l] = -w * o.Bs;
+            }
+        }
+    }
+}
+
 // any of f_out, grad, gv, jv, hv may be null
 static __device__ void acopf_eval(const DV &d, int inst, const double *__restrict__ x, double sigma,
                            const double *__restrict__ lam, double *f_out, double *grad, double *gv,
                            double *jv, double *hv)
 {
+    if (d.acr) { acr_eval(d, inst, x, sigma, lam, f_out, grad, gv, jv, hv); return; }   // uniform over the launch
     const int nb = d.nb, ng = d.ng, nl = d.nl;
     const int VA = 0, VM = nb, PG = 2 * nb, QG = 2 * nb + ng, PF = 2 * nb + 2 * ng;
     const int PT = PF + nl, QF = PF + 2 * nl, QT = PF + 3 * nl;

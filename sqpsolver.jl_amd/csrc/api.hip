@@ -664,23 +664,32 @@ extern "C" int sqphip_compute_mu_rule(int32_t rule, int64_t iter, double rho, do
 }
 
 // ---- ACOPF evaluator + batched SQP -----------------------------------------------------------------
-extern "C" int sqphip_acopf_attach(sqphip_ctx *h, int32_t nb, int32_t ng, int32_t nl, const int32_t *f_bus,
-                                   const int32_t *t_bus, const int32_t *gen_bus, const int32_t *bal_ptr,
-                                   const int32_t *bal_colP, const int32_t *bal_colQ, const double *bal_coef,
-                                   int32_t ref_bus)
+// structure counts of the two layouts (acopf_synth.py acopf_layout / acr_layout) without shunts
+static int acopf_nnzj(int acr, int nb, int ng, int nl, int ndc)
+{
+    const int nbal = 2 * nl + ng + 2 * ndc;
+    return acr ? 1 + 2 * nbal + 4 * nb + 24 * nl + 2 * ndc : 32 * nl + 2 * ng + 1 + 6 * ndc;
+}
+static int acopf_nnzh(int acr, int nb, int ng, int nl) { return acr ? ng + 28 * nl + 4 * nb : ng + 44 * nl; }
+
+static int acopf_attach_impl(sqphip_ctx *h, int acr, int32_t nb, int32_t ng, int32_t nl, const int32_t *f_bus,
+                             const int32_t *t_bus, const int32_t *gen_bus, const int32_t *bal_ptr,
+                             const int32_t *bal_colP, const int32_t *bal_colQ, const double *bal_coef,
+                             int32_t ref_bus)
 {
     if (!h || nb <= 0 || ng <= 0 || nl <= 0) return SQPHIP_EINVAL;
+    if (!f_bus || !t_bus || !gen_bus || !bal_ptr || !bal_colP || !bal_colQ || !bal_coef) return SQPHIP_EINVAL;
     Ctx &C0 = h->c;
     // HVDC lines add 4 variables, 1 row, 2 balance incidences (= 4 Jacobian entries) and 2 loss-row entries each
-    const int n_ac = 2 * nb + 2 * ng + 4 * nl, m_ac = 1 + 2 * nb + 8 * nl;
+    const int n_ac = 2 * nb + 2 * ng + 4 * nl, m_ac = acr ? 1 + 4 * nb + 6 * nl : 1 + 2 * nb + 8 * nl;
     if (C0.d.n < n_ac || (C0.d.n - n_ac) % 4 != 0) return SQPHIP_EINVAL;
     const int ndc = (C0.d.n - n_ac) / 4;
     if (C0.d.m != m_ac + ndc) return SQPHIP_EINVAL;
     const int nbal = bal_ptr[nb];
-    // (a structure with bus shunts has 2 more Jacobian and 1 more Hessian entry per shunted bus at the end of the
-    // lists; sqphip_acopf_set_shunts checks the exact counts)
-    const int extraJ = C0.d.nnzj_coo - (32 * nl + 2 * ng + 1) - 6 * ndc, extraH = C0.d.nnzh_coo - (ng + 44 * nl);
-    if (extraJ < 0 || extraJ != 2 * extraH || extraH > nb || nbal != 2 * nl + ng + 2 * ndc) return SQPHIP_EINVAL;
+    // (a structure with bus shunts has 2 (polar) / 4 (rectangular) more Jacobian and 1 / 2 more Hessian entries per
+    // shunted bus at the end of the lists; sqphip_acopf_set_shunts checks the exact counts)
+    const int extraJ = C0.d.nnzj_coo - acopf_nnzj(acr, nb, ng, nl, ndc), extraH = C0.d.nnzh_coo - acopf_nnzh(acr, nb, ng, nl);
+    if (extraJ < 0 || extraJ != 2 * extraH || extraH > (acr ? 2 * nb : nb) || nbal != 2 * nl + ng + 2 * ndc) return SQPHIP_EINVAL;
     for (int l = 0; l < nl; ++l)
         if (f_bus[l] < 0 || f_bus[l] >= nb || t_bus[l] < 0 || t_bus[l] >= nb) return SQPHIP_EINVAL;
     for (int k = 0; k < nbal; ++k)
@@ -688,7 +697,7 @@ extern "C" int sqphip_acopf_attach(sqphip_ctx *h, int32_t nb, int32_t ng, int32_
     if (ref_bus < 0 || ref_bus >= nb) return SQPHIP_EINVAL;
     return guarded(h, [&](Ctx &C) {
         DV &d = C.d;
-        d.nb = nb; d.ng = ng; d.nl = nl; d.ref_bus = ref_bus;
+        d.nb = nb; d.ng = ng; d.nl = nl; d.ref_bus = ref_bus; d.acr = acr;
         d.ndc = ndc;
         d.dc_loss1 = C.upload(std::vector<double>(ndc > 0 ? ndc : 1, 0.0));   // sqphip_acopf_set_dclines overrides
         d.f_bus = C.upload(std::vector<int>(f_bus, f_bus + nl));
@@ -707,14 +716,32 @@ extern "C" int sqphip_acopf_attach(sqphip_ctx *h, int32_t nb, int32_t ng, int32_
     });
 }
 
+extern "C" int sqphip_acopf_attach(sqphip_ctx *h, int32_t nb, int32_t ng, int32_t nl, const int32_t *f_bus,
+                                   const int32_t *t_bus, const int32_t *gen_bus, const int32_t *bal_ptr,
+                                   const int32_t *bal_colP, const int32_t *bal_colQ, const double *bal_coef,
+                                   int32_t ref_bus)
+{
+    return acopf_attach_impl(h, 0, nb, ng, nl, f_bus, t_bus, gen_bus, bal_ptr, bal_colP, bal_colQ, bal_coef, ref_bus);
+}
+
+extern "C" int sqphip_acopf_attach_acr(sqphip_ctx *h, int32_t nb, int32_t ng, int32_t nl, const int32_t *f_bus,
+                                       const int32_t *t_bus, const int32_t *gen_bus, const int32_t *bal_ptr,
+                                       const int32_t *bal_colP, const int32_t *bal_colQ, const double *bal_coef,
+                                       int32_t ref_bus)
+{
+    return acopf_attach_impl(h, 1, nb, ng, nl, f_bus, t_bus, gen_bus, bal_ptr, bal_colP, bal_colQ, bal_coef, ref_bus);
+}
+
 extern "C" int sqphip_acopf_set_shunts(sqphip_ctx *h, int32_t nsh, const int32_t *sh_bus, const double *gs,
                                        const double *bs)
 {
     if (!h || !h->c.acopf_attached || nsh < 0) return SQPHIP_EINVAL;
     Ctx &C0 = h->c;
     const int nl = C0.d.nl, ng = C0.d.ng, nb = C0.d.nb;
-    if (C0.d.nnzj_coo != 32 * nl + 2 * ng + 1 + 2 * nsh + 6 * C0.d.ndc || C0.d.nnzh_coo != ng + 44 * nl + nsh) return SQPHIP_EINVAL;
-    if (nsh > 0 && C0.d.nlin != 2 * nl + 1) return SQPHIP_EINVAL;     // balance rows must not be declared linear
+    const int acr = C0.d.acr;
+    if (C0.d.nnzj_coo != acopf_nnzj(acr, nb, ng, nl, C0.d.ndc) + (acr ? 4 : 2) * nsh ||
+        C0.d.nnzh_coo != acopf_nnzh(acr, nb, ng, nl) + (acr ? 2 : 1) * nsh) return SQPHIP_EINVAL;
+    if (nsh > 0 && C0.d.nlin != (acr ? 1 : 2 * nl + 1)) return SQPHIP_EINVAL;     // balance rows must not be declared linear
     std::vector<int> of(nb, -1);
     for (int s = 0; s < nsh; ++s) {
         if (sh_bus[s] < 0 || sh_bus[s] >= nb || of[sh_bus[s]] >= 0) return SQPHIP_EINVAL;
@@ -894,6 +921,21 @@ extern "C" int sqphip_get_counters(sqphip_ctx *h, sqphip_counters *c)
             c->solve_launches = (int64_t)(C.mfp().fwd.size() + C.mfp().bwd.size());
             c->ldlt_flops = (double)nf * Y.flops;
         }
+        return SQPHIP_OK;
+    });
+}
+
+extern "C" int sqphip_get_mode_counters(sqphip_ctx *h, int64_t *out)
+{
+    if (!h || !out) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) -> int {
+        for (int k = 0; k < 12; ++k) out[k] = 0;
+        if (!C.d.sst) return SQPHIP_OK;
+        std::vector<SqpState> S((size_t)C.d.B);
+        SQPHIP_HIP_OK(hipMemcpyAsync(S.data(), C.d.sst, sizeof(SqpState) * C.d.B, hipMemcpyDeviceToHost, C.stream));
+        SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        for (auto &s : S)
+            for (int k = 0; k < 4; ++k) { out[3 * k] += s.md_qp[k]; out[3 * k + 1] += s.md_ipm[k]; out[3 * k + 2] += s.md_fac[k]; }
         return SQPHIP_OK;
     });
 }

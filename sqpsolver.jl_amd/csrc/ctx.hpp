@@ -41,6 +41,7 @@ struct SqpState {
     int iter, ret, step_acceptance, fr, sub_status, done, stage, need_qp, qp_mode, want_eval;
     int n_qp, trace_len, it_ipm, soc_pending, lp_pending, started;
     long tot_ipm, tot_fac, tot_sol;
+    long md_qp[4], md_ipm[4], md_fac[4];   // the same work split by sub-problem mode (0 QP, 1 FR, 2 SOC, 3 LP phase)
     int budget;          // outer iterations this instance may still start in the current sqp_run call
 };
 
@@ -116,6 +117,7 @@ struct DV {
     double *trace;      // [B][CAP][COLS]
     // ---- ACOPF evaluator data
     int nb, ng, nl, ref_bus;
+    int acr;                              // 1: rectangular voltage coordinates (acopf_dev.hpp acr_eval), 0: polar
     int ndc; const double *dc_loss1;   // HVDC lines (shared): 4 variables each behind all others, one loss row each at the end
     int nsh; const int *sh_bus, *sh_of_bus; const double *sh_gs, *sh_bs;   // bus shunts (shared): list, bus -> index or -1
     const int *f_bus, *t_bus, *gen_bus, *bal_ptr, *bal_colP, *bal_colQ;

@@ -125,6 +125,13 @@ static __device__ void push_trace(const DV &d, int inst, SqpState &S, double pn)
     }
 }
 
+// work of a finished sub-problem, booked under its mode (sqphip_get_mode_counters)
+static __device__ void book_mode(SqpState &S, const IpmState &I)
+{
+    const int k = I.mode & 3;
+    S.md_qp[k]++; S.md_ipm[k] += I.ipm_iters; S.md_fac[k] += I.n_factor;
+}
+
 static __device__ void qp_request(IpmState &I, int mode, double delta, double mu_pen)
 {
     I.mode = mode; I.delta = delta; I.mu_pen = mu_pen;
@@ -204,6 +211,7 @@ __global__ __launch_bounds__(TPB) void k_sqp_lp_finish(DV d)
     if (threadIdx.x == 0) {
         S.sub_status = I.status; S.stage = ST_TOP; S.n_qp++; S.it_ipm = I.ipm_iters;
         S.tot_ipm += I.ipm_iters; S.tot_fac += I.n_factor; S.tot_sol += I.n_solve;
+        book_mode(S, I);
     }
     __syncthreads();
     push_trace(d, inst, S, norm_inf(ps, d.n));            // print(sqp, "LP")
@@ -302,6 +310,7 @@ __global__ __launch_bounds__(TPB) void k_sqp_mid(DV d)
         S.mu = fmax(fmax(S.mu, nl_), fmax(nL, nU));
         S.sub_status = st; S.n_qp++; S.it_ipm += I.ipm_iters;
         S.tot_ipm += I.ipm_iters; S.tot_fac += I.n_factor; S.tot_sol += I.n_solve;
+        book_mode(S, I);
     }
     __syncthreads();
     if (st == SQPHIP_MOI_LOCALLY_SOLVED) {
@@ -426,7 +435,7 @@ __global__ __launch_bounds__(TPB) void k_sqp_soc_finish(DV d)
     const double qs = qmodel_step(d, inst, S, psoc, x, df, E, jv, hv, gL, gU, xL, xU, tmpx, tmpE);
     const double pred = S.q0 - qs;
     const double rho = ared / pred;
-    if (threadIdx.x == 0) { S.n_qp++; S.it_ipm += I.ipm_iters; S.tot_ipm += I.ipm_iters; S.tot_fac += I.n_factor; S.tot_sol += I.n_solve; }
+    if (threadIdx.x == 0) { S.n_qp++; S.it_ipm += I.ipm_iters; S.tot_ipm += I.ipm_iters; S.tot_fac += I.n_factor; S.tot_sol += I.n_solve; book_mode(S, I); }
     if (ared > 0 && rho > 0) {
         accept_step(d, x, lam, mxL, mxU, psoc, plam, pmxL, pmxU);
         if (threadIdx.x == 0) S.step_acceptance = 1;

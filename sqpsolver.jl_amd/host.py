@@ -238,8 +238,8 @@ class Context:
         keep = [np.ascontiguousarray(a, dtype=np.int32) for a in
                 (net.f_bus, net.t_bus, net.gen_bus, lay.bal_ptr, lay.bal_colP, lay.bal_colQ)]
         coef = _f(lay.bal_coef)
-        self._ck(self.L.sqphip_acopf_attach(self.h, net.nb, net.ng, net.nl, *[_i(a) for a in keep],
-                                            _d(coef), int(net.ref_bus)))
+        attach = self.L.sqphip_acopf_attach_acr if getattr(lay, "form", "polar") == "acr" else self.L.sqphip_acopf_attach
+        self._ck(attach(self.h, net.nb, net.ng, net.nl, *[_i(a) for a in keep], _d(coef), int(net.ref_bus)))
         if len(lay.dc_loss1):
             self._ck(self.L.sqphip_acopf_set_dclines(self.h, len(lay.dc_loss1), _d(_f(lay.dc_loss1))))
         if len(lay.sh_bus):
@@ -324,6 +324,13 @@ class Context:
         c = _lib.Counters()
         self._ck(self.L.sqphip_get_counters(self.h, C.byref(c)))
         return {k: getattr(c, k) for k, _ in _lib.Counters._fields_}
+
+    def mode_counters(self):
+        """Work of the batched run since sqp_reset by sub-problem mode: {mode: (sub-problems, IPM iterations,
+        factorisations)} for QP / FR / SOC / LP."""
+        out = (C.c_int64 * 12)()
+        self._ck(self.L.sqphip_get_mode_counters(self.h, out))
+        return {name: (out[3 * k], out[3 * k + 1], out[3 * k + 2]) for k, name in enumerate(("QP", "FR", "SOC", "LP"))}
 
     def reset_counters(self):
         self._ck(self.L.sqphip_reset_counters(self.h))
