@@ -53,7 +53,10 @@ typedef struct {
     int32_t use_soc;                                   /* :29 */
     int32_t literal_quirks;  /* 1: reproduce SURVEY.md App. C #2/#3 (JuMP-sign Hessian/KT residual) */
     double ipm_tol;          /* interior-point optimality tolerance (scaled), default 1e-9 */
-    int32_t ipm_max_iter;    /* default 200 */
+    int32_t ipm_max_iter;    /* default 200; a second-order correction (mode 2) gets half of it: a correction that has not
+                              * converged by then is abandoned -- for run! that is the same as any other unsuccessful
+                              * correction (no correction step, sqp_trust_region.jl:341-360), and no successful one of a
+                              * 5082-sub-problem survey of the IEEE-118 workload needed more than 83 iterations */
     int32_t ipm_phase1;      /* 1: confirm infeasibility verdicts with a phase-1 run (default 0) */
     int32_t device;          /* HIP device ordinal */
     int32_t ipm_corrector;   /* 1 (default): Mehrotra predictor-corrector iterations until the first inertia
@@ -323,6 +326,18 @@ int sqphip_get_counters(sqphip_ctx *ctx, sqphip_counters *c);
  * interior-point iterations, KKT factorisations of mode k = 0 QP (sub_optimize!, subproblem_JuMP.jl:127-183), 1 FR
  * (:352-393), 2 SOC (sqp_trust_region.jl:341-360), 3 linear phase (:264-304).  12 values. */
 int sqphip_get_mode_counters(sqphip_ctx *ctx, int64_t *out12);
+/* ... and per instance (arrays of length batch, any may be NULL): sub-problems, interior-point iterations and KKT
+ * factorisations since sqphip_sqp_reset.  With continuous batching a call to sqphip_sqp_run lasts as long as its
+ * busiest instance: max / mean of `factorisations` is the load imbalance of the batch. */
+int sqphip_sqp_work(sqphip_ctx *ctx, int64_t *sub_problems, int64_t *ipm_iterations, int64_t *factorisations);
+/* The last (up to 64) sub-problems of one instance in the order they finished: rows of four int32 (mode, MOI status,
+ * interior-point iterations, factorisations); *n_rows receives the number written (cap: rows available in `rows`). */
+int sqphip_sqp_qp_log(sqphip_ctx *ctx, int32_t inst, int32_t *rows, int32_t cap, int32_t *n_rows);
+/* Diagnostics: the sub-problem request instance `inst` of the batched run worked on last, in the argument convention of
+ * sqphip_qp_solve (x_k[n], c[n], b[m], jac_coo[nnzJ], hess_coo[nnzH]; any pointer may be NULL), so that a sub-problem
+ * seen on the device can be replayed through sqphip_qp_solve or another solver. */
+int sqphip_sqp_last_request(sqphip_ctx *ctx, int32_t inst, int32_t *mode, double *delta, double *mu_pen, double *x_k,
+                            double *c, double *b, double *jac_coo, double *hess_coo);
 int sqphip_reset_counters(sqphip_ctx *ctx);
 /* HIP-event timing of the factor / trailing-update / solve kernels (off by default) */
 int sqphip_set_timing(sqphip_ctx *ctx, int32_t enabled);

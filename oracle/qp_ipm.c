@@ -67,6 +67,7 @@ struct ora_qp {
     int64_t nt;
     double *tv;
     double delta_w_last;
+    int cur_mode;           /* mode of the sub-problem being solved (ora_qp_solve) */
     /* warm start (opt.ipm_warm_start): mode of the last solved sub-problem, -1 = none; its p and y are still in place */
     int prev_mode;
     double prev_sf;
@@ -818,7 +819,10 @@ static int ipm_run(ora_qp *q, const double *p_start, const double *y_start)
     int mpc = q->opt.ipm_corrector != 0;
     double *soc = mpc ? (double *)calloc((size_t)(2 * n + 4 * m + 1), sizeof(double)) : NULL;
     int verbose = getenv("ORA_IPM_VERBOSE") != NULL;
-    for (int it = 0; it < q->opt.ipm_max_iter; ++it) {
+    /* iteration limit; half of it for a second-order correction: one that has not converged by then is abandoned,
+     * which for run! is the same as any other unsuccessful correction (same rule as the product, ipm.hip k_ipm_prepare) */
+    const int it_max = q->cur_mode == ORA_MODE_SOC ? q->opt.ipm_max_iter / 2 : q->opt.ipm_max_iter;
+    for (int it = 0; it < it_max; ++it) {
         ipm_meas ms;
         ipm_measure(q, rd, rp, &ms);
         if (!isfinite(ms.rd) || !isfinite(ms.cavg) || !isfinite(ms.rp)) { rc = 2; break; }
@@ -971,6 +975,7 @@ int ora_qp_solve(ora_qp *q, int mode, const double *x_k, double delta, double mu
 {
     int64_t n = q->n, m = q->m;
     q->ipm_iters = 0; q->n_factor = 0; q->last_elastic = 0.0;
+    q->cur_mode = mode;
     memcpy(q->jv, jval, sizeof(double) * (size_t)q->nnzj);
     int use_obj = (mode == ORA_MODE_QP || mode == ORA_MODE_SOC || mode == ORA_MODE_L1QP);
     double *pstart = NULL;

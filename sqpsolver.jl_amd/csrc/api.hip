@@ -940,6 +940,64 @@ extern "C" int sqphip_get_mode_counters(sqphip_ctx *h, int64_t *out)
     });
 }
 
+extern "C" int sqphip_sqp_work(sqphip_ctx *h, int64_t *qp, int64_t *ipm, int64_t *fac)
+{
+    if (!h) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) -> int {
+        if (!C.d.sst) return SQPHIP_EINVAL;
+        std::vector<SqpState> S((size_t)C.d.B);
+        SQPHIP_HIP_OK(hipMemcpyAsync(S.data(), C.d.sst, sizeof(SqpState) * C.d.B, hipMemcpyDeviceToHost, C.stream));
+        SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        for (int b = 0; b < C.d.B; ++b) {
+            if (qp) qp[b] = S[b].n_qp;
+            if (ipm) ipm[b] = S[b].tot_ipm;
+            if (fac) fac[b] = S[b].tot_fac;
+        }
+        return SQPHIP_OK;
+    });
+}
+
+extern "C" int sqphip_sqp_qp_log(sqphip_ctx *h, int32_t inst, int32_t *rows, int32_t cap, int32_t *n_rows)
+{
+    if (!h || !rows || !n_rows || cap < 0) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) -> int {
+        if (!C.d.sst || inst < 0 || inst >= C.d.B) return SQPHIP_EINVAL;
+        SqpState S;
+        SQPHIP_HIP_OK(hipMemcpyAsync(&S, C.d.sst + inst, sizeof(SqpState), hipMemcpyDeviceToHost, C.stream));
+        SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        const int have = S.qlog_n < SQPHIP_QLOG_CAP ? S.qlog_n : SQPHIP_QLOG_CAP, n = have < cap ? have : cap;
+        for (int k = 0; k < n; ++k) {
+            const int src = (S.qlog_n - n + k) % SQPHIP_QLOG_CAP;
+            for (int c = 0; c < 4; ++c) rows[4 * k + c] = S.qlog[4 * src + c];
+        }
+        *n_rows = n;
+        return SQPHIP_OK;
+    });
+}
+
+extern "C" int sqphip_sqp_last_request(sqphip_ctx *h, int32_t inst, int32_t *mode, double *delta, double *mu_pen,
+                                       double *x_k, double *c, double *b, double *jac_coo, double *hess_coo)
+{
+    if (!h) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) -> int {
+        const DV &d = C.d;
+        if (!d.ist || inst < 0 || inst >= d.B) return SQPHIP_EINVAL;
+        IpmState I;
+        SQPHIP_HIP_OK(hipMemcpyAsync(&I, d.ist + inst, sizeof(IpmState), hipMemcpyDeviceToHost, C.stream));
+        auto get = [&](double *dst, const double *src, long stride) {
+            if (dst && stride > 0)
+                SQPHIP_HIP_OK(hipMemcpyAsync(dst, src + inst * stride, sizeof(double) * stride, hipMemcpyDeviceToHost, C.stream));
+        };
+        get(x_k, d.xk, d.n); get(c, d.cin, d.n); get(b, d.bE, d.m);
+        get(jac_coo, d.jcoo, d.nnzj_coo); get(hess_coo, d.hcoo, d.nnzh_coo);
+        SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        if (mode) *mode = I.mode;
+        if (delta) *delta = I.delta;
+        if (mu_pen) *mu_pen = I.mu_pen;
+        return SQPHIP_OK;
+    });
+}
+
 extern "C" int sqphip_reset_counters(sqphip_ctx *h)
 {
     if (!h) return SQPHIP_EINVAL;

@@ -33,6 +33,7 @@ struct IpmState {
     double elastic;
 };
 
+#define SQPHIP_QLOG_CAP 64
 // SQP-TR state of one instance: the scalar fields of SqpTR
 // (/root/reference/src/algorithms/sqp_trust_region.jl:6-24, sqp.jl:16-59)
 struct SqpState {
@@ -42,6 +43,7 @@ struct SqpState {
     int n_qp, trace_len, it_ipm, soc_pending, lp_pending, started;
     long tot_ipm, tot_fac, tot_sol;
     long md_qp[4], md_ipm[4], md_fac[4];   // the same work split by sub-problem mode (0 QP, 1 FR, 2 SOC, 3 LP phase)
+    int qlog_n, qlog[4 * SQPHIP_QLOG_CAP]; // the last sub-problems of this instance: mode, MOI status, iterations, factorisations
     int budget;          // outer iterations this instance may still start in the current sqp_run call
 };
 

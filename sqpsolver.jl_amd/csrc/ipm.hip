@@ -253,7 +253,8 @@ __global__ __launch_bounds__(TPB) void k_ipm_prepare(DV d)
     if (d.phase[inst] != PH_PREP) return;
     IpmState &st = d.ist[inst];
     INST_PTRS
-    if (st.iter >= d.ipm_max_iter) {
+    // iteration limit; half of it for a second-order correction (sqphip.h, options.ipm_max_iter)
+    if (st.iter >= (st.mode == SQPHIP_MODE_SOC ? d.ipm_max_iter / 2 : d.ipm_max_iter)) {
         if (threadIdx.x == 0) { st.rc = 1; d.phase[inst] = PH_DONE; }
         return;
     }

@@ -14,6 +14,7 @@
 #include "dev_util.hpp"
 #include "acopf_dev.hpp"
 #include <cmath>
+#include <chrono>
 #include <thread>
 
 namespace sqphip {
@@ -130,6 +131,9 @@ static __device__ void book_mode(SqpState &S, const IpmState &I)
 {
     const int k = I.mode & 3;
     S.md_qp[k]++; S.md_ipm[k] += I.ipm_iters; S.md_fac[k] += I.n_factor;
+    int *q = S.qlog + 4 * (S.qlog_n % SQPHIP_QLOG_CAP);
+    q[0] = I.mode; q[1] = I.status; q[2] = I.ipm_iters; q[3] = I.n_factor;
+    S.qlog_n++;
 }
 
 static __device__ void qp_request(IpmState &I, int mode, double delta, double mu_pen)
@@ -475,14 +479,6 @@ __global__ void k_sqp_count(DV d)
     }
 }
 
-static void read_sqp_counters(Ctx &C)
-{
-    hipLaunchKernelGGL(k_sqp_count, dim3(1), dim3(64), 0, C.stream, C.d);
-    SQPHIP_HIP_OK(hipMemcpyAsync(C.h_counters + 2, C.d.counters + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, C.stream));
-    SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
-    SQPHIP_HIP_OK(hipGetLastError());       // a failed launch anywhere in the sweep surfaces here
-}
-
 void sqp_reset(Ctx &C)
 {
     hipLaunchKernelGGL(k_sqp_reset, dim3(C.d.B), dim3(TPB), 0, C.stream, C.d);
@@ -520,15 +516,45 @@ static void sqp_run_lane(Ctx &C, int max_outer)
     const dim3 gB(d.B), bT(TPB);
     hipLaunchKernelGGL(k_sqp_budget, dim3(1), dim3(64), 0, s, d, max_outer > 0 ? max_outer : 0x3fffffff);
     hipLaunchKernelGGL(k_sqp_begin, gB, bT, 0, s, d);
-    for (long sweep = 0; sweep < 100000000L; ++sweep) {
-        ipm_sweep(C, /*sqp_level=*/true);
-        read_sqp_counters(C);
-        static const bool sweep_log = getenv("SQPHIP_SWEEP_LOG") != nullptr;    // instances with work left, per sweep
-        if (sweep_log) fprintf(stderr, "%d%c", C.h_counters[2], (sweep % 32) == 31 ? '\n' : ' ');
-        if (C.tm.pending_trailing.size() > 4096) C.tm.flush();
-        if (C.h_counters[2] == 0) break;
+    // The "anyone left?" counter of sweep k is read while sweep k + 1 is already queued: the stream never runs dry
+    // behind a host round trip.  The price is one sweep of gated-off kernels after the last instance has finished.
+    static const bool sweep_log = getenv("SQPHIP_SWEEP_LOG") != nullptr;    // instances with work left, per sweep
+    static const bool lockstep = getenv("SQPHIP_SWEEP_LOCKSTEP") != nullptr; // experiment switch: read before queueing
+    hipEvent_t ev[2];
+    for (auto &e : ev) SQPHIP_HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    auto left_after = [&](long k) {          // instances with work left after sweep k
+        SQPHIP_HIP_OK(hipEventSynchronize(ev[k & 1]));
+        SQPHIP_HIP_OK(hipGetLastError());   // a failed launch anywhere in the sweep surfaces here
+        const int left = C.h_counters[2 + 2 * (k & 1)];
+        if (sweep_log) fprintf(stderr, "%d%c", left, (k % 32) == 31 ? '\n' : ' ');
+        return left;
+    };
+    try {
+        for (long sweep = 0; sweep < 100000000L; ++sweep) {
+            ipm_sweep(C, /*sqp_level=*/true);
+            hipLaunchKernelGGL(k_sqp_count, dim3(1), dim3(64), 0, s, d);
+            SQPHIP_HIP_OK(hipMemcpyAsync(C.h_counters + 2 + 2 * (sweep & 1), d.counters + 2, 2 * sizeof(int),
+                                         hipMemcpyDeviceToHost, s));
+            SQPHIP_HIP_OK(hipEventRecord(ev[sweep & 1], s));
+            if (C.tm.pending_trailing.size() > 4096) C.tm.flush();
+            if (lockstep) { if (left_after(sweep) == 0) break; continue; }
+            if (sweep >= 1 && left_after(sweep - 1) == 0) break;
+        }
+        SQPHIP_HIP_OK(hipStreamSynchronize(s));
+    } catch (...) {
+        for (auto &e : ev) hipEventDestroy(e);
+        throw;
     }
-    SQPHIP_HIP_OK(hipStreamSynchronize(s));
+    for (auto &e : ev) hipEventDestroy(e);
+    if (const char *e = getenv("SQPHIP_EMPTY_SWEEPS")) {      // experiment: wall time of a sweep with every kernel gated off
+        const int n = atoi(e);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int k = 0; k < n; ++k) ipm_sweep(C, true);
+        SQPHIP_HIP_OK(hipStreamSynchronize(s));
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        fprintf(stderr, "sqphip: %d gated-off sweeps of %d instances: %.1f us each\n", n, d.B, us / (n > 0 ? n : 1));
+        C.n_sweeps -= n;
+    }
 }
 
 // SQP-level kernels of a sweep, in dependency order (called from ipm_sweep)

@@ -340,6 +340,15 @@ SparseSym sparse_symbolic(int nu, const std::vector<std::vector<int>> &adj, cons
         std::vector<int> fill(S.level_ptr.begin(), S.level_ptr.end() - 1);
         for (int s = 0; s < S.ns; ++s) S.level_sn[fill[S.sn_level[s]]++] = s;
     }
+    if (getenv("SQPHIP_SYM_DUMP"))          // fronts by level: columns x rows(children)
+        for (int l = 0; l < S.nlevels; ++l) {
+            fprintf(stderr, "level %2d:", l);
+            for (int k = S.level_ptr[l]; k < S.level_ptr[l + 1]; ++k) {
+                const int s = S.level_sn[k];
+                fprintf(stderr, " %dx%d(%d)", S.sn_nc[s], S.sn_nr[s], S.child_ptr[s + 1] - S.child_ptr[s]);
+            }
+            fprintf(stderr, "\n");
+        }
     return S;
 }
 

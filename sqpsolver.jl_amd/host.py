@@ -332,6 +332,26 @@ class Context:
         self._ck(self.L.sqphip_get_mode_counters(self.h, out))
         return {name: (out[3 * k], out[3 * k + 1], out[3 * k + 2]) for k, name in enumerate(("QP", "FR", "SOC", "LP"))}
 
+    def sqp_work(self):
+        """Per instance: (sub-problems, IPM iterations, factorisations) since sqp_reset, three int64 arrays."""
+        out = [np.zeros(self.batch, dtype=np.int64) for _ in range(3)]
+        self._ck(self.L.sqphip_sqp_work(self.h, *[a.ctypes.data_as(C.POINTER(C.c_int64)) for a in out]))
+        return tuple(out)
+
+    def sqp_qp_log(self, inst):
+        """The last (up to 64) sub-problems of an instance: list of (mode, MOI status, IPM iterations, factorisations)."""
+        rows = np.zeros((64, 4), dtype=np.int32); n = C.c_int32()
+        self._ck(self.L.sqphip_sqp_qp_log(self.h, inst, _i(rows), 64, C.byref(n)))
+        return [tuple(int(v) for v in rows[k]) for k in range(n.value)]
+
+    def sqp_last_request(self, inst):
+        """The sub-problem request an instance of the batched run worked on last (arguments of QpHip / sqphip_qp_solve)."""
+        mode = C.c_int32(); delta = C.c_double(); mu = C.c_double()
+        xk = np.zeros(self.n); c = np.zeros(self.n); b = np.zeros(self.m); jc = np.zeros(self.nnzj); hc = np.zeros(self.nnzh)
+        self._ck(self.L.sqphip_sqp_last_request(self.h, inst, C.byref(mode), C.byref(delta), C.byref(mu), _d(xk), _d(c),
+                                                _d(b), _d(jc), _d(hc)))
+        return dict(mode=mode.value, delta=delta.value, mu_pen=mu.value, x_k=xk, c=c, b=b, jac_coo=jc, hess_coo=hc)
+
     def reset_counters(self):
         self._ck(self.L.sqphip_reset_counters(self.h))
 
