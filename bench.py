@@ -175,6 +175,7 @@ def main():
         run_steps(args.warmup)
     c0 = ctx.counters()
     m0 = ctx.mode_counters()
+    w0 = ctx.sqp_work()[2].copy()
     ctx.set_timing(not args.no_kernel_timing)
     sync()
     t0 = time.perf_counter()
@@ -184,6 +185,7 @@ def main():
     ctx.set_timing(False)
     c1 = ctx.counters()
     m1 = ctx.mode_counters()
+    wfac = ctx.sqp_work()[2] - w0            # factorisations per instance over the timed steps (= sweeps it was active in)
     # rank-local table of the timed steps by sub-problem mode (sub-problems, IPM iterations and factorisations per solve)
     by_mode = {}
     for k in m1:
@@ -348,6 +350,7 @@ def main():
                        "sweeps": int(c1["n_sweeps"] - c0["n_sweeps"]),
                        "ipm_iterations_per_qp": n_ipm / max(1.0, n_qp), "factorisations_per_qp": n_fac / max(1.0, n_qp),
                        "by_mode": by_mode,
+                       "busiest_instance_over_mean": float(wfac.max() / max(1.0, wfac.mean())),
                        "instances_done_in_timed_steps": int(np.sum(g_done)),
                        "note": "with literal_quirks = 1 (the reference's JuMP-sign Hessian, SURVEY.md App. C #2) the "
                                "sub-problems are non-convex and most scenarios never meet the termination test; see "

@@ -1304,6 +1304,50 @@ def test_batch_of_eight_matches_oracle_instance_by_instance():
     ctx.close()
 
 
+def test_subproblem_of_the_batched_run_replays_through_the_seat():
+    """Diagnostics of the batched run (sqphip_sqp_work, _qp_log, _last_request): the per-instance work adds up to the
+    counters, the sub-problem log lists every solve in order, and the last request of an instance -- fetched from the
+    device and replayed through the drop-in seat sqphip_qp_solve of a fresh context and through the oracle's seat --
+    gives the logged status and iteration count again.  The run is cut after the iteration whose second-order
+    correction is the sub-problem that kept one instance of the bench busy for 200 iterations before corrections got
+    half the iteration limit (scenario 109 of the IEEE-118 set)."""
+    nb, ng, nl, seed = CASES["case118"]
+    base = acopf_synth(nb, ng, nl, seed)
+    ids = [109, 3]
+    nets = [contingency(base, s, seed) for s in ids]
+    lays = [acopf_layout(nt) for nt in nets]
+    kw = dict(max_iter=3000, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=1)
+    ctx = pkg.Context(lays[0].n, lays[0].m, lays[0].num_linear, lays[0].jrow, lays[0].jcol, lays[0].hrow, lays[0].hcol,
+                      lays[0].xL, lays[0].xU, lays[0].gL, lays[0].gU, pkg.default_options(**kw), batch=2)
+    ctx.acopf_attach(base, lays[0])
+    for b in range(2):
+        ctx.acopf_set_instance(b, nets[b], lays[b])
+    ctx.sqp_reset(); ctx.sqp_run(6)
+    qp, ipm, fac = ctx.sqp_work()
+    tot = ctx.counters()
+    assert (qp.sum(), ipm.sum(), fac.sum()) == (tot["n_qp"], tot["n_ipm_iter"], tot["n_factor"])
+    opts = pkg.default_options(**kw)
+    for b in range(2):
+        log = ctx.sqp_qp_log(b)
+        assert len(log) == qp[b] and sum(r[2] for r in log) == ipm[b] and sum(r[3] for r in log) == fac[b]
+        assert log[0][0] == 3 and all(r[2] <= opts.ipm_max_iter // (2 if r[0] == 2 else 1) for r in log)
+        rq = ctx.sqp_last_request(b)
+        assert rq["mode"] == log[-1][0]
+        one = pkg.Context(lays[b].n, lays[b].m, lays[b].num_linear, lays[b].jrow, lays[b].jcol, lays[b].hrow, lays[b].hcol,
+                          lays[b].xL, lays[b].xU, lays[b].gL, lays[b].gU, pkg.default_options(**kw))
+        rg = one.qp_solve(rq["mode"], rq["x_k"], rq["delta"], rq["mu_pen"], rq["c"], rq["b"], rq["jac_coo"], rq["hess_coo"])
+        one.close()
+        assert (rg["status"], rg["ipm_iters"], rg["n_factor"]) == log[-1][1:]
+        S = dict(n=lays[b].n, m=lays[b].m, num_linear=lays[b].num_linear, jrow=lays[b].jrow, jcol=lays[b].jcol,
+                 hrow=lays[b].hrow, hcol=lays[b].hcol, xL=lays[b].xL, xU=lays[b].xU, gL=lays[b].gL, gU=lays[b].gU)
+        ro = _oracle_qp(None, S, O.default_options(**kw))(rq["mode"], rq["x_k"], rq["delta"], rq["mu_pen"], rq["c"],
+                                                          rq["b"], rq["jac_coo"], rq["hess_coo"])
+        assert ro["status"] == rg["status"] and abs(ro["ipm_iters"] - rg["ipm_iters"]) <= max(2, 0.2 * ro["ipm_iters"])
+    # scenario 109: the correction is abandoned at half the iteration limit
+    assert ctx.sqp_qp_log(0)[-1][:3] == (2, 11, opts.ipm_max_iter // 2)
+    ctx.close()
+
+
 def test_penalty_escalation_on_the_device():
     """The device twin of test_oracle_kat.py::test_penalty_escalation_on_a_badly_scaled_feasible_row: a feasible
     sub-problem with a multiplier of 1e5 (above the exact-penalty weight 1e4) is solved, not declared infeasible;
