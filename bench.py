@@ -36,7 +36,7 @@ sys.path.insert(0, _ROOT)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet fp64 matrix peak; MI355X_MICROARCH.md has no fp64 row.  The on-box
                                # register-resident MFMA probe (printed next to it) sustains 77.6 of it.
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~ 8 TB/s
-DEFAULT_BATCH = {"case14": 512, "case118": 512, "case1354": 256, "case9241": 16}
+DEFAULT_BATCH = {"case14": 512, "case118": 512, "case1354": 512, "case9241": 64}
 
 
 def host_cores():
@@ -264,7 +264,8 @@ def main():
 
     # ---- rank 0, single-GPU only: the dense MFMA LDL^T on its own, the run-to-termination legs, the CPU baseline
     dense = None
-    if rank == 0 and not args.no_dense_ldlt:
+    small = args.workload in ("case14", "case118")      # the extra legs belong to the headline workload
+    if rank == 0 and not args.no_dense_ldlt and small:
         import ctypes as C
         sec, trs, nl_ = C.c_double(), C.c_double(), C.c_int64()
         if _lib.lib().sqphip_ldlt_bench(local_rank, 64, 2813, 3, C.byref(sec), C.byref(trs), C.byref(nl_)) == 0 and sec.value > 0:
@@ -274,7 +275,7 @@ def main():
                      "frac": tf / FP64_MFMA_PEAK_TFLOPS, "k_trailing_ms": 1e3 * trs.value, "k_trailing_launches": int(nl_.value)}
 
     termination = None
-    if rank == 0 and world == 1 and not args.no_termination:
+    if rank == 0 and world == 1 and not args.no_termination and small:
         termination = {}
         for lq in (1, 0):
             tctx, _ = make_ctx(lq, max_iter=60)
