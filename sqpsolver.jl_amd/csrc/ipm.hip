@@ -64,7 +64,7 @@ __device__ __forceinline__ double jact_col(const DV &d, const double *jv, const 
 
 // ---------------------------------------------------------------------------------------------
 // K2: COO -> CSC with duplicate summation by precomputed gather lists (sqp.jl:94-102, :113-116)
-__global__ __launch_bounds__(TPB) void k_qp_gather(DV d)
+static __device__ void b_qp_gather(const DV &d)
 {
     const int inst = blockIdx.x;
     const IpmState &st = d.ist[inst];
@@ -136,7 +136,7 @@ __device__ __forceinline__ double nudge_inside(double v, double lo, double hi)
 
 // ---------------------------------------------------------------------------------------------
 // Mode set-up (stage 0 only computes the request-dependent data), weights, interior start.
-__global__ __launch_bounds__(TPB) void k_ipm_start(DV d)
+static __device__ void b_ipm_start(const DV &d)
 {
     const int inst = blockIdx.x;
     IpmState &st = d.ist[inst];
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(TPB) void k_ipm_start(DV d)
 
 // ---------------------------------------------------------------------------------------------
 // top of an interior-point iteration: residuals, convergence test, barrier update, diagonals
-__global__ __launch_bounds__(TPB) void k_ipm_prepare(DV d)
+static __device__ void b_ipm_prepare(const DV &d)
 {
     const int inst = blockIdx.x;
     if (d.phase[inst] != PH_PREP) return;
@@ -488,7 +488,7 @@ __device__ double build_rhs(const DV &d, int inst, double tgt, bool soc)
 // xv, which the panel kernels of the factorisation turn into L^-1 rhs on the fly (fused forward elimination).
 // Runs for every instance in PH_FACTOR, i.e. again before each re-factorisation.  In predictor-corrector mode
 // this is the predictor's (affine-scaling, target 0) right-hand side.
-__global__ __launch_bounds__(TPB) void k_build_rhs(DV d)
+static __device__ void b_build_rhs(const DV &d)
 {
     const int inst = blockIdx.x;
     if (d.phase[inst] != PH_FACTOR) return;
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(TPB) void k_inertia(DV d)
 // against the full sparse operator, decide.  Condensed form: one refinement step when the residual is above 1e-11
 // relative (the elimination puts 1/D-sized terms into the matrix; see oracle/qp_ipm.c, kkt_solve) -- the residual
 // becomes the next right-hand side, the sweep runs one more forward/backward solve and calls this kernel with last = 1.
-__global__ __launch_bounds__(TPB) void k_refine(DV d, int last, int want)
+static __device__ void b_refine(const DV &d, int last, int want)
 {
     const int inst = blockIdx.x;
     if (d.phase[inst] != want) return;
@@ -640,7 +640,7 @@ __device__ void expand_directions(const DV &d, int inst, double tgt, bool soc, d
 // corrector's right-hand side goes through the same factorisation.  If this factorisation needed an inertia
 // correction the sub-problem is not convex along the path: the solve falls back to the monotone rule for good,
 // restarted from the current average complementarity.
-__global__ __launch_bounds__(TPB) void k_mpc(DV d)
+static __device__ void b_mpc(const DV &d)
 {
     const int inst = blockIdx.x;
     if (d.phase[inst] != PH_MPC) return;
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(TPB) void k_mpc(DV d)
 }
 
 // directions, fraction-to-boundary step lengths, update
-__global__ __launch_bounds__(TPB) void k_ipm_step(DV d)
+static __device__ void b_ipm_step(const DV &d)
 {
     const int inst = blockIdx.x;
     if (d.phase[inst] != PH_STEP) return;
@@ -832,6 +832,43 @@ __global__ void k_count(DV d)
 }
 
 // ---------------------------------------------------------------------------------------------
+// The vector stages of a sweep as three kernels instead of nine: one workgroup owns one instance in all of them, so
+// the stages of an instance simply run one after the other inside its workgroup (a barrier in between publishes the
+// phase / state words thread 0 wrote); every stage keeps its own gate.  Same arithmetic as the separate launches.
+__global__ __launch_bounds__(TPB) void k_qp_gather(DV d) { b_qp_gather(d); }
+
+// start of a sub-problem (COO -> CSC values, canonical programme), first convergence test, Newton right-hand side
+__global__ __launch_bounds__(TPB) void k_ipm_head(DV d)
+{
+    b_qp_gather(d);
+    __syncthreads();
+    b_ipm_start(d);
+    __syncthreads();
+    b_ipm_prepare(d);
+    __syncthreads();
+    b_build_rhs(d);
+}
+
+// behind solve slot A: residual check of the first solve, then the corrector's system in predictor-corrector mode
+__global__ __launch_bounds__(TPB) void k_ipm_mid(DV d, int last)
+{
+    b_refine(d, last, PH_SOLVE);
+    if (!d.ipm_corrector) return;
+    __syncthreads();
+    b_mpc(d);
+}
+
+// behind solve slot B: residual check of the second solve, the step, and the convergence test of the new iterate
+__global__ __launch_bounds__(TPB) void k_ipm_tail(DV d, int last)
+{
+    b_refine(d, last, PH_RESOLVE);
+    __syncthreads();
+    b_ipm_step(d);
+    __syncthreads();
+    b_ipm_prepare(d);
+}
+
+// ---------------------------------------------------------------------------------------------
 void launch_qp_gather(Ctx &C)
 {
     hipLaunchKernelGGL(k_qp_gather, dim3(C.d.B), dim3(TPB), 0, C.stream, C.d);
@@ -863,11 +900,8 @@ void ipm_sweep(Ctx &C, bool sqp_level)
     C.n_sweeps++;
     hipLaunchKernelGGL(k_qp_finish, gB, bT, 0, s, d);
     if (sqp_level) sqp_stage_kernels(C);
-    hipLaunchKernelGGL(k_qp_gather, gB, bT, 0, s, d);
-    hipLaunchKernelGGL(k_ipm_start, gB, bT, 0, s, d);
-    hipLaunchKernelGGL(k_ipm_prepare, gB, bT, 0, s, d);
+    hipLaunchKernelGGL(k_ipm_head, gB, bT, 0, s, d);
     if (!d.sparse) hipLaunchKernelGGL(k_kkt_assemble, dim3(d.Fpad, d.B), dim3(128), 0, s, d);
-    hipLaunchKernelGGL(k_build_rhs, gB, bT, 0, s, d);
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (C.tm.enabled) { ev = C.tm.get(); hipEventRecord(ev.first, s); }
     // assembly + factorisation, with the forward elimination of xv fused in
@@ -894,13 +928,10 @@ void ipm_sweep(Ctx &C, bool sqp_level)
     // and, with hundreds of instances in flight, 2 forward + 3 backward passes nearly every sweep, each as long as its
     // slowest front chain however few instances took part.)
     const int last = d.condense != 0 ? 0 : 1;          // full form: no refinement
-    hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, last, (int)PH_SOLVE);
-    if (d.ipm_corrector) hipLaunchKernelGGL(k_mpc, gB, bT, 0, s, d);
+    hipLaunchKernelGGL(k_ipm_mid, gB, bT, 0, s, d, last);
     lin_solve(PH_RESOLVE, false);
-    hipLaunchKernelGGL(k_refine, gB, bT, 0, s, d, last, (int)PH_RESOLVE);
     if (C.tm.enabled) { hipEventRecord(ev.second, s); C.tm.pending_solve.push_back(ev); }
-    hipLaunchKernelGGL(k_ipm_step, gB, bT, 0, s, d);
-    hipLaunchKernelGGL(k_ipm_prepare, gB, bT, 0, s, d);
+    hipLaunchKernelGGL(k_ipm_tail, gB, bT, 0, s, d, last);
 }
 
 // Runs every instance whose IpmState.start flag is set until each has a final MOI status

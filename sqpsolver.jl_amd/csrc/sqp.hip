@@ -201,7 +201,7 @@ __global__ __launch_bounds__(TPB) void k_sqp_begin(DV d)
     }
 }
 
-__global__ __launch_bounds__(TPB) void k_sqp_lp_finish(DV d)
+static __device__ void b_sqp_lp_finish(const DV &d)
 {
     const int inst = blockIdx.x;
     SQP_PTRS
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(TPB) void k_sqp_lp_finish(DV d)
 
 // top of the loop: iteration limit, eval_functions!, infeasibility measures, QP request
 // (sqp_trust_region.jl:126-141)
-__global__ __launch_bounds__(TPB) void k_sqp_top(DV d)
+static __device__ void b_sqp_top(const DV &d)
 {
     const int inst = blockIdx.x;
     SQP_PTRS
@@ -292,7 +292,7 @@ static __device__ void accept_step(const DV &d, double *x, double *lam, double *
 
 // after the QP: compute_step!, status branches, phi, termination tests, do_step!
 // (sqp_trust_region.jl:141-213, :370-380, :515-579)
-__global__ __launch_bounds__(TPB) void k_sqp_mid(DV d)
+static __device__ void b_sqp_mid(const DV &d)
 {
     const int inst = blockIdx.x;
     SQP_PTRS
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(TPB) void k_sqp_mid(DV d)
 }
 
 // second half of do_step! for instances that requested a second-order correction (:551-572)
-__global__ __launch_bounds__(TPB) void k_sqp_soc_finish(DV d)
+static __device__ void b_sqp_soc_finish(const DV &d)
 {
     const int inst = blockIdx.x;
     SQP_PTRS
@@ -557,15 +557,21 @@ static void sqp_run_lane(Ctx &C, int max_outer)
     }
 }
 
-// SQP-level kernels of a sweep, in dependency order (called from ipm_sweep)
-void sqp_stage_kernels(Ctx &C)
+// SQP-level stages of a sweep in dependency order, one kernel (one workgroup owns one instance: its stages run one
+// after the other, a barrier in between publishes the stage word thread 0 wrote; every stage keeps its own gate)
+__global__ __launch_bounds__(TPB) void k_sqp_stage(DV d)
 {
-    DV &d = C.d;
-    const dim3 gB(d.B), bT(TPB);
-    hipLaunchKernelGGL(k_sqp_lp_finish, gB, bT, 0, C.stream, d);
-    hipLaunchKernelGGL(k_sqp_mid, gB, bT, 0, C.stream, d);
-    if (d.use_soc) hipLaunchKernelGGL(k_sqp_soc_finish, gB, bT, 0, C.stream, d);
-    hipLaunchKernelGGL(k_sqp_top, gB, bT, 0, C.stream, d);
+    b_sqp_lp_finish(d);
+    __syncthreads();
+    b_sqp_mid(d);
+    __syncthreads();
+    if (d.use_soc) { b_sqp_soc_finish(d); __syncthreads(); }
+    b_sqp_top(d);
+}
+
+void sqp_stage_kernels(Ctx &C)          // called from ipm_sweep
+{
+    hipLaunchKernelGGL(k_sqp_stage, dim3(C.d.B), dim3(TPB), 0, C.stream, C.d);
 }
 
 // ---------------------------------------------------------------------------------------------
