@@ -918,7 +918,7 @@ extern "C" int sqphip_get_counters(sqphip_ctx *h, sqphip_counters *c)
             for (int q = 0; q < Y.ns; ++q) cb += (long)(Y.sn_nr[q] + 1) * Y.sn_nr[q] - (long)Y.sn_nr[q] * (Y.sn_nr[q] - 1) / 2;
             c->cb_doubles = cb;
             c->factor_launches = (int64_t)C.mfp().fac.size();
-            c->solve_launches = (int64_t)(C.mfp().fwd.size() + C.mfp().bwd.size());
+            c->solve_launches = (int64_t)(C.mfp().fwd.size() + C.mfp().bwd.size() + (C.mfp().top.count > 0 ? 1 : 0));
             c->ldlt_flops = (double)nf * Y.flops;
         }
         return SQPHIP_OK;

@@ -171,7 +171,19 @@ MfPlan mf_build_plan(int n, int m, const std::vector<int> &kpos, int mk, const s
     }
     // solves: one launch per level; a workgroup of four waves takes one front of more than 64 rows or four smaller ones
     const bool big_solve = !(getenv("SQPHIP_MF_BIG_SOLVE") && atoi(getenv("SQPHIP_MF_BIG_SOLVE")) == 0);   // experiment switch
+    // The top of the assembly tree is narrow (IEEE-118: one or two fronts per level over the last eight of thirteen
+    // levels): a launch per level there is a launch per front.  From the first level on above which no level holds
+    // more than two fronts, ONE workgroup per instance walks the remaining fronts in order (k_mf_solve_top: forward
+    // pass up, backward pass down, a workgroup barrier between fronts) -- same arithmetic, 2 x levels fewer launches.
+    P.top_level = S.nlevels;
+    if (big_solve && !(getenv("SQPHIP_MF_TOP") && atoi(getenv("SQPHIP_MF_TOP")) == 0)) {
+        int l = S.nlevels;
+        while (l > 0 && S.level_ptr[l] - S.level_ptr[l - 1] <= 2) --l;
+        if (S.nlevels - l >= 2) P.top_level = l;
+    }
+    int top_maxfs = 64, top_lcap = 0;
     for (int l = 0; l < S.nlevels; ++l) {
+        const bool top = l >= P.top_level;
         MfLaunch L{(int)P.sol_items.size() / 4, 0, 256, 0, 0, 0};
         int maxfs = 64, lcap = 0;                       // lcap: doubles for the LDS image of a big front's triangular corner
         std::vector<int> small;
@@ -192,7 +204,15 @@ MfPlan mf_build_plan(int n, int m, const std::vector<int> &kpos, int mk, const s
         L.tiles = big_solve ? 64 : maxfs;
         L.cls = std::max(4 * L.tiles, maxfs + 16);                     // doubles of the vector area (cls is free in solve launches)
         L.lds_bytes = 8 * (L.cls + lcap);
-        P.fwd.push_back(L);
+        if (!top) { P.fwd.push_back(L); continue; }
+        if (l == P.top_level) P.top.begin = L.begin;
+        P.top.count += L.count;
+        top_maxfs = std::max(top_maxfs, maxfs); top_lcap = std::max(top_lcap, lcap);
+    }
+    if (P.top.count) {
+        P.top.tiles = 64;
+        P.top.cls = std::max(4 * 64, top_maxfs + 16);
+        P.top.lds_bytes = 8 * (P.top.cls + top_lcap);
     }
     P.bwd.assign(P.fwd.rbegin(), P.fwd.rend());
     // packed records for the kernels

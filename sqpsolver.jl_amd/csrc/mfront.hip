@@ -599,6 +599,43 @@ __global__ __launch_bounds__(256) void k_mf_bwd(DV d, int ibegin, int want, int 
     if (s >= 0) mf_front_bwd(d, inst, s, mf_lds + wstride * wave, threadIdx.x & 63, generic);
 }
 
+// The narrow top of the assembly tree in one launch (mfplan.hip, P.top): one workgroup of four waves per instance walks
+// the work items of the levels >= top_level in order -- forward pass upwards, then the backward pass downwards -- with
+// a workgroup barrier between items (the vectors and update rows live in global memory, visible to the workgroup
+// after the barrier).  The items and the per-front routines are those of k_mf_fwd / k_mf_bwd.
+__global__ __launch_bounds__(256) void k_mf_solve_top(DV d, int ibegin, int count, int want, int do_fwd, int generic,
+                                                      int wstride, int vecsz, int lcap)
+{
+    const int inst = blockIdx.x;
+    if (d.phase[inst] != want) return;
+    extern __shared__ double mf_lds[];
+    const int4 *items = reinterpret_cast<const int4 *>(d.mf.sol_items) + ibegin;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (do_fwd)
+        for (int i = 0; i < count; ++i) {
+            const int4 it = items[i];
+            if (it.y == -2) {
+                const int nc = d.mf.desc[it.x].nc;
+                mf_front_fwd_big(d, inst, it.x, mf_lds, nc * nc <= lcap ? mf_lds + vecsz : nullptr, threadIdx.x);
+            } else {
+                const int s = wave == 0 ? it.x : (wave == 1 ? it.y : (wave == 2 ? it.z : it.w));
+                if (s >= 0) mf_front_fwd(d, inst, s, mf_lds + wstride * wave, threadIdx.x & 63, generic);
+            }
+            __syncthreads();
+        }
+    for (int i = count - 1; i >= 0; --i) {
+        const int4 it = items[i];
+        if (it.y == -2) {
+            const int nc = d.mf.desc[it.x].nc;
+            mf_front_bwd_big(d, inst, it.x, mf_lds, nc * nc <= lcap ? mf_lds + vecsz : nullptr, threadIdx.x);
+        } else {
+            const int s = wave == 0 ? it.x : (wave == 1 ? it.y : (wave == 2 ? it.z : it.w));
+            if (s >= 0) mf_front_bwd(d, inst, s, mf_lds + wstride * wave, threadIdx.x & 63, generic);
+        }
+        __syncthreads();
+    }
+}
+
 // whole solve of one instance by ONE workgroup of NWV waves: the waves deal out the fronts of a level, a workgroup
 // barrier closes the level (the vectors live in global memory, visible CU-wide after the barrier).  With hundreds of
 // instances in flight this fills the chip without a launch per level: 2 x levels launches become one.
@@ -669,6 +706,9 @@ void mf_solve(Ctx &C, int want, bool skip_fwd)
     if (!skip_fwd)
         for (const MfLaunch &L : C.mfp().fwd)
             hipLaunchKernelGGL(k_mf_fwd, dim3(L.count, d.B), dim3(256), L.lds_bytes, s, d, L.begin, want, generic, L.tiles, L.cls, L.lds_bytes / 8 - L.cls);
+    if (const MfLaunch &T = C.mfp().top; T.count > 0)
+        hipLaunchKernelGGL(k_mf_solve_top, dim3(d.B), dim3(256), T.lds_bytes, s, d, T.begin, T.count, want, skip_fwd ? 0 : 1, generic,
+                           T.tiles, T.cls, T.lds_bytes / 8 - T.cls);
     for (const MfLaunch &L : C.mfp().bwd)
         hipLaunchKernelGGL(k_mf_bwd, dim3(L.count, d.B), dim3(256), L.lds_bytes, s, d, L.begin, want, generic, L.tiles, L.cls, L.lds_bytes / 8 - L.cls);
 }

@@ -113,6 +113,8 @@ struct MfPlan {
     std::vector<MfGather> ea_ent, ev_ent;
     std::vector<int> sched;                      // fronts in launch order
     std::vector<MfLaunch> fac, fwd, bwd;
+    MfLaunch top{0, 0, 256, 0, 0, 0};           // solves: the narrow top of the assembly tree (levels >= top_level) in one launch
+    int top_level = 0;                            // = S.nlevels when there is no such launch
     long nnzK = 0;                               // structural entries of the lower triangle (destinations)
 };
 
