@@ -112,7 +112,7 @@ void make_lanes(Ctx &C)
 {
     C.lanes.clear();
     int G = 1;
-    if (C.d.sparse) G = C.d.B >= 256 ? 4 : (C.d.B >= 64 ? 2 : 1);
+    if (C.d.sparse) G = C.d.B >= 128 ? 4 : (C.d.B >= 64 ? 2 : 1);
     if (const char *e = getenv("SQPHIP_GROUPS")) G = atoi(e);
     if (G > C.d.B) G = C.d.B;
     if (G > 7) G = 7;                       // counter slots
