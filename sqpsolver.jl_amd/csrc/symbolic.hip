@@ -239,6 +239,36 @@ SparseSym sparse_symbolic(int nu, const std::vector<std::vector<int>> &adj, cons
             K.swap(keep);
         }
     }
+    // Second pass, the spine of the tree: from each root downwards the deepest child is merged into its parent while the
+    // merged front stays within `chain_front` rows, whatever the zeros cost.  The fronts along the spine are eliminated
+    // and solved one after the other by construction (each waits for its child): fewer, larger fronts there trade flops
+    // that run in parallel for per-front latency that does not.
+    static const int chain_front = getenv("SQPHIP_SYM_CHAIN") ? atoi(getenv("SQPHIP_SYM_CHAIN")) : opt.chain_front;
+    if (chain_front > 0) {
+        std::vector<std::vector<int>> kids(ns0);
+        std::vector<int> height(ns0, 0), par(ns0, -1);
+        auto find0 = [&](int s) { while (group[s] != s) s = group[s]; return s; };
+        for (int s = 0; s < ns0; ++s)
+            if (group[s] == s && snp[s] >= 0) { par[s] = find0(snp[s]); kids[par[s]].push_back(s); }
+        for (int s = 0; s < ns0; ++s)                       // postorder: children before parents
+            if (group[s] == s && par[s] >= 0) height[par[s]] = std::max(height[par[s]], height[s] + 1);
+        for (int r = ns0 - 1; r >= 0; --r) {
+            if (group[r] != r || par[r] >= 0) continue;      // roots only
+            int s = r;
+            for (;;) {
+                int c = -1;
+                for (int k : kids[s]) if (c < 0 || height[k] > height[c] || (height[k] == height[c] && k > c)) c = k;
+                if (c < 0 || height[c] == 0) break;          // the leaves stay as they are
+                if (gnc[s] + gnc[c] + nr[s] <= chain_front) {
+                    group[c] = s; gnc[s] += gnc[c];
+                    kids[s].erase(std::find(kids[s].begin(), kids[s].end(), c));
+                    for (int g : kids[c]) { par[g] = s; kids[s].push_back(g); }
+                    height[s] = 0;
+                    for (int g : kids[s]) height[s] = std::max(height[s], height[g] + 1);
+                } else s = c;
+            }
+        }
+    }
     auto find = [&](int s) { while (group[s] != s) s = group[s]; return s; };
     // final order: subtrees of the standing children first, then the columns of the group in their old order
     std::vector<int> inv3;
