@@ -104,6 +104,7 @@ DV group_view(const DV &d, int i0, int Bg, int g)
     v.counters = d.counters + 8 * (g + 1);
     if (v.br_ohm) { v.br_ohm += o * d.nl * 12; v.c2 += o * d.ng; v.c1 += o * d.ng; }
     v.mf.fronts += o * d.mf.stride; v.mf.vals += o * (long)d.mf.nnzK;
+    if (v.mf.fronts1) { v.mf.fronts1 += o * d.mf.stride; v.mf.vals1 += o * (long)d.mf.nnzK; v.dinv1 += o * d.Fpad; v.vv1 += o * d.Fpad; }
     return v;
 }
 
@@ -151,7 +152,7 @@ __global__ void k_mf_test_setup(DV d, int inst, double hsc, double dw, int ph)
 {
     for (int i = threadIdx.x; i < d.B; i += blockDim.x) { d.phase[i] = PH_IDLE; d.ist[i].start = 0; }
     __syncthreads();
-    if (threadIdx.x == 0) { d.ist[inst].hsc = hsc; d.ist[inst].dw = dw; d.ist[inst].stage = 0; d.phase[inst] = ph; }
+    if (threadIdx.x == 0) { d.ist[inst].hsc = hsc; d.ist[inst].dw = dw; d.ist[inst].stage = 0; d.ist[inst].sel = 0; d.ist[inst].fac_attempt = 0; d.phase[inst] = ph; }
 }
 
 }  // namespace
@@ -273,6 +274,15 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
                 M.nnzK = (int)P.nnzK;
                 M.vals = C.dalloc<double>((size_t)B * P.nnzK);
                 M.fronts = C.dalloc<double>((size_t)B * P.stride);
+                // Second candidate of a sweep (the speculative next shift, k_inertia / dev_util.hpp): a failed first shift then
+                // costs no extra sweep.  It pays while a sweep is bound by the latency of its kernel chain -- up to ~256
+                // resident instances (+15 % QP/s at 64, +8 % at 128, +6.5 % at 256) -- and costs once the front kernels are
+                // throughput-bound (-5 % at 512).  SQPHIP_MF_SPEC: 0 off, 1 shrink attempts and retries, 2 retries only.
+                d.spec_mode = getenv("SQPHIP_MF_SPEC") ? atoi(getenv("SQPHIP_MF_SPEC")) : (B <= 256 ? 1 : 0);
+                if (d.spec_mode != 0) {
+                    M.vals1 = C.dalloc<double>((size_t)B * P.nnzK);
+                    M.fronts1 = C.dalloc<double>((size_t)B * P.stride);
+                }
             } else if (d.condense && opt->kkt_tile_order) {
                 KktOrder o = kkt_order(d.n, (int)m, kpos, d.mk, PH.colptr, PH.rowval, rptr, rcol, /*rows_last=*/true);
                 upos = o.pos; d.Ts = o.Ts; d.Nf = o.Nf;
@@ -323,6 +333,7 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
         d.rhs = C.dalloc<double>(BN); d.sol = C.dalloc<double>(BN); d.wN = C.dalloc<double>(BN);
         const size_t BF = (size_t)B * d.Fpad;          // solve vectors and pivots live in the factorised order
         d.xv = C.dalloc<double>(BF); d.vv = C.dalloc<double>(BF); d.dinv = C.dalloc<double>(BF);
+        if (d.sparse && d.mf.fronts1) { d.vv1 = C.dalloc<double>(BF); d.dinv1 = C.dalloc<double>(BF); }
         d.K = C.dalloc<double>(d.sparse ? 1 : (size_t)B * d.ld * d.Fpad);
         d.ist = C.dalloc<IpmState>(B); d.sst = C.dalloc<SqpState>(B);
         d.phase = C.dalloc<int>(B); d.counters = C.dalloc<int>(64);

@@ -30,6 +30,7 @@ struct IpmState {
     // outcome
     int prev_mode;                 // 1 + mode of this instance's last solved sub-problem (options.ipm_warm_start), 0 none
     int status, ipm_iters, n_factor, n_solve;   // n_solve: forward + backward solves with the factors (incl. refinement)
+    int sel;                       // which of the two factorisations of the last sweep the solves use (mfront.hip, candidates)
     double elastic;
 };
 
@@ -57,6 +58,7 @@ struct MfDev {
     const long *off;
     long stride;                          // doubles of front storage per instance
     double *fronts;                       // [B][stride]
+    double *fronts1, *vals1;              // second candidate of a sweep (speculative next shift, k_inertia); null: off
     const int *asm_ptr, *dest_loc, *dest_rc, *item_ptr;
     const MfItem *items;
     const int *ea_ptr, *ea_rc, *ea_src_ptr, *ea_src;
@@ -104,6 +106,8 @@ struct DV {
     double *socZL, *socZU, *socZP, *socZM, *socVL, *socVU;   // predictor's dz*dx per complementarity pair
     // linear algebra
     double *K, *dinv, *xv, *vv;
+    double *dinv1, *vv1;                  // pivots / D^-1 L^-1 b of the second candidate (sparse path)
+    int spec_mode;                        // which first shifts get a second candidate: 1 shrink attempts and retries, 2 retries only
     // QP outputs
     double *op, *olam, *omxU, *omxL, *oslack;
     IpmState *ist;

@@ -33,4 +33,19 @@ template <class Op> static __device__ __forceinline__ double block_reduce(double
 
 static __device__ __forceinline__ bool fin(double v) { return isfinite(v); }
 
+// Inertia correction: the shift tried after `dw` has given the wrong inertia (Ipopt's schedule; dw_last = last shift
+// that worked in this solve).  k_inertia walks this sequence; the sparse path factorises TWO consecutive members per
+// sweep whenever the first is not a sure thing (mf_speculates): a failed first shift then costs no extra sweep.
+static __device__ __forceinline__ double next_shift(double dw, double dw_last)
+{
+    if (dw == 0.0) return dw_last == 0.0 ? 1e-4 : fmax(1e-20, dw_last / 3.0);
+    return dw * (dw_last == 0.0 ? 100.0 : 8.0);
+}
+// a second candidate is worth its flops when the first shift is a shrink attempt or a retry (it fails about one time
+// in three); the plain delta_w = 0 of a solve that never needed a correction is not speculated on
+static __device__ __forceinline__ bool mf_speculates(const DV &d, const IpmState &st)
+{
+    return d.sparse && d.mf.fronts1 != nullptr && (st.fac_attempt > 0 || (d.spec_mode == 1 && st.dw > 0.0));
+}
+
 }  // namespace sqphip

@@ -497,35 +497,43 @@ static __device__ void b_build_rhs(const DV &d)
     if (threadIdx.x == 0) st.rn = fmax(1.0, rn);
 }
 
-// after the factorisation: inertia from pivot signs -> PH_SOLVE, or a larger delta_w (stays PH_FACTOR)
+// after the factorisation: inertia from pivot signs -> PH_SOLVE, or a larger delta_w (stays PH_FACTOR).
+// Sparse path: the sweep has factorised the shift st.dw AND -- for the instances mf_speculates() names -- the next shift
+// of the schedule.  The bookkeeping below is that of a run that factorises one shift per sweep (same counters, same
+// decisions as the oracle); the second candidate only saves the sweep a failed first shift would have cost.
 __global__ __launch_bounds__(TPB) void k_inertia(DV d)
 {
     const int inst = blockIdx.x;
     if (d.phase[inst] != PH_FACTOR) return;
     IpmState &st = d.ist[inst];
-    const double *dinv = d.dinv + (long)inst * d.Fpad;
-    double np = 0, bad = 0;
+    const bool spec = mf_speculates(d, st);
+    const double *dinv = d.dinv + (long)inst * d.Fpad, *dinv1 = spec ? d.dinv1 + (long)inst * d.Fpad : nullptr;
+    double np = 0, bad = 0, np1 = 0, bad1 = 0;
     for (int i = threadIdx.x; i < d.Fpad; i += TPB) {
         if (d.uinv[i] < 0) continue;             // identity padding
         const double v = dinv[i];
         if (!fin(v) || v == 0.0) bad += 1; else if (v > 0) np += 1;
+        if (spec) {
+            const double w = dinv1[i];
+            if (!fin(w) || w == 0.0) bad1 += 1; else if (w > 0) np1 += 1;
+        }
     }
     np = block_reduce<OpSum>(np); bad = block_reduce<OpSum>(bad);
-    const bool ok = (np == (double)d.n) && bad == 0;
+    if (spec) { np1 = block_reduce<OpSum>(np1); bad1 = block_reduce<OpSum>(bad1); }
+    const bool ok[2] = { (np == (double)d.n) && bad == 0, spec && (np1 == (double)d.n) && bad1 == 0 };
     if (threadIdx.x != 0) return;
-    st.n_factor++;
-    if (!ok) {
+    for (int cand = 0; cand < (spec ? 2 : 1); ++cand) {
+        st.n_factor++;                           // the factorisation with the shift st.dw
+        if (ok[cand]) {
+            if (st.dw > 0.0) st.dw_last = st.dw;
+            st.refine_it = 0; st.sel = cand;
+            d.phase[inst] = PH_SOLVE;
+            return;
+        }
         st.fac_attempt++;
-        double dw = st.dw;
-        if (dw == 0.0) dw = st.dw_last == 0.0 ? 1e-4 : fmax(1e-20, st.dw_last / 3.0);
-        else dw *= (st.dw_last == 0.0 ? 100.0 : 8.0);
-        st.dw = dw;
-        if (dw > 1e40 || st.fac_attempt >= 60) { st.rc = 2; d.phase[inst] = PH_DONE; }
-        return;
+        st.dw = next_shift(st.dw, st.dw_last);   // (candidate 1 was factorised with exactly this shift)
+        if (st.dw > 1e40 || st.fac_attempt >= 60) { st.rc = 2; d.phase[inst] = PH_DONE; return; }
     }
-    if (st.dw > 0.0) st.dw_last = st.dw;
-    st.refine_it = 0;
-    d.phase[inst] = PH_SOLVE;
 }
 
 // after a triangular solve: accumulate (expanding the eliminated rows in the condensed form), form the residual

@@ -27,6 +27,22 @@
 
 namespace sqphip {
 
+// Two candidates per sweep: 0 = the factorisation with the shift st.dw, 1 = the one with the next shift of the schedule
+// (dev_util.hpp next_shift), computed in the same launches for the instances mf_speculates() names; k_inertia picks
+// (IpmState.sel) and the solves follow.  The factor kernels run over 2 B "instances": blockIdx.y >= B is candidate 1.
+__device__ __forceinline__ double *mf_arena(const DV &d, int inst, int cand) { return (cand ? d.mf.fronts1 : d.mf.fronts) + (long)inst * d.mf.stride; }
+__device__ __forceinline__ double *mf_vals(const DV &d, int inst, int cand) { return (cand ? d.mf.vals1 : d.mf.vals) + (long)inst * d.mf.nnzK; }
+__device__ __forceinline__ double *mf_dinv(const DV &d, int inst, int cand) { return (cand ? d.dinv1 : d.dinv) + (long)inst * d.Fpad; }
+__device__ __forceinline__ double *mf_vv(const DV &d, int inst, int cand) { return (cand ? d.vv1 : d.vv) + (long)inst * d.Fpad; }
+// instance and candidate of a factor-side workgroup; false: nothing to do
+__device__ __forceinline__ bool mf_candidate(const DV &d, int want, int &inst, int &cand)
+{
+    inst = blockIdx.y; cand = 0;
+    if (inst >= d.B) { inst -= d.B; cand = 1; }
+    if (d.phase[inst] != want) return false;
+    return cand == 0 || mf_speculates(d, d.ist[inst]);
+}
+
 #define MF_REG_P 1e-8      // = IPM_REG_P / IPM_REG_D of ipm.hip
 #define MF_REG_D 1e-8
 
@@ -56,13 +72,13 @@ __device__ long long g_mf_trace[1 << 16][8];
 template <int NT, bool INPLACE>
 __global__ __launch_bounds__(NT) void k_mf_factor(DV d, int sbegin, int want, int with_rhs)
 {
-    const int inst = blockIdx.y;
-    if (d.phase[inst] != want) return;
+    int inst, cand;
+    if (!mf_candidate(d, want, inst, cand)) return;
     const MfDev &M = d.mf;
     const int s = M.sched[sbegin + blockIdx.x];
     const MfFrontDesc Fd = M.desc[s];
     const int nc = Fd.nc, nr = Fd.nr, fs = nc + nr, ld = fs + 1, f0 = Fd.first;
-    double *G = M.fronts + (long)inst * M.stride + Fd.off;
+    double *G = mf_arena(d, inst, cand) + Fd.off;
     extern __shared__ double mf_lds[];
     double *F = INPLACE ? G : mf_lds;
     const int tid = threadIdx.x;
@@ -97,7 +113,7 @@ __global__ __launch_bounds__(NT) void k_mf_factor(DV d, int sbegin, int want, in
     for (int q = M.child_ptr[s]; q < M.child_ptr[s + 1]; ++q) {
         const int c = M.child[q];
         const int cnc = M.nc[c], cnr = M.nr[c], cld = cnc + cnr + 1;
-        const double *Cg = M.fronts + (long)inst * M.stride + M.off[c] + (long)cnc * cld + cnc;
+        const double *Cg = mf_arena(d, inst, cand) + M.off[c] + (long)cnc * cld + cnc;
         const int *rel = M.rel + M.rowptr[c];
         for (int jj = cg; jj < cnr; jj += ncg) {
             const int gj = rel[jj] * ld;
@@ -121,7 +137,7 @@ __global__ __launch_bounds__(NT) void k_mf_factor(DV d, int sbegin, int want, in
     }
     MF_TR(4)
     // 5. results: L (scaled) and 1 / D, z = D^-1 L^-1 b, contribution block with its right-hand-side row
-    double *dinv = d.dinv + (long)inst * d.Fpad + f0, *vv = d.vv + (long)inst * d.Fpad + f0;
+    double *dinv = mf_dinv(d, inst, cand) + f0, *vv = mf_vv(d, inst, cand) + f0;
     for (int j = cg; j < fs; j += ncg) {
         const double *Fj = F + j * ld;
         double *Gj = G + (long)j * ld;
@@ -149,18 +165,19 @@ extern "C" int sqphip_mf_trace_read(long long *out, int nfronts)
 // runs at full occupancy and off the level-by-level critical path of the front kernels.
 __global__ __launch_bounds__(256) void k_mf_values(DV d, int want)
 {
-    const int inst = blockIdx.y;
-    if (d.phase[inst] != want) return;
+    int inst, cand;
+    if (!mf_candidate(d, want, inst, cand)) return;
     const MfDev &M = d.mf;
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= M.nnzK) return;
     const IpmState &st = d.ist[inst];
+    const double dw = cand ? next_shift(st.dw, st.dw_last) : st.dw;
     const double *hv = d.hv + (long)inst * d.nnzhc, *jv = d.jv + (long)inst * d.nnzjc;
     const double *Dd = d.Dd + (long)inst * d.m, *sigp = d.sigp + (long)inst * d.n, *hd = d.hd + (long)inst * d.n;
     const int *rt = d.rtype + (long)inst * d.m;
     double a = 0.0;
-    for (int k = M.item_ptr[e]; k < M.item_ptr[e + 1]; ++k) a += mf_item_value(M.items[k], hv, jv, Dd, sigp, hd, rt, st.hsc, st.dw);
-    M.vals[(long)inst * M.nnzK + e] = a;
+    for (int k = M.item_ptr[e]; k < M.item_ptr[e + 1]; ++k) a += mf_item_value(M.items[k], hv, jv, Dd, sigp, hd, rt, st.hsc, dw);
+    mf_vals(d, inst, cand)[e] = a;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -198,14 +215,14 @@ template <int NW, int MAXT, bool LDSIMG>
 __global__ __launch_bounds__(64 * NW) void k_mf_factor2(DV d, int sbegin, int want, int with_rhs, int Tl)
 {
     constexpr int NT = 64 * NW;
-    const int inst = blockIdx.y;
-    if (d.phase[inst] != want) return;
+    int inst, cand;
+    if (!mf_candidate(d, want, inst, cand)) return;
     const MfDev &M = d.mf;
     const int s = M.sched[sbegin + blockIdx.x];
     const MfFrontDesc Fd = M.desc[s];
     const int nc = Fd.nc, nr = Fd.nr, fs = nc + nr, ld = fs + 1, f0 = Fd.first;
-    const double *arena = M.fronts + (long)inst * M.stride;
-    double *G = M.fronts + (long)inst * M.stride + Fd.off;
+    const double *arena = mf_arena(d, inst, cand);
+    double *G = mf_arena(d, inst, cand) + Fd.off;
     extern __shared__ double mf_lds[];
     const int R = 16 * Tl;
     double *Xp = mf_lds + (LDSIMG ? R * R : 0), *Lp = Xp + 4 * R, *blk = Lp + 4 * R, *dl = blk + 16;
@@ -224,7 +241,7 @@ __global__ __launch_bounds__(64 * NW) void k_mf_factor2(DV d, int sbegin, int wa
     __syncthreads();
     MF_TR(1)
     {
-        const double *vals = M.vals + (long)inst * M.nnzK;
+        const double *vals = mf_vals(d, inst, cand);
         for (int e = Fd.asm_begin + tid; e < Fd.asm_end; e += NT) {
             const int rc = M.dest_rc[e];
             F[(rc >> 16) * LD + (rc & 0xffff)] = vals[e];
@@ -332,7 +349,7 @@ __global__ __launch_bounds__(64 * NW) void k_mf_factor2(DV d, int sbegin, int wa
     __syncthreads();
     MF_TR(4)
     // 4. results
-    double *dinv = d.dinv + (long)inst * d.Fpad + f0, *vv = d.vv + (long)inst * d.Fpad + f0;
+    double *dinv = mf_dinv(d, inst, cand) + f0, *vv = mf_vv(d, inst, cand) + f0;
 #pragma unroll
     for (int q = 0; q < MAXT; ++q) {
         if (ti_[q] < 0) continue;
@@ -367,8 +384,9 @@ __device__ __forceinline__ void mf_front_fwd(const DV &d, int inst, int s, doubl
     const MfDev &M = d.mf;
     const MfFrontDesc Fd = M.desc[s];
     const int nc = Fd.nc, nr = Fd.nr, fs = nc + nr, ld = fs + 1, f0 = Fd.first;
-    const double *arena = M.fronts + (long)inst * M.stride;
-    double *G = M.fronts + (long)inst * M.stride + Fd.off;
+    const int cand = d.ist[inst].sel;
+    const double *arena = mf_arena(d, inst, cand);
+    double *G = mf_arena(d, inst, cand) + Fd.off;
     const double *b = d.xv + (long)inst * d.Fpad + f0;
     for (int i = lane; i < fs; i += 64) y[i] = i < nc ? b[i] : 0.0;
     wave_sync();
@@ -380,8 +398,8 @@ __device__ __forceinline__ void mf_front_fwd(const DV &d, int inst, int s, doubl
         y[g.where] += a;
     }
     wave_sync();
-    const double *dinv = d.dinv + (long)inst * d.Fpad + f0;
-    double *vv = d.vv + (long)inst * d.Fpad + f0;
+    const double *dinv = mf_dinv(d, inst, cand) + f0;
+    double *vv = mf_vv(d, inst, cand) + f0;
     if (nc <= 64 && !generic) {
         // lane i owns y_i of the triangular part; y_k travels by a wave shuffle (no barrier, loads pipeline freely)
         double yi = lane < nc ? y[lane] : 0.0;
@@ -416,9 +434,10 @@ __device__ __forceinline__ void mf_front_bwd(const DV &d, int inst, int s, doubl
     const MfDev &M = d.mf;
     const MfFrontDesc Fd = M.desc[s];
     const int nc = Fd.nc, nr = Fd.nr, fs = nc + nr, ld = fs + 1, f0 = Fd.first;
-    const double *G = M.fronts + (long)inst * M.stride + Fd.off;
+    const int cand = d.ist[inst].sel;
+    const double *G = mf_arena(d, inst, cand) + Fd.off;
     double *xg = d.xv + (long)inst * d.Fpad;
-    const double *vv = d.vv + (long)inst * d.Fpad + f0;
+    const double *vv = mf_vv(d, inst, cand) + f0;
     const int *rows = M.rows + Fd.rowptr;
     for (int i = lane; i < fs; i += 64) x[i] = i < nc ? vv[i] : xg[rows[i - nc]];
     wave_sync();
@@ -460,10 +479,11 @@ __device__ __forceinline__ void mf_front_fwd_big(const DV &d, int inst, int s, d
     const MfDev &M = d.mf;
     const MfFrontDesc Fd = M.desc[s];
     const int nc = Fd.nc, nr = Fd.nr, fs = nc + nr, ld = fs + 1, f0 = Fd.first;
-    const double *arena = M.fronts + (long)inst * M.stride;
-    double *G = M.fronts + (long)inst * M.stride + Fd.off;
-    const double *b = d.xv + (long)inst * d.Fpad + f0, *dinv = d.dinv + (long)inst * d.Fpad + f0;
-    double *vv = d.vv + (long)inst * d.Fpad + f0;
+    const int cand = d.ist[inst].sel;
+    const double *arena = mf_arena(d, inst, cand);
+    double *G = mf_arena(d, inst, cand) + Fd.off;
+    const double *b = d.xv + (long)inst * d.Fpad + f0, *dinv = mf_dinv(d, inst, cand) + f0;
+    double *vv = mf_vv(d, inst, cand) + f0;
     const int lane = tid & 63, wave = tid >> 6;
     if (Ls)
         for (int c = wave; c < nc; c += 4)
@@ -512,9 +532,10 @@ __device__ __forceinline__ void mf_front_bwd_big(const DV &d, int inst, int s, d
     const MfDev &M = d.mf;
     const MfFrontDesc Fd = M.desc[s];
     const int nc = Fd.nc, nr = Fd.nr, fs = nc + nr, ld = fs + 1, f0 = Fd.first;
-    const double *G = M.fronts + (long)inst * M.stride + Fd.off;
+    const int cand = d.ist[inst].sel;
+    const double *G = mf_arena(d, inst, cand) + Fd.off;
     double *xg = d.xv + (long)inst * d.Fpad;
-    const double *vv = d.vv + (long)inst * d.Fpad + f0;
+    const double *vv = mf_vv(d, inst, cand) + f0;
     const int *rows = M.rows + Fd.rowptr;
     const int lane = tid & 63, wave = tid >> 6;
     double *part = x + fs;                       // 16 block sums behind the vector
@@ -672,9 +693,10 @@ void mf_factor(Ctx &C, int want, bool with_rhs)
     hipStream_t s = C.stream;
     static const bool v1 = getenv("SQPHIP_MF_V1") != nullptr;      // cross-check: the plain rank-1 kernel for every front
     const int wr = (int)with_rhs;
-    if (!v1) hipLaunchKernelGGL(k_mf_values, dim3((d.mf.nnzK + 255) / 256, d.B), dim3(256), 0, s, d, want);
+    const int nb = d.mf.fronts1 ? 2 * d.B : d.B;         // with the second candidate the factor side runs over 2 B "instances"
+    if (!v1) hipLaunchKernelGGL(k_mf_values, dim3((d.mf.nnzK + 255) / 256, nb), dim3(256), 0, s, d, want);
     for (const MfLaunch &L : C.mfp().fac) {
-        const dim3 grid(L.count, d.B);
+        const dim3 grid(L.count, nb);
         const int cls = v1 ? 5 : L.cls;
         switch (cls) {
         case 0: hipLaunchKernelGGL((k_mf_factor2<1, 3, true>), grid, dim3(64), L.lds_bytes, s, d, L.begin, want, wr, L.tiles); break;

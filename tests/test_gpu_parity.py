@@ -1277,6 +1277,30 @@ def test_instance_groups_change_nothing_but_the_schedule():
         assert [t["ipm_iters"] for t in a[3]] == [t["ipm_iters"] for t in b[3]]
 
 
+def test_speculative_second_shift_changes_nothing_but_the_schedule(monkeypatch):
+    """Below ~256 resident instances a sweep factorises the shift delta_w AND the next shift of the inertia-correction
+    schedule for every instance whose first shift is a shrink attempt or a retry; k_inertia then books the work exactly
+    as a run with one shift per sweep would.  With and without the second candidate: the same iterates bit for bit, the
+    same iteration / factorisation counters, fewer sweeps."""
+    nb, ng, nl, seed = CASES["case118"]
+    base = acopf_synth(nb, ng, nl, seed)
+    nets = [base, contingency(base, 7, seed), contingency(base, 3, seed)]
+    lays = [acopf_layout(nt) for nt in nets]
+    kw = dict(max_iter=6, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=1)
+    got = {}
+    for mode in ("1", "0", "2"):
+        monkeypatch.setenv("SQPHIP_MF_SPEC", mode)
+        ctx = _run_batch(nets, lays, kw)
+        c = ctx.counters()
+        got[mode] = ([ctx.sqp_get(b)["x"] for b in range(3)], [ctx.sqp_qp_log(b) for b in range(3)],
+                     (c["n_qp"], c["n_ipm_iter"], c["n_factor"]), c["n_sweeps"])
+        ctx.close()
+    for mode in ("1", "2"):
+        assert all(np.array_equal(a, b) for a, b in zip(got[mode][0], got["0"][0]))
+        assert got[mode][1] == got["0"][1] and got[mode][2] == got["0"][2]
+    assert got["1"][3] <= got["2"][3] < got["0"][3]
+
+
 def test_batch_of_eight_matches_oracle_instance_by_instance():
     """Batch 8 (XCD-aware tile map, eight concurrent stage workgroups): every instance against the oracle."""
     nb, ng, nl, seed = CASES["case14"]
