@@ -278,7 +278,10 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
                 // costs no extra sweep.  It pays while a sweep is bound by the latency of its kernel chain -- up to ~256
                 // resident instances (+15 % QP/s at 64, +8 % at 128, +6.5 % at 256) -- and costs once the front kernels are
                 // throughput-bound (-5 % at 512).  SQPHIP_MF_SPEC: 0 off, 1 shrink attempts and retries, 2 retries only.
-                d.spec_mode = getenv("SQPHIP_MF_SPEC") ? atoi(getenv("SQPHIP_MF_SPEC")) : (B <= 256 ? 1 : 0);
+                // Large matrices (1354 / 9241 buses) rarely fail a shrink attempt and gain nothing (measured): the second
+                // arena is only spent where it is small (<= 1 GB).
+                const bool small_arena = (double)B * (double)P.stride * 8.0 <= 1e9;
+                d.spec_mode = getenv("SQPHIP_MF_SPEC") ? atoi(getenv("SQPHIP_MF_SPEC")) : (B <= 256 && small_arena ? 1 : 0);
                 if (d.spec_mode != 0) {
                     M.vals1 = C.dalloc<double>((size_t)B * P.nnzK);
                     M.fronts1 = C.dalloc<double>((size_t)B * P.stride);
