@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-termination", action="store_true", help="skip the run-to-termination legs")
     ap.add_argument("--no-dense-ldlt", action="store_true", help="skip the dense LDL^T record")
+    ap.add_argument("--no-screening", action="store_true", help="skip the scenario-queue record")
+    ap.add_argument("--screening-factor", type=int, default=4, help="scenario-queue record: scenarios = factor x slots")
     ap.add_argument("--literal-quirks", type=int, default=1)
     ap.add_argument("--kkt-mode", type=int, default=0, help="options.kkt_mode: 0 auto (sparse here), 1 dense MFMA, 2 sparse")
     ap.add_argument("--kkt-tile-order", type=int, default=None)
@@ -297,6 +299,36 @@ def main():
                                 "factorisations_per_solve": v[2] / v[0]} for k, v in tm.items() if v[0] > 0}}
             tctx.close()
 
+    # scenario queue (sqphip_sqp_stream_*): FACTOR x as many scenarios as slots, each run to termination, slots refilled on
+    # the device as runs end -- the throughput of a screening job, free of the wait for the busiest instance of a batch
+    screening = None
+    if rank == 0 and world == 1 and not args.no_screening and small:
+        screening = {}
+        M = args.screening_factor * total
+        for lq, mi in ((1, 20), (0, 60)):
+            opts_q = pkg.default_options(max_iter=mi, literal_quirks=lq, device=local_rank, ipm_corrector=args.ipm_corrector,
+                                         **lin_kw, **sqp_kw)
+            qctx = pkg.Context(lay0.n, lay0.m, lay0.num_linear, lay0.jrow, lay0.jcol, lay0.hrow, lay0.hcol,
+                               lay0.xL, lay0.xU, lay0.gL, lay0.gU, opts_q, batch=B)
+            qctx.acopf_attach(base, lay0)
+            qctx.stream_begin(M)
+            for s_id in range(M):
+                net = base if s_id == 0 else contingency(base, s_id, seed)
+                qctx.stream_set(s_id, net, acopf_layout(net))
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            qctx.stream_run()
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            qc = qctx.counters()
+            st = np.array([qctx.stream_get(s_id)["status"] for s_id in range(0, M, max(1, M // 256))])
+            screening[f"literal_quirks_{lq}"] = {
+                "scenarios": M, "slots": B, "max_outer_iterations": mi, "seconds": tb - ta,
+                "qp_solved": int(qc["n_qp"]), "qp_per_s": qc["n_qp"] / (tb - ta), "scenarios_per_s": M / (tb - ta),
+                "factorisations_per_qp": qc["n_factor"] / max(1, qc["n_qp"]),
+                "converged_fraction_of_sample": float(np.mean(st == 0))}
+            qctx.close()
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU restatement (NOT Julia/Ipopt): a bounded sample of the same workload, one scenario per host thread
@@ -359,6 +391,7 @@ def main():
             "roofline": roofline,
             "dense_ldlt": dense,
             "termination": termination,
+            "screening": screening,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -274,6 +274,19 @@ int sqphip_sqp_reset(sqphip_ctx *ctx);
 int sqphip_sqp_run(sqphip_ctx *ctx, int32_t max_outer);
 /* results per instance (src/model.jl result slots as written by sqp_trust_region.jl:215-222);
  * any pointer may be NULL */
+/* Scenario queue: more scenarios than the context has slots (contingency screening).  A slot whose run has terminated
+ * files its result under its scenario id, takes the next id from a device-wide counter, loads that scenario from tables
+ * in HBM and starts over -- inside the kernels of the running sweep, without the host -- so the batch stays full until
+ * the queue is empty and no slot waits for the slowest run of a batch (no reference counterpart; SURVEY.md section
+ * 8f-4, load re-balancing of stragglers).  Which slot solves which scenario depends on timing, the result of a
+ * scenario does not.  _begin allocates tables for n_scenarios; _set uploads one scenario (the arguments of
+ * sqphip_set_bounds and sqphip_acopf_set_instance); _run solves them all; _get returns one result (final point,
+ * objective, status as src/status.jl, iterations). */
+int sqphip_sqp_stream_begin(sqphip_ctx *ctx, int32_t n_scenarios);
+int sqphip_sqp_stream_set(sqphip_ctx *ctx, int32_t scenario, const double *xL, const double *xU, const double *gL,
+                          const double *gU, const double *ohm, const double *c2, const double *c1, const double *x0);
+int sqphip_sqp_stream_run(sqphip_ctx *ctx);
+int sqphip_sqp_stream_get(sqphip_ctx *ctx, int32_t scenario, double *x, double *obj_val, int32_t *status, int32_t *iter);
 int sqphip_sqp_get(sqphip_ctx *ctx, int32_t inst, double *x, double *g, double *mult_g,
                    double *mult_x_L, double *mult_x_U, double *obj_val, int32_t *status,
                    int32_t *iter);

@@ -100,6 +100,7 @@ DV group_view(const DV &d, int i0, int Bg, int g)
     v.rhs += o * d.Npad; v.sol += o * d.Npad; v.wN += o * d.Npad;
     v.xv += o * d.Fpad; v.vv += o * d.Fpad; v.dinv += o * d.Fpad;
     v.ist += o; v.sst += o; v.phase += o;
+    if (v.stream.slot_scen) v.stream.slot_scen += o;
     v.trace += o * SQPHIP_TRACE_CAP * SQPHIP_TRACE_COLS;
     v.counters = d.counters + 8 * (g + 1);
     if (v.br_ohm) { v.br_ohm += o * d.nl * 12; v.c2 += o * d.ng; v.c1 += o * d.ng; }
@@ -1008,6 +1009,85 @@ extern "C" int sqphip_sqp_last_request(sqphip_ctx *h, int32_t inst, int32_t *mod
         if (mode) *mode = I.mode;
         if (delta) *delta = I.delta;
         if (mu_pen) *mu_pen = I.mu_pen;
+        return SQPHIP_OK;
+    });
+}
+
+// ---- scenario queue: more scenarios than slots ----------------------------------------------------------------
+extern "C" int sqphip_sqp_stream_begin(sqphip_ctx *h, int32_t n_scenarios)
+{
+    if (!h || !h->c.acopf_attached || n_scenarios <= 0) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) {
+        DV &d = C.d;
+        StreamDev &Q = d.stream;
+        const size_t M = (size_t)n_scenarios;
+        Q.M = n_scenarios;
+        Q.next = C.dalloc<int>(1); Q.slot_scen = C.dalloc<int>((size_t)d.B);
+        Q.xL = C.dalloc<double>(M * d.n); Q.xU = C.dalloc<double>(M * d.n); Q.x0 = C.dalloc<double>(M * d.n);
+        Q.gL = C.dalloc<double>(M * d.m); Q.gU = C.dalloc<double>(M * d.m);
+        Q.ohm = C.dalloc<double>(M * d.nl * 12); Q.c2 = C.dalloc<double>(M * d.ng); Q.c1 = C.dalloc<double>(M * d.ng);
+        Q.rx = C.dalloc<double>(M * d.n); Q.robj = C.dalloc<double>(M);
+        Q.rstat = C.dalloc<int>(M); Q.riter = C.dalloc<int>(M);
+        SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        make_lanes(C);
+        return SQPHIP_OK;
+    });
+}
+
+extern "C" int sqphip_sqp_stream_set(sqphip_ctx *h, int32_t scen, const double *xL, const double *xU, const double *gL,
+                                     const double *gU, const double *ohm, const double *c2, const double *c1,
+                                     const double *x0)
+{
+    if (!h || scen < 0 || scen >= h->c.d.stream.M || !xL || !xU || !gL || !gU || !ohm || !c2 || !c1 || !x0) return SQPHIP_EINVAL;
+    for (int i = 0; i < h->c.d.m; ++i) {
+        if (gL[i] == -INFINITY && gU[i] == INFINITY) return SQPHIP_EINVAL;
+        if (h->c.d.condense && gL[i] == gU[i] && h->c.h_kpos[i] < 0) {
+            h->c.err = "sqphip_sqp_stream_set: row " + std::to_string(i) + " is an equality for this scenario but was not one when "
+                       "the context was created (options.kkt_condense = 1 fixes the kept rows)";
+            return SQPHIP_EINVAL;
+        }
+    }
+    return guarded(h, [&](Ctx &C) {
+        DV &d = C.d;
+        const StreamDev &Q = d.stream;
+        const size_t s = (size_t)scen;
+        h2d(C, const_cast<double *>(Q.xL) + s * d.n, xL, d.n); h2d(C, const_cast<double *>(Q.xU) + s * d.n, xU, d.n);
+        h2d(C, const_cast<double *>(Q.x0) + s * d.n, x0, d.n);
+        h2d(C, const_cast<double *>(Q.gL) + s * d.m, gL, d.m); h2d(C, const_cast<double *>(Q.gU) + s * d.m, gU, d.m);
+        h2d(C, const_cast<double *>(Q.ohm) + s * d.nl * 12, ohm, (size_t)d.nl * 12);
+        h2d(C, const_cast<double *>(Q.c2) + s * d.ng, c2, d.ng); h2d(C, const_cast<double *>(Q.c1) + s * d.ng, c1, d.ng);
+        SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        return SQPHIP_OK;
+    });
+}
+
+extern "C" int sqphip_sqp_stream_run(sqphip_ctx *h)
+{
+    if (!h || !h->c.acopf_attached || h->c.d.stream.M <= 0) return SQPHIP_ESTATE;
+    return guarded(h, [&](Ctx &C) {
+        auto t0 = std::chrono::steady_clock::now();
+        SQPHIP_HIP_OK(hipMemsetAsync(C.d.stream.next, 0, sizeof(int), C.stream));
+        sqp_stream_arm(C);
+        sqp_run(C, 0);
+        C.total_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return SQPHIP_OK;
+    });
+}
+
+extern "C" int sqphip_sqp_stream_get(sqphip_ctx *h, int32_t scen, double *x, double *obj_val, int32_t *status, int32_t *iter)
+{
+    if (!h || scen < 0 || scen >= h->c.d.stream.M) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) {
+        const DV &d = C.d;
+        const StreamDev &Q = d.stream;
+        d2h(C, x, Q.rx + (size_t)scen * d.n, d.n);
+        d2h(C, obj_val, Q.robj + scen, 1);
+        int st = 0, it = 0;
+        SQPHIP_HIP_OK(hipMemcpyAsync(&st, Q.rstat + scen, sizeof(int), hipMemcpyDeviceToHost, C.stream));
+        SQPHIP_HIP_OK(hipMemcpyAsync(&it, Q.riter + scen, sizeof(int), hipMemcpyDeviceToHost, C.stream));
+        SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        if (status) *status = st;
+        if (iter) *iter = it;
         return SQPHIP_OK;
     });
 }

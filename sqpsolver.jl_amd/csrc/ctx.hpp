@@ -72,6 +72,18 @@ struct MfDev {
     double *vals;                         // [B][nnzK] assembled values of the destinations (k_mf_values)
 };
 
+// Scenario queue (sqphip_sqp_stream_*): more scenarios than slots.  A slot whose run has terminated stores its result
+// under its scenario id, takes the next id from a device-wide counter, loads that scenario's data from the tables and
+// starts over -- inside the stage kernel, no host involvement; the batch stays full until the queue is empty.
+struct StreamDev {
+    int M;                                            // scenarios (0: no queue)
+    int *next;                                        // next scenario id to hand out
+    int *slot_scen;                                   // [B] scenario a slot works on; -2 fresh slot, -1 queue exhausted
+    const double *xL, *xU, *gL, *gU, *ohm, *c2, *c1, *x0;   // [M][.] scenario tables
+    double *rx, *robj;                                // results: final point [M][n], objective
+    int *rstat, *riter;                               // ... run! status (src/status.jl), iterations
+};
+
 // everything kernels need, by value
 struct DV {
     int n, m, nlin, N, Npad, ld, B;       // N = n + m, Npad = stride of the full-length vectors rhs / sol / wN
@@ -123,6 +135,7 @@ struct DV {
     double *trace;      // [B][CAP][COLS]
     // ---- ACOPF evaluator data
     int nb, ng, nl, ref_bus;
+    StreamDev stream;
     int acr;                              // 1: rectangular voltage coordinates (acopf_dev.hpp acr_eval), 0: polar
     int ndc; const double *dc_loss1;   // HVDC lines (shared): 4 variables each behind all others, one loss row each at the end
     int nsh; const int *sh_bus, *sh_of_bus; const double *sh_gs, *sh_bs;   // bus shunts (shared): list, bus -> index or -1
@@ -187,6 +200,7 @@ struct Ctx {
 void ipm_run_all(Ctx &C);            // runs every instance whose IpmState.start is set, to completion
 void ipm_sweep(Ctx &C, bool sqp_level);
 void sqp_stage_kernels(Ctx &C);      // sqp.hip: SQP-level kernels of a sweep
+void sqp_stream_arm(Ctx &C);          // scenario queue: every slot draws its first scenario in the first sweep
 void launch_qp_gather(Ctx &C);       // COO -> CSC for instances with start set (stage 0)
 // comm.hip
 void comm_release(Ctx &C);

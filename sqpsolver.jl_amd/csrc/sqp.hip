@@ -154,9 +154,9 @@ static __device__ void finalize(const DV &d, int inst, SqpState &S, const double
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void k_sqp_reset(DV d)
+// state of a run about to start from x0; keep_totals: the cumulative work counters survive (a slot of the scenario queue)
+static __device__ void reset_instance(const DV &d, int inst, bool keep_totals)
 {
-    const int inst = blockIdx.x;
     SQP_PTRS
     const double *x0 = d.x0 + on;
     for (int j = threadIdx.x; j < d.n; j += TPB) { x[j] = x0[j]; mxL[j] = 0; mxU[j] = 0; ps[j] = 0; psoc[j] = 0; }
@@ -166,14 +166,20 @@ __global__ __launch_bounds__(TPB) void k_sqp_reset(DV d)
         z.phi = 1e20; z.mu = d.init_mu; z.Delta = d.tr_size;
         z.prim_infeas = INFINITY; z.dual_infeas = INFINITY;
         z.step_acceptance = 1; z.fr = 0; z.iter = 1; z.ret = -5;
+        if (keep_totals) {
+            z.n_qp = S.n_qp; z.tot_ipm = S.tot_ipm; z.tot_fac = S.tot_fac; z.tot_sol = S.tot_sol; z.budget = S.budget;
+            for (int k = 0; k < 4; ++k) { z.md_qp[k] = S.md_qp[k]; z.md_ipm[k] = S.md_ipm[k]; z.md_fac[k] = S.md_fac[k]; }
+        }
         S = z;
         I.start = 0; I.dw_last = 0.0; I.prev_mode = 0;
         d.phase[inst] = PH_IDLE;
     }
 }
 
+__global__ __launch_bounds__(TPB) void k_sqp_reset(DV d) { reset_instance(d, blockIdx.x, false); }
+
 // run! prologue: sqp_trust_region.jl:100-122
-__global__ __launch_bounds__(TPB) void k_sqp_begin(DV d)
+static __device__ void b_sqp_begin(const DV &d)
 {
     const int inst = blockIdx.x;
     SQP_PTRS
@@ -200,6 +206,8 @@ __global__ __launch_bounds__(TPB) void k_sqp_begin(DV d)
         if (threadIdx.x == 0) { qp_request(I, SQPHIP_MODE_LP, S.Delta, S.mu); S.stage = ST_LP; }
     }
 }
+
+__global__ __launch_bounds__(TPB) void k_sqp_begin(DV d) { b_sqp_begin(d); }
 
 static __device__ void b_sqp_lp_finish(const DV &d)
 {
@@ -479,6 +487,21 @@ __global__ void k_sqp_count(DV d)
     }
 }
 
+// scenario queue: every slot starts "terminated, nothing to file" and draws its first scenario in the first sweep
+__global__ void k_sqp_stream_arm(DV d)
+{
+    for (int i = threadIdx.x; i < d.B; i += blockDim.x) {
+        d.sst[i].done = 1; d.sst[i].stage = ST_DONE; d.stream.slot_scen[i] = -2;
+    }
+}
+
+void sqp_stream_arm(Ctx &C)
+{
+    hipLaunchKernelGGL(k_sqp_reset, dim3(C.d.B), dim3(TPB), 0, C.stream, C.d);
+    hipLaunchKernelGGL(k_sqp_stream_arm, dim3(1), dim3(256), 0, C.stream, C.d);
+    SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+}
+
 void sqp_reset(Ctx &C)
 {
     hipLaunchKernelGGL(k_sqp_reset, dim3(C.d.B), dim3(TPB), 0, C.stream, C.d);
@@ -557,6 +580,49 @@ static void sqp_run_lane(Ctx &C, int max_outer)
     }
 }
 
+// Scenario queue (ctx.hpp StreamDev): a slot whose run has terminated files its result under its scenario id, takes the
+// next id, loads that scenario and runs the prologue of run! -- all inside the stage kernel of the sweep in which the
+// run ended, so the slot never idles while scenarios are left.
+static __device__ void b_sqp_stream(const DV &d)
+{
+    const int inst = blockIdx.x;
+    SQP_PTRS
+    const StreamDev &Q = d.stream;
+    const int cur = Q.slot_scen[inst];
+    const bool go = S.done && cur != -1;
+    __syncthreads();                 // gate read by every thread before any write
+    if (!go) return;
+    if (cur >= 0) {
+        double *rx = Q.rx + (long)cur * d.n;
+        for (int j = threadIdx.x; j < d.n; j += TPB) rx[j] = x[j];
+        if (threadIdx.x == 0) { Q.robj[cur] = S.obj_val; Q.rstat[cur] = S.ret; Q.riter[cur] = S.iter; }
+    }
+    __shared__ int nxt;
+    if (threadIdx.x == 0) nxt = atomicAdd(Q.next, 1);
+    __syncthreads();
+    const int sc = nxt;
+    if (sc >= Q.M) {
+        if (threadIdx.x == 0) Q.slot_scen[inst] = -1;
+        return;
+    }
+    {
+        double *xLw = d.xL + on, *xUw = d.xU + on, *gLw = d.gL + om, *gUw = d.gU + om, *x0w = d.x0 + on;
+        double *ohm = d.br_ohm + (long)inst * d.nl * 12, *c2 = d.c2 + (long)inst * d.ng, *c1 = d.c1 + (long)inst * d.ng;
+        const double *sxL = Q.xL + (long)sc * d.n, *sxU = Q.xU + (long)sc * d.n, *sx0 = Q.x0 + (long)sc * d.n;
+        const double *sgL = Q.gL + (long)sc * d.m, *sgU = Q.gU + (long)sc * d.m;
+        const double *so = Q.ohm + (long)sc * d.nl * 12, *s2 = Q.c2 + (long)sc * d.ng, *s1 = Q.c1 + (long)sc * d.ng;
+        for (int j = threadIdx.x; j < d.n; j += TPB) { xLw[j] = sxL[j]; xUw[j] = sxU[j]; x0w[j] = sx0[j]; }
+        for (int i = threadIdx.x; i < d.m; i += TPB) { gLw[i] = sgL[i]; gUw[i] = sgU[i]; }
+        for (int k = threadIdx.x; k < 12 * d.nl; k += TPB) ohm[k] = so[k];
+        for (int g = threadIdx.x; g < d.ng; g += TPB) { c2[g] = s2[g]; c1[g] = s1[g]; }
+    }
+    __syncthreads();
+    reset_instance(d, inst, true);
+    if (threadIdx.x == 0) Q.slot_scen[inst] = sc;
+    __syncthreads();
+    b_sqp_begin(d);
+}
+
 // SQP-level stages of a sweep in dependency order, one kernel (one workgroup owns one instance: its stages run one
 // after the other, a barrier in between publishes the stage word thread 0 wrote; every stage keeps its own gate)
 __global__ __launch_bounds__(TPB) void k_sqp_stage(DV d)
@@ -567,6 +633,7 @@ __global__ __launch_bounds__(TPB) void k_sqp_stage(DV d)
     __syncthreads();
     if (d.use_soc) { b_sqp_soc_finish(d); __syncthreads(); }
     b_sqp_top(d);
+    if (d.stream.M > 0) { __syncthreads(); b_sqp_stream(d); }
 }
 
 void sqp_stage_kernels(Ctx &C)          // called from ipm_sweep

@@ -352,6 +352,23 @@ class Context:
                                                 _d(b), _d(jc), _d(hc)))
         return dict(mode=mode.value, delta=delta.value, mu_pen=mu.value, x_k=xk, c=c, b=b, jac_coo=jc, hess_coo=hc)
 
+    # ---- scenario queue (more scenarios than slots)
+    def stream_begin(self, n_scenarios):
+        self._ck(self.L.sqphip_sqp_stream_begin(self.h, int(n_scenarios)))
+
+    def stream_set(self, scen, net, lay, x0=None):
+        self._ck(self.L.sqphip_sqp_stream_set(self.h, int(scen), _d(_f(lay.xL)), _d(_f(lay.xU)), _d(_f(lay.gL)), _d(_f(lay.gU)),
+                                              _d(_f(net.branch_coeffs().ravel())), _d(_f(net.c2)), _d(_f(net.c1)),
+                                              _d(_f(lay.x0 if x0 is None else x0))))
+
+    def stream_run(self):
+        self._ck(self.L.sqphip_sqp_stream_run(self.h))
+
+    def stream_get(self, scen):
+        x = np.zeros(self.n); obj = C.c_double(); st = C.c_int32(); it = C.c_int32()
+        self._ck(self.L.sqphip_sqp_stream_get(self.h, int(scen), _d(x), C.byref(obj), C.byref(st), C.byref(it)))
+        return dict(x=x, obj_val=obj.value, status=st.value, iter=it.value)
+
     def reset_counters(self):
         self._ck(self.L.sqphip_reset_counters(self.h))
 

@@ -1301,6 +1301,42 @@ def test_speculative_second_shift_changes_nothing_but_the_schedule(monkeypatch):
     assert got["1"][3] <= got["2"][3] < got["0"][3]
 
 
+@pytest.mark.parametrize("slots", [4, 64])
+def test_scenario_queue_gives_the_batch_results(slots):
+    """More scenarios than slots (sqphip_sqp_stream_*): 12 IEEE-14-shaped contingency scenarios through 4 slots (three
+    scenarios per slot, refilled on the device as runs terminate) and through 64 slots (more slots than scenarios: the
+    surplus slots find the queue empty) give, scenario by scenario, the status, iteration count, objective and final
+    point of the ordinary batched run, bit for bit; the work counters add up to the same totals."""
+    nb, ng, nl, seed = CASES["case14"]
+    base = acopf_synth(nb, ng, nl, seed)
+    M = 12
+    nets = [base] + [contingency(base, s, seed) for s in range(1, M)]
+    lays = [acopf_layout(nt) for nt in nets]
+    kw = dict(max_iter=60, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=0)
+    ctx = _run_batch(nets, lays, kw)
+    ref = [ctx.sqp_get(b) for b in range(M)]
+    tot = ctx.counters()
+    ctx.close()
+    q = pkg.Context(lays[0].n, lays[0].m, lays[0].num_linear, lays[0].jrow, lays[0].jcol, lays[0].hrow, lays[0].hcol,
+                    lays[0].xL, lays[0].xU, lays[0].gL, lays[0].gU, pkg.default_options(**kw), batch=slots)
+    q.acopf_attach(base, lays[0])
+    q.stream_begin(M)
+    for s in range(M):
+        q.stream_set(s, nets[s], lays[s])
+    q.stream_run()
+    for s in range(M):
+        r = q.stream_get(s)
+        assert (r["status"], r["iter"]) == (ref[s]["status"], ref[s]["iter"]), s
+        assert r["obj_val"] == ref[s]["obj_val"] and np.array_equal(r["x"], ref[s]["x"]), s
+    c = q.counters()
+    assert (c["n_qp"], c["n_ipm_iter"], c["n_factor"]) == (tot["n_qp"], tot["n_ipm_iter"], tot["n_factor"])
+    ret, it, done = q.sqp_status()
+    assert done.all()
+    q.stream_run()                                       # a second pass over the same queue: same results
+    assert q.stream_get(M - 1)["iter"] == ref[M - 1]["iter"]
+    q.close()
+
+
 def test_batch_of_eight_matches_oracle_instance_by_instance():
     """Batch 8 (XCD-aware tile map, eight concurrent stage workgroups): every instance against the oracle."""
     nb, ng, nl, seed = CASES["case14"]
