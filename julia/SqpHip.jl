@@ -156,6 +156,40 @@ function hip_gather_status(qp::QpHip, total::Integer)
     return ret, it, done
 end
 
+# ---- batched ACOPF runs on the device (include/sqphip.h; no reference counterpart): a context created with the structure
+# of the ACP or ACR layout, `hip_acopf_attach` (rectangular = true: ACRPowerModel, examples/acopf/opf.jl:46), per-instance
+# data, `hip_sqp_run`; or a scenario queue when there are more scenarios than slots ------------------------------------
+function hip_acopf_attach(ctx::Ptr{Cvoid}, nb, ng, nl, f_bus::Vector{Int32}, t_bus::Vector{Int32}, gen_bus::Vector{Int32},
+                          bal_ptr::Vector{Int32}, bal_colP::Vector{Int32}, bal_colQ::Vector{Int32},
+                          bal_coef::Vector{Float64}, ref_bus; rectangular::Bool = false)
+    args = (ctx, Int32(nb), Int32(ng), Int32(nl), f_bus, t_bus, gen_bus, bal_ptr, bal_colP, bal_colQ, bal_coef, Int32(ref_bus))
+    T = (Ptr{Cvoid}, Int32, Int32, Int32, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Cdouble}, Int32)
+    rc = rectangular ? ccall((:sqphip_acopf_attach_acr, LIBSQPHIP), Cint, T, args...) :
+                       ccall((:sqphip_acopf_attach, LIBSQPHIP), Cint, T, args...)
+    _check(ctx, rc)
+end
+hip_sqp_run(ctx::Ptr{Cvoid}, max_outer::Integer = 0) =
+    _check(ctx, ccall((:sqphip_sqp_run, LIBSQPHIP), Cint, (Ptr{Cvoid}, Int32), ctx, max_outer))
+hip_stream_begin(ctx::Ptr{Cvoid}, n_scenarios::Integer) =
+    _check(ctx, ccall((:sqphip_sqp_stream_begin, LIBSQPHIP), Cint, (Ptr{Cvoid}, Int32), ctx, n_scenarios))
+hip_stream_set(ctx::Ptr{Cvoid}, s::Integer, xL, xU, gL, gU, ohm, c2, c1, x0) =        # s is 0-based
+    _check(ctx, ccall((:sqphip_sqp_stream_set, LIBSQPHIP), Cint,
+                      (Ptr{Cvoid}, Int32, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
+                       Ptr{Cdouble}, Ptr{Cdouble}), ctx, s, xL, xU, gL, gU, ohm, c2, c1, x0))
+hip_stream_run(ctx::Ptr{Cvoid}) = _check(ctx, ccall((:sqphip_sqp_stream_run, LIBSQPHIP), Cint, (Ptr{Cvoid},), ctx))
+function hip_stream_get(ctx::Ptr{Cvoid}, s::Integer, n::Integer)
+    x = zeros(n); obj = Ref{Cdouble}(0.0); st = Ref{Cint}(0); it = Ref{Cint}(0)
+    _check(ctx, ccall((:sqphip_sqp_stream_get, LIBSQPHIP), Cint, (Ptr{Cvoid}, Int32, Ptr{Cdouble}, Ref{Cdouble}, Ref{Cint}, Ref{Cint}),
+                      ctx, s, x, obj, st, it))
+    return x, obj[], st[], it[]
+end
+# work of a batched run by instance (sub-problems, interior-point iterations, factorisations)
+function hip_sqp_work(ctx::Ptr{Cvoid}, batch::Integer)
+    qp, ipm, fac = zeros(Int64, batch), zeros(Int64, batch), zeros(Int64, batch)
+    _check(ctx, ccall((:sqphip_sqp_work, LIBSQPHIP), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}), ctx, qp, ipm, fac))
+    return qp, ipm, fac
+end
+
 # ---- dispatch: replaces the body of sub_optimize!(sqp) at sqp_trust_region.jl:314-331 when the user passes
 # `"external_optimizer" => SqpHipBackend` (optimizer_with_attributes(SqpSolver.Optimizer, ...)) --------------------------
 struct SqpHipBackend end
