@@ -519,7 +519,33 @@ __device__ __forceinline__ void mf_front_fwd_big(const DV &d, int inst, int s, d
         }
         __syncthreads();
     }
-    for (int i = nc + tid; i < fs; i += 256) {                    // rows below the supernode: the update for the ancestors
+    // rows below the supernode: the update for the ancestors, y_i - sum_k L_ik y_k.  A front has few such rows (tens) and
+    // many columns: one thread per row would walk nc dependent-latency loads while most of the workgroup idles, so eight
+    // column groups share a row (32 rows x 8 groups per pass) and their partial sums meet, in fixed order, in the LDS
+    // area the L11 image no longer needs.
+    if (Ls && nc >= 16) {
+        double *part = Ls;
+        const int r = tid & 31, kc = tid >> 5;
+        for (int rb = nc; rb < fs; rb += 32) {
+            const int i = rb + r;
+            double a = 0.0;
+            if (i < fs) {
+#pragma unroll 4
+                for (int k = kc; k < nc; k += 8) a += G[(long)k * ld + i] * y[k];
+            }
+            part[kc * 32 + r] = a;
+            __syncthreads();
+            if (kc == 0 && i < fs) {
+                double acc = y[i];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc -= part[q * 32 + r];
+                G[(long)i * ld + fs] = acc;
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    for (int i = nc + tid; i < fs; i += 256) {
         double acc = y[i];
 #pragma unroll 8
         for (int k = 0; k < nc; ++k) acc -= G[(long)k * ld + i] * y[k];
@@ -544,16 +570,17 @@ __device__ __forceinline__ void mf_front_bwd_big(const DV &d, int inst, int s, d
             for (int r = c + 1 + lane; r < nc; r += 64) Ls[c * nc + r] = G[(long)c * ld + r];
     for (int i = tid; i < fs; i += 256) x[i] = i < nc ? vv[i] : xg[rows[i - nc]];
     __syncthreads();
-    {   // x_cols -= L21' x_rows: column k by 16 threads, every column block independent of the others
-        const int c = tid >> 4, r = tid & 15;
-        for (int kb = 0; kb < nc; kb += 16) {
+    {   // x_cols -= L21' x_rows: column k by 8 threads, 32 columns per pass (a front has tens of rows below its columns:
+        // more columns in flight per pass matter more than longer coalesced runs), every column independent of the others
+        const int c = tid >> 3, r = tid & 7;
+        for (int kb = 0; kb < nc; kb += 32) {
             double a = 0.0;
             if (kb + c < nc) {
                 const double *Gc = G + (long)(kb + c) * ld;
 #pragma unroll 4
-                for (int i = nc + r; i < fs; i += 16) a += Gc[i] * x[i];
+                for (int i = nc + r; i < fs; i += 8) a += Gc[i] * x[i];
             }
-            a += __shfl_xor(a, 8); a += __shfl_xor(a, 4); a += __shfl_xor(a, 2); a += __shfl_xor(a, 1);
+            a += __shfl_xor(a, 4); a += __shfl_xor(a, 2); a += __shfl_xor(a, 1);
             if (r == 0 && kb + c < nc) x[kb + c] -= a;
         }
     }

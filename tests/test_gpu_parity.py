@@ -1368,9 +1368,7 @@ def test_subproblem_of_the_batched_run_replays_through_the_seat():
     """Diagnostics of the batched run (sqphip_sqp_work, _qp_log, _last_request): the per-instance work adds up to the
     counters, the sub-problem log lists every solve in order, and the last request of an instance -- fetched from the
     device and replayed through the drop-in seat sqphip_qp_solve of a fresh context and through the oracle's seat --
-    gives the logged status and iteration count again.  The run is cut after the iteration whose second-order
-    correction is the sub-problem that kept one instance of the bench busy for 200 iterations before corrections got
-    half the iteration limit (scenario 109 of the IEEE-118 set)."""
+    gives the logged status and iteration count again."""
     nb, ng, nl, seed = CASES["case118"]
     base = acopf_synth(nb, ng, nl, seed)
     ids = [109, 3]
@@ -1403,9 +1401,32 @@ def test_subproblem_of_the_batched_run_replays_through_the_seat():
         ro = _oracle_qp(None, S, O.default_options(**kw))(rq["mode"], rq["x_k"], rq["delta"], rq["mu_pen"], rq["c"],
                                                           rq["b"], rq["jac_coo"], rq["hess_coo"])
         assert ro["status"] == rg["status"] and abs(ro["ipm_iters"] - rg["ipm_iters"]) <= max(2, 0.2 * ro["ipm_iters"])
-    # scenario 109: the correction is abandoned at half the iteration limit
-    assert ctx.sqp_qp_log(0)[-1][:3] == (2, 11, opts.ipm_max_iter // 2)
     ctx.close()
+
+
+def test_cycling_correction_is_abandoned_at_half_the_iteration_limit():
+    """The sub-problem that made the rule (tests/golden/soc_cycling_subproblem.npz: the second-order correction of outer
+    iteration 6 of scenario 109 as the device ran it when it was found, fetched with sqphip_sqp_last_request by
+    scripts/gpu_dump_qp.py): a non-convex programme on which the regularised Newton iteration cycles.  As a correction
+    (mode 2) it stops at half the iteration limit with ITERATION_LIMIT, on the device and in the oracle; the same data
+    as an ordinary sub-problem (mode 0) gets the whole limit."""
+    D = np.load(os.path.join(GOLD, "soc_cycling_subproblem.npz"))
+    nb, ng, nl, seed = CASES["case118"]
+    net = contingency(acopf_synth(nb, ng, nl, seed), 109, seed)
+    lay = acopf_layout(net)
+    kw = dict(max_iter=3000, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=1)
+    opts = pkg.default_options(**kw)
+    assert int(D["mode"]) == 2
+    one = pkg.Context(lay.n, lay.m, lay.num_linear, lay.jrow, lay.jcol, lay.hrow, lay.hcol, lay.xL, lay.xU, lay.gL, lay.gU, opts)
+    S = dict(n=lay.n, m=lay.m, num_linear=lay.num_linear, jrow=lay.jrow, jcol=lay.jcol, hrow=lay.hrow, hcol=lay.hcol,
+             xL=lay.xL, xU=lay.xU, gL=lay.gL, gU=lay.gU)
+    oq = _oracle_qp(None, S, O.default_options(**kw))
+    for mode, limit in ((2, opts.ipm_max_iter // 2), (0, opts.ipm_max_iter)):
+        rg = one.qp_solve(mode, D["x_k"], float(D["delta"]), float(D["mu_pen"]), D["c"], D["b"], D["jac_coo"], D["hess_coo"])
+        ro = oq(mode, D["x_k"], float(D["delta"]), float(D["mu_pen"]), D["c"], D["b"], D["jac_coo"], D["hess_coo"])
+        assert (ro["status"], ro["ipm_iters"]) == (11, limit)
+        assert (rg["status"], rg["ipm_iters"]) == (11, limit)
+    one.close()
 
 
 def test_penalty_escalation_on_the_device():

@@ -190,3 +190,24 @@ def test_oracle_sparse_and_dense_linear_algebra_agree_on_a_whole_solve(quirks):
         assert abs(rd["n_ipm_iter"] - rs["n_ipm_iter"]) <= max(2, 0.02 * rd["n_ipm_iter"])
         tol = 1e-8 if rd["status"] == 0 else 1e-5
         assert np.abs(rd["x"] - rs["x"]).max() <= tol * max(1.0, np.abs(rd["x"]).max())
+
+
+def test_oracle_gives_a_cycling_correction_half_the_iteration_limit():
+    """tests/golden/soc_cycling_subproblem.npz (a second-order correction of the IEEE-118 workload on which the
+    regularised Newton iteration cycles; fetched from the device, see tests/test_gpu_parity.py): as a correction the
+    oracle stops at half of options.ipm_max_iter, as an ordinary sub-problem at the whole limit, both ITERATION_LIMIT --
+    the rule the product follows (include/sqphip.h, options.ipm_max_iter)."""
+    import os
+    from sqpsolver_jl_amd.acopf_synth import contingency
+    D = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "soc_cycling_subproblem.npz"))
+    nb, ng, nl, seed = CASES["case118"]
+    lay = acopf_layout(contingency(acopf_synth(nb, ng, nl, seed), 109, seed))
+    jcp, jrv, jslot, _ = O.coo_to_csc(lay.n, lay.jrow, lay.jcol)
+    hcp, hrv, hslot, hslot_t = O.coo_to_csc(lay.n, lay.hrow, lay.hcol, sym=True)
+    jv = np.zeros(len(jrv)); np.add.at(jv, jslot, D["jac_coo"])
+    hv = np.zeros(len(hrv)); np.add.at(hv, hslot, D["hess_coo"]); ok = hslot_t >= 0; np.add.at(hv, hslot_t[ok], D["hess_coo"][ok])
+    o = O.default_options(tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=1, num_threads=4, kkt_mode=2)
+    q = O.QpSolver(lay.n, lay.m, lay.num_linear, jcp, jrv, hcp, hrv, lay.xL, lay.xU, lay.gL, lay.gU, o)
+    for mode, limit in ((2, o.ipm_max_iter // 2), (0, o.ipm_max_iter)):
+        r = q.solve(mode, D["x_k"], float(D["delta"]), float(D["mu_pen"]), D["c"], D["b"], jv, hv)
+        assert (r["status"], r["ipm_iters"]) == (11, limit)
