@@ -52,9 +52,9 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="case118", choices=["case14", "case118", "case1354", "case9241"])
-    ap.add_argument("--formulation", default="polar", choices=["polar", "acr"],
-                    help="voltage coordinates of the ACOPF evaluator: polar (ACP, default) or rectangular (ACR, the one "
-                         "examples/acopf/opf.jl:46 runs)")
+    ap.add_argument("--formulation", default="polar", choices=["polar", "acr", "acwr"],
+                    help="ACOPF evaluator: polar (ACP, default), rectangular (ACR, the one examples/acopf/opf.jl:46 runs) "
+                         "or the W-space model of examples/acopf/acwr.jl")
     ap.add_argument("--batch", type=int, default=None, help="instances of the whole job (default 512 for case118)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-termination", action="store_true", help="skip the run-to-termination legs")
@@ -102,9 +102,9 @@ def main():
     dev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")   # collective buffers
 
     import sqpsolver_jl_amd as pkg
-    from sqpsolver_jl_amd.acopf_synth import acopf_synth, acopf_layout, acr_layout, contingency, CASES
-    if args.formulation == "acr":
-        acopf_layout = acr_layout
+    from sqpsolver_jl_amd.acopf_synth import acopf_synth, acopf_layout, acr_layout, acwr_layout, contingency, CASES
+    if args.formulation != "polar":
+        acopf_layout = {"acr": acr_layout, "acwr": acwr_layout}[args.formulation]
     from sqpsolver_jl_amd.shard import shard_range, gather_status
     from sqpsolver_jl_amd import _lib
 

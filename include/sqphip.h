@@ -244,6 +244,19 @@ int sqphip_acopf_attach_acr(sqphip_ctx *ctx, int32_t nb, int32_t ng, int32_t nl,
                             const int32_t *f_bus, const int32_t *t_bus, const int32_t *gen_bus,
                             const int32_t *bal_ptr, const int32_t *bal_colP, const int32_t *bal_colQ,
                             const double *bal_coef, int32_t ref_bus);
+/* ... and in the W-space form of /root/reference/examples/acopf/acwr.jl:1-37 (ACWRPowerModel over PowerModels' build_opf;
+ * defined by the reference, instantiated by none of its scripts): variables (vi, vr, w, wr, wi, pg, qg, flows, dc lines)
+ * with w_i = |v_i|^2 and wr, wi per bus pair i < j; balance, angle-difference (wi <= tan(angmax) wr, wi >= tan(angmin) wr)
+ * and Ohm rows linear in (w, wr, wi); constraint_model_voltage as nb + 2 nbp quadratic equalities; thermal limits.
+ * Structure: sqpsolver.jl_amd/acopf_synth.py acwr_layout.  bp_i / bp_j: the buses of pair k; br_bp / br_sig: pair and
+ * orientation (+1: from = i, -1: from = j) of branch l; bp_tmin / bp_tmax: tan of the pair's angle limits.  Shunts enter
+ * the (linear) balance rows through w: sqphip_acopf_set_shunts supplies them without changing the structure. */
+int sqphip_acopf_attach_acwr(sqphip_ctx *ctx, int32_t nb, int32_t ng, int32_t nl,
+                             const int32_t *f_bus, const int32_t *t_bus, const int32_t *gen_bus,
+                             const int32_t *bal_ptr, const int32_t *bal_colP, const int32_t *bal_colQ,
+                             const double *bal_coef, int32_t ref_bus, int32_t nbp, const int32_t *bp_i,
+                             const int32_t *bp_j, const int32_t *br_bp, const double *br_sig, const double *bp_tmin,
+                             const double *bp_tmax);
 /* Bus shunts (optional, after sqphip_acopf_attach): bus sh_bus[s] consumes gs[s] vm^2 of active and injects
  * bs[s] vm^2 of reactive power.  The context must have been created with the matching structure: two more Jacobian
  * COO entries (P row, Q row; column vm) and one more Hessian COO entry (vm, vm) per shunted bus at the END of the

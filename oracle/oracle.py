@@ -107,6 +107,8 @@ def lib():
             ctor.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, dp, ip, dp, dp,
                              ip, ip, ip, dp, C.c_int64, lp, lp, C.c_int64, lp, lp,
                              dp, dp, dp, dp, C.c_int, ip, dp, dp, C.c_int, dp]
+        L.ora_problem_acopf_acwr.restype = C.c_void_p
+        L.ora_problem_acopf_acwr.argtypes = L.ora_problem_acopf.argtypes + [C.c_int, ip, ip, ip, dp, dp, dp]
         L.ora_problem_nlp.restype = C.POINTER(Nlp)
         L.ora_problem_nlp.argtypes = [C.c_void_p]
         L.ora_problem_x0.restype = dp
@@ -248,13 +250,19 @@ def problem_acopf(net, lay):
     c2, c1, coef, xL, xU, gL, gU = args
     jr, jc, hr, hc = (np.ascontiguousarray(a, dtype=np.int64)
                       for a in (lay.jrow, lay.jcol, lay.hrow, lay.hcol))
-    ctor = lib().ora_problem_acopf_acr if getattr(lay, "form", "polar") == "acr" else lib().ora_problem_acopf
-    h = ctor(net.nb, net.ng, net.nl, _i(fb), _i(tb), _d(ohm),
-                                _i(gb), _d(c2), _d(c1), _i(bp), _i(bcp), _i(bcq), _d(coef),
-                                len(jr), _l(jr), _l(jc), len(hr), _l(hr), _l(hc),
-                                _d(xL), _d(xU), _d(gL), _d(gU), len(lay.sh_bus),
-                                _i(np.ascontiguousarray(lay.sh_bus, dtype=np.int32)), _d(f64(lay.sh_gs)), _d(f64(lay.sh_bs)),
-                                len(lay.dc_loss1), _d(f64(lay.dc_loss1)))
+    form = getattr(lay, "form", "polar")
+    common = (net.nb, net.ng, net.nl, _i(fb), _i(tb), _d(ohm),
+              _i(gb), _d(c2), _d(c1), _i(bp), _i(bcp), _i(bcq), _d(coef),
+              len(jr), _l(jr), _l(jc), len(hr), _l(hr), _l(hc),
+              _d(xL), _d(xU), _d(gL), _d(gU), len(lay.sh_bus),
+              _i(np.ascontiguousarray(lay.sh_bus, dtype=np.int32)), _d(f64(lay.sh_gs)), _d(f64(lay.sh_bs)),
+              len(lay.dc_loss1), _d(f64(lay.dc_loss1)))
+    if form == "acwr":
+        bpi, bpj, brb = (np.ascontiguousarray(a, dtype=np.int32) for a in (lay.bp_i, lay.bp_j, lay.br_bp))
+        h = lib().ora_problem_acopf_acwr(*common, len(bpi), _i(bpi), _i(bpj), _i(brb), _d(f64(lay.br_sig)),
+                                         _d(f64(lay.bp_tmin)), _d(f64(lay.bp_tmax)))
+    else:
+        h = (lib().ora_problem_acopf_acr if form == "acr" else lib().ora_problem_acopf)(*common)
     return Problem(h, x0=lay.x0)
 
 

@@ -20,6 +20,8 @@ struct ora_problem {
     int ndc; double *dc_loss1;    /* HVDC lines: variables p_f, p_t, q_f, q_t behind all others, one loss row each at the end */
     int nsh; int32_t *sh_bus; double *sh_gs, *sh_bs;   /* bus shunts: + gs vm^2 (P row), - bs vm^2 (Q row) */
     double *ohm, *c2, *c1, *bal_coef;      /* ohm[nl][12]: (A, Bc, Bs) of p_f, q_f, p_t, q_t per branch */
+    /* W-space form (acwr): bus pairs i < j, pair and orientation of every branch, tan of the pairs' angle limits, shunts per bus */
+    int nbp; int32_t *bp_i, *bp_j, *br_bp; double *br_sig, *bp_tmin, *bp_tmax, *gsb, *bsb;
 };
 
 static int64_t *i64dup(const int64_t *s, int64_t k)
@@ -52,7 +54,8 @@ void ora_problem_destroy(ora_problem *P)
     if (!P) return;
     void *ptrs[] = { P->x0, P->jrow, P->jcol, P->hrow, P->hcol, P->xL, P->xU, P->gL, P->gU,
         P->f_bus, P->t_bus, P->gen_bus, P->bal_ptr, P->bal_colP, P->bal_colQ, P->ohm,
-        P->c2, P->c1, P->bal_coef, P->sh_bus, P->sh_gs, P->sh_bs, P->dc_loss1 };
+        P->c2, P->c1, P->bal_coef, P->sh_bus, P->sh_gs, P->sh_bs, P->dc_loss1,
+        P->bp_i, P->bp_j, P->br_bp, P->br_sig, P->bp_tmin, P->bp_tmax, P->gsb, P->bsb };
     for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) free(ptrs[i]);
     free(P);
 }
@@ -441,5 +444,146 @@ ora_problem *ora_problem_acopf_acr(int nb, int ng, int nl, const int32_t *f_bus,
     P->c2 = ddup(c2, ng); P->c1 = ddup(c1, ng);
     P->nlp.eval_f = ac_f; P->nlp.eval_grad_f = ac_df; P->nlp.eval_g = acr_g;
     P->nlp.eval_jac_g = acr_jac; P->nlp.eval_h = acr_h;
+    return P;
+}
+
+/* ------------------------------------------------------------------ ACOPF, W-space form (ACWR) */
+/* /root/reference/examples/acopf/acwr.jl:1-37 over PowerModels' build_opf, laid out by sqpsolver.jl_amd/acopf_synth.py
+ * acwr_layout: x = (vi, vr, w, wr, wi, pg, qg, flows, dc); every constraint of the W-R model is linear in (w, wr, wi)
+ * and constraint_model_voltage ties them to (vr, vi) by nb + 2 nbp quadratic equalities. */
+#define WIDX(P) \
+    const int nb = (P)->nb, ng = (P)->ng, nl = (P)->nl, nbp = (P)->nbp; \
+    const int VI = 0, VR = nb, W = 2 * nb, WR = 3 * nb, WI = 3 * nb + nbp, PG = 3 * nb + 2 * nbp, PF = PG + 2 * ng; \
+    const int PT = PF + nl, QF = PF + 2 * nl, QT = PF + 3 * nl; \
+    const int A0 = 1 + 2 * nb, O0 = A0 + 2 * nbp, V0 = O0 + 4 * nl, T0 = V0 + nb + 2 * nbp, D0 = T0 + 2 * nl; \
+    (void)VI; (void)VR; (void)W; (void)WR; (void)WI; (void)PG; (void)PT; (void)QF; (void)QT; (void)A0; (void)O0; (void)V0; \
+    (void)T0; (void)D0; (void)ng;
+
+static double wr_f(void *u, const double *x)
+{
+    const ora_problem *P = (const ora_problem *)u; WIDX(P)
+    double f = 0.0;
+    for (int g = 0; g < ng; ++g) f += P->c2[g] * x[PG + g] * x[PG + g] + P->c1[g] * x[PG + g];
+    return f;
+}
+static void wr_df(void *u, const double *x, double *gr)
+{
+    const ora_problem *P = (const ora_problem *)u; WIDX(P)
+    memset(gr, 0, sizeof(double) * (size_t)P->nlp.n);
+    for (int g = 0; g < ng; ++g) gr[PG + g] = 2 * P->c2[g] * x[PG + g] + P->c1[g];
+}
+static void wr_g(void *u, const double *x, double *gv)
+{
+    const ora_problem *P = (const ora_problem *)u; WIDX(P)
+    const int own[4] = { PF, QF, PT, QT };
+    gv[0] = x[VI + P->ref_bus];
+    for (int i = 0; i < nb; ++i) {
+        double sp = 0.0, sq = 0.0;
+        for (int k = P->bal_ptr[i]; k < P->bal_ptr[i + 1]; ++k) {
+            sp += P->bal_coef[k] * x[P->bal_colP[k]];
+            sq += P->bal_coef[k] * x[P->bal_colQ[k]];
+        }
+        gv[1 + 2 * i] = sp + P->gsb[i] * x[W + i]; gv[2 + 2 * i] = sq - P->bsb[i] * x[W + i];
+        gv[V0 + i] = x[W + i] - x[VR + i] * x[VR + i] - x[VI + i] * x[VI + i];
+    }
+    for (int k = 0; k < nbp; ++k) {
+        const int i = P->bp_i[k], j = P->bp_j[k];
+        gv[A0 + 2 * k] = x[WI + k] - P->bp_tmax[k] * x[WR + k];
+        gv[A0 + 2 * k + 1] = x[WI + k] - P->bp_tmin[k] * x[WR + k];
+        gv[V0 + nb + 2 * k] = x[WR + k] - (x[VR + i] * x[VR + j] + x[VI + i] * x[VI + j]);
+        gv[V0 + nb + 2 * k + 1] = x[WI + k] - (x[VI + i] * x[VR + j] - x[VR + i] * x[VI + j]);
+    }
+    for (int l = 0; l < nl; ++l) {
+        gv[T0 + 2 * l] = x[PF + l] * x[PF + l] + x[QF + l] * x[QF + l];
+        gv[T0 + 2 * l + 1] = x[PT + l] * x[PT + l] + x[QT + l] * x[QT + l];
+        const int k = P->br_bp[l]; const double sg = P->br_sig[l];
+        for (int c = 0; c < 4; ++c) {
+            double A, Bc, Bs; int st; ohm_coef(P, l, c, &A, &Bc, &Bs, &st);
+            const double ws = x[W + (st ? P->t_bus[l] : P->f_bus[l])];
+            gv[O0 + 4 * l + c] = x[own[c] + l] - (A * ws + Bc * x[WR + k] + sg * Bs * x[WI + k]);
+        }
+    }
+    for (int d = 0; d < P->ndc; ++d)
+        gv[D0 + d] = (1.0 - P->dc_loss1[d]) * x[PF + 4 * nl + d] + x[PF + 4 * nl + P->ndc + d];
+}
+static void wr_jac(void *u, const double *x, double *v)
+{
+    const ora_problem *P = (const ora_problem *)u; WIDX(P)
+    int64_t o = 0;
+    v[o++] = 1.0;
+    for (int i = 0; i < nb; ++i) {
+        int s = P->bal_ptr[i], e = P->bal_ptr[i + 1];
+        for (int k = s; k < e; ++k) v[o++] = P->bal_coef[k];
+        for (int k = s; k < e; ++k) v[o++] = P->bal_coef[k];
+    }
+    for (int i = 0; i < nb; ++i) { v[o++] = P->gsb[i]; v[o++] = -P->bsb[i]; }
+    for (int k = 0; k < nbp; ++k) { v[o++] = 1.0; v[o++] = -P->bp_tmax[k]; }
+    for (int k = 0; k < nbp; ++k) { v[o++] = 1.0; v[o++] = -P->bp_tmin[k]; }
+    for (int c = 0; c < 4; ++c)
+        for (int l = 0; l < nl; ++l) {
+            double A, Bc, Bs; int st; ohm_coef(P, l, c, &A, &Bc, &Bs, &st);
+            v[o++] = 1.0; v[o++] = -A; v[o++] = -Bc; v[o++] = -P->br_sig[l] * Bs;
+        }
+    for (int i = 0; i < nb; ++i) { v[o++] = 1.0; v[o++] = -2 * x[VR + i]; v[o++] = -2 * x[VI + i]; }
+    for (int k = 0; k < nbp; ++k) {
+        const int i = P->bp_i[k], j = P->bp_j[k];
+        v[o++] = 1.0; v[o++] = -x[VR + j]; v[o++] = -x[VR + i]; v[o++] = -x[VI + j]; v[o++] = -x[VI + i];
+    }
+    for (int k = 0; k < nbp; ++k) {
+        const int i = P->bp_i[k], j = P->bp_j[k];
+        v[o++] = 1.0; v[o++] = -x[VR + j]; v[o++] = -x[VI + i]; v[o++] = x[VI + j]; v[o++] = x[VR + i];
+    }
+    for (int l = 0; l < nl; ++l) { v[o++] = 2 * x[PF + l]; v[o++] = 2 * x[QF + l]; }
+    for (int l = 0; l < nl; ++l) { v[o++] = 2 * x[PT + l]; v[o++] = 2 * x[QT + l]; }
+    for (int d = 0; d < P->ndc; ++d) { v[o++] = 1.0 - P->dc_loss1[d]; v[o++] = 1.0; }
+}
+static void wr_h(void *u, const double *x, double sig, const double *lam, double *v)
+{
+    const ora_problem *P = (const ora_problem *)u; WIDX(P)
+    (void)x;
+    int64_t o = 0;
+    for (int g = 0; g < ng; ++g) v[o++] = sig * 2 * P->c2[g];
+    for (int l = 0; l < nl; ++l) { double w = 2 * lam[T0 + 2 * l]; v[o++] = w; v[o++] = w; }
+    for (int l = 0; l < nl; ++l) { double w = 2 * lam[T0 + 2 * l + 1]; v[o++] = w; v[o++] = w; }
+    for (int i = 0; i < nb; ++i) { double w = -2 * lam[V0 + i]; v[o++] = w; v[o++] = w; }
+    for (int k = 0; k < nbp; ++k) { double w = -lam[V0 + nb + 2 * k]; v[o++] = w; v[o++] = w; }
+    for (int k = 0; k < nbp; ++k) { double w = lam[V0 + nb + 2 * k + 1]; v[o++] = -w; v[o++] = w; }
+}
+
+ora_problem *ora_problem_acopf_acwr(int nb, int ng, int nl, const int32_t *f_bus,
+                                    const int32_t *t_bus, const double *ohm,
+                                    const int32_t *gen_bus, const double *c2,
+                                    const double *c1, const int32_t *bal_ptr, const int32_t *bal_colP,
+                                    const int32_t *bal_colQ, const double *bal_coef,
+                                    int64_t nnzj, const int64_t *jrow, const int64_t *jcol,
+                                    int64_t nnzh, const int64_t *hrow, const int64_t *hcol,
+                                    const double *xL, const double *xU, const double *gL,
+                                    const double *gU, int nsh, const int32_t *sh_bus, const double *sh_gs,
+                                    const double *sh_bs, int ndc, const double *dc_loss1,
+                                    int nbp, const int32_t *bp_i, const int32_t *bp_j, const int32_t *br_bp,
+                                    const double *br_sig, const double *bp_tmin, const double *bp_tmax)
+{
+    int64_t n = 3 * nb + 2 * nbp + 2 * ng + 4 * nl + 4 * ndc;
+    int64_t m = 1 + 2 * nb + 2 * nbp + 4 * nl + nb + 2 * nbp + 2 * nl + ndc;
+    double *x0 = (double *)calloc((size_t)n, sizeof(double));
+    ora_problem *P = mk(n, m, 1 + 2 * nb + 2 * nbp + 4 * nl, nnzj, jrow, jcol, nnzh, hrow, hcol, xL, xU, gL, gU, x0);
+    free(x0);
+    P->nb = nb; P->ng = ng; P->nl = nl; P->nbp = nbp;
+    P->ref_bus = (int)(jcol[0] - 1);
+    P->f_bus = i32dup(f_bus, nl); P->t_bus = i32dup(t_bus, nl); P->gen_bus = i32dup(gen_bus, ng);
+    P->bal_ptr = i32dup(bal_ptr, nb + 1);
+    int64_t nbal = bal_ptr[nb];
+    P->bal_colP = i32dup(bal_colP, nbal); P->bal_colQ = i32dup(bal_colQ, nbal);
+    P->bal_coef = ddup(bal_coef, nbal);
+    P->ohm = ddup(ohm, 12 * (int64_t)nl);
+    P->ndc = ndc; P->dc_loss1 = ddup(dc_loss1, ndc);
+    P->nsh = nsh; P->sh_bus = i32dup(sh_bus, nsh); P->sh_gs = ddup(sh_gs, nsh); P->sh_bs = ddup(sh_bs, nsh);
+    P->gsb = (double *)calloc((size_t)nb, sizeof(double)); P->bsb = (double *)calloc((size_t)nb, sizeof(double));
+    for (int s = 0; s < nsh; ++s) { P->gsb[sh_bus[s]] = sh_gs[s]; P->bsb[sh_bus[s]] = sh_bs[s]; }
+    P->bp_i = i32dup(bp_i, nbp); P->bp_j = i32dup(bp_j, nbp); P->br_bp = i32dup(br_bp, nl);
+    P->br_sig = ddup(br_sig, nl); P->bp_tmin = ddup(bp_tmin, nbp); P->bp_tmax = ddup(bp_tmax, nbp);
+    P->c2 = ddup(c2, ng); P->c1 = ddup(c1, ng);
+    P->nlp.eval_f = wr_f; P->nlp.eval_grad_f = wr_df; P->nlp.eval_g = wr_g;
+    P->nlp.eval_jac_g = wr_jac; P->nlp.eval_h = wr_h;
     return P;
 }

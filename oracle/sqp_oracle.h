@@ -221,6 +221,19 @@ ora_problem *ora_problem_acopf_acr(int nb, int ng, int nl, const int32_t *f_bus,
                                const double *xL, const double *xU, const double *gL,
                                const double *gU, int nsh, const int32_t *sh_bus, const double *sh_gs,
                                const double *sh_bs, int ndc, const double *dc_loss1);
+/* ... and in the W-space form of examples/acopf/acwr.jl (acopf_synth.py, acwr_layout) */
+ora_problem *ora_problem_acopf_acwr(int nb, int ng, int nl, const int32_t *f_bus,
+                               const int32_t *t_bus, const double *ohm /* [nl][12] */,
+                               const int32_t *gen_bus, const double *c2,
+                               const double *c1, const int32_t *bal_ptr, const int32_t *bal_colP,
+                               const int32_t *bal_colQ, const double *bal_coef,
+                               int64_t nnzj, const int64_t *jrow, const int64_t *jcol,
+                               int64_t nnzh, const int64_t *hrow, const int64_t *hcol,
+                               const double *xL, const double *xU, const double *gL,
+                               const double *gU, int nsh, const int32_t *sh_bus, const double *sh_gs,
+                               const double *sh_bs, int ndc, const double *dc_loss1,
+                                    int nbp, const int32_t *bp_i, const int32_t *bp_j, const int32_t *br_bp,
+                                    const double *br_sig, const double *bp_tmin, const double *bp_tmax);
 const ora_nlp *ora_problem_nlp(const ora_problem *p);
 const double *ora_problem_x0(const ora_problem *p);
 void ora_problem_destroy(ora_problem *p);

@@ -28,7 +28,7 @@ from __future__ import annotations
 import dataclasses
 import numpy as np
 
-__all__ = ["Network", "acopf_synth", "contingency", "renumber_buses", "NlpLayout", "acopf_layout", "acr_layout",
+__all__ = ["Network", "acopf_synth", "contingency", "renumber_buses", "NlpLayout", "acopf_layout", "acr_layout", "acwr_layout",
            "CASES"]
 
 # nb, ng, nl per SURVEY.md section 8 table
@@ -290,7 +290,15 @@ class NlpLayout:
     sh_gs: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(0))
     sh_bs: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(0))
     dc_loss1: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(0))   # per dc line (empty: none)
-    form: str = "polar"   # "polar" (ACPPowerModel, acopf_layout) or "acr" (ACRPowerModel, acr_layout)
+    form: str = "polar"   # "polar" (ACPPowerModel, acopf_layout), "acr" (ACRPowerModel, acr_layout), "acwr" (acwr_layout)
+    # W-space form only: bus pairs (i < j), the pair and orientation (+1: from = i) of every branch, tan of the pair's
+    # angle limits (coefficients of the linear angle rows)
+    bp_i: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(0, dtype=np.int32))
+    bp_j: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(0, dtype=np.int32))
+    br_bp: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(0, dtype=np.int32))
+    br_sig: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(0))
+    bp_tmin: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(0))
+    bp_tmax: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(0))
 
 
 def acopf_layout(net: Network) -> NlpLayout:
@@ -547,3 +555,143 @@ def acr_layout(net: Network) -> NlpLayout:
                      bal_coef=np.asarray(coef), sh_bus=sh_bus, sh_gs=sh_gs, sh_bs=sh_bs,
                      dc_loss1=(np.zeros(0) if ndc == 0 else np.asarray(net.dcline["loss1"], dtype=np.float64)),
                      form="acr")
+
+
+def acwr_layout(net: Network) -> NlpLayout:
+    """The W-space model of /root/reference/examples/acopf/acwr.jl:1-37 (`ACWRPowerModel <: AbstractWRModel`, built by
+    `build_acwr` with PowerModels' own `build_opf`): the lifted variables w_i = |v_i|^2, wr_ij, wi_ij of the W-R
+    formulation carry every constraint linearly, and `constraint_model_voltage` ties them to rectangular voltages:
+
+    variables  vi[nb], vr[nb] (free; start vr = 1), w[nb] in [vmin^2, vmax^2] (start 1.001), wr[nbp] (start 1), wi[nbp]
+               per bus pair (i < j) within PowerModels' voltage-product bounds, pg, qg, p_f, p_t, q_f, q_t, dc lines
+    rows       0                 vi[ref] = 0   (WR models have no reference constraint; kept so that the rotation of
+                                 (vr, vi) -- which no other row sees -- does not leave the Newton matrix singular)
+               1 .. 2 nb         power balance with the shunt terms gs w_i, -bs w_i            (linear)
+               A0 + 2 k, +1      wi_k - tan(angmax_k) wr_k <= 0,  wi_k - tan(angmin_k) wr_k >= 0   (linear)
+               O0 + 4 l + c      flow_c - (A w_self + Bc wr + sigma Bs wi) = 0                     (linear)
+               V0 + i            w_i - vr_i^2 - vi_i^2 = 0
+               V0 + nb + 2 k, +1 wr_k - (vr_i vr_j + vi_i vi_j) = 0,  wi_k - (vi_i vr_j - vr_i vi_j) = 0
+               T0 + 2 l, +1      thermal limits
+               D0 + d            dc-line loss rows
+    sigma = +1 when the branch runs from i to j of its pair, -1 otherwise (wi changes sign with the orientation)."""
+    nb, ng, nl, ndc = net.nb, net.ng, net.nl, net.ndc
+    f, t = net.f_bus.astype(np.int64), net.t_bus.astype(np.int64)
+    lo, hi = np.minimum(f, t), np.maximum(f, t)
+    key = lo * nb + hi
+    uniq, br_bp = np.unique(key, return_inverse=True)
+    nbp = len(uniq)
+    bp_i, bp_j = uniq // nb, uniq % nb
+    sig = np.where(f == lo, 1.0, -1.0)
+    # angle limits of a pair in its own orientation: the tightest over its branches
+    amin = np.full(nbp, -np.inf); amax = np.full(nbp, np.inf)
+    for l in range(nl):
+        a, b = (net.angmin[l], net.angmax[l]) if sig[l] > 0 else (-net.angmax[l], -net.angmin[l])
+        amin[br_bp[l]] = max(amin[br_bp[l]], a); amax[br_bp[l]] = min(amax[br_bp[l]], b)
+    VI, VR, W, WR, WI = 0, nb, 2 * nb, 3 * nb, 3 * nb + nbp
+    PG = 3 * nb + 2 * nbp
+    QG, PF = PG + ng, PG + 2 * ng
+    PT, QF, QT = PF + nl, PF + 2 * nl, PF + 3 * nl
+    DC = PF + 4 * nl
+    n = DC + 4 * ndc
+    A0 = 1 + 2 * nb
+    O0 = A0 + 2 * nbp
+    V0 = O0 + 4 * nl
+    T0 = V0 + nb + 2 * nbp
+    D0 = T0 + 2 * nl
+    m = D0 + ndc
+    L = np.arange(nl, dtype=np.int64); I = np.arange(nb, dtype=np.int64); K = np.arange(nbp, dtype=np.int64)
+
+    jr, jc = [np.array([0])], [np.array([VI + net.ref_bus])]
+    inc = [[] for _ in range(nb)]
+    for l in range(nl):
+        inc[int(f[l])].append((PF + l, QF + l, 1.0))
+        inc[int(t[l])].append((PT + l, QT + l, 1.0))
+    for g in range(ng):
+        inc[int(net.gen_bus[g])].append((PG + g, QG + g, -1.0))
+    for d in range(ndc):
+        inc[int(net.dcline["f_bus"][d])].append((DC + d, DC + 2 * ndc + d, 1.0))
+        inc[int(net.dcline["t_bus"][d])].append((DC + ndc + d, DC + 3 * ndc + d, 1.0))
+    bal_ptr = np.zeros(nb + 1, dtype=np.int32)
+    colP, colQ, coef = [], [], []
+    for i in range(nb):
+        bal_ptr[i + 1] = bal_ptr[i] + len(inc[i])
+        for cp, cq, cf in inc[i]:
+            colP.append(cp); colQ.append(cq); coef.append(cf)
+    colP = np.asarray(colP, dtype=np.int64); colQ = np.asarray(colQ, dtype=np.int64)
+    for i in range(nb):
+        s_, e = bal_ptr[i], bal_ptr[i + 1]
+        jr.append(np.full(e - s_, 1 + 2 * i)); jc.append(colP[s_:e])
+        jr.append(np.full(e - s_, 2 + 2 * i)); jc.append(colQ[s_:e])
+    # shunt terms of the balance rows: (P row, w_i), (Q row, w_i) for every bus (coefficient 0 without a shunt)
+    jr.append(np.stack([1 + 2 * I, 2 + 2 * I], 1).ravel()); jc.append(np.repeat(W + I, 2))
+    # angle rows: (wi, wr) each
+    jr.append(np.repeat(A0 + 2 * K, 2)); jc.append(np.stack([WI + K, WR + K], 1).ravel())
+    jr.append(np.repeat(A0 + 2 * K + 1, 2)); jc.append(np.stack([WI + K, WR + K], 1).ravel())
+    # Ohm rows, kind-major like the other layouts: (own, w_self, wr, wi)
+    own = [PF, QF, PT, QT]
+    for c in range(4):
+        ws = W + (f if c < 2 else t)
+        jr.append(np.repeat(O0 + 4 * L + c, 4)); jc.append(np.stack([own[c] + L, ws, WR + br_bp, WI + br_bp], 1).ravel())
+    # model-voltage rows
+    jr.append(np.repeat(V0 + I, 3)); jc.append(np.stack([W + I, VR + I, VI + I], 1).ravel())
+    jr.append(np.repeat(V0 + nb + 2 * K, 5)); jc.append(np.stack([WR + K, VR + bp_i, VR + bp_j, VI + bp_i, VI + bp_j], 1).ravel())
+    jr.append(np.repeat(V0 + nb + 2 * K + 1, 5)); jc.append(np.stack([WI + K, VI + bp_i, VR + bp_j, VR + bp_i, VI + bp_j], 1).ravel())
+    jr.append(np.repeat(T0 + 2 * L, 2)); jc.append(np.stack([PF + L, QF + L], 1).ravel())
+    jr.append(np.repeat(T0 + 2 * L + 1, 2)); jc.append(np.stack([PT + L, QT + L], 1).ravel())
+    if ndc:
+        D = np.arange(ndc, dtype=np.int64)
+        jr.append(np.repeat(D0 + D, 2)); jc.append(np.stack([DC + D, DC + ndc + D], 1).ravel())
+    jrow = np.concatenate(jr).astype(np.int64) + 1
+    jcol = np.concatenate(jc).astype(np.int64) + 1
+
+    hr, hc = [], []
+    G = np.arange(ng, dtype=np.int64)
+    hr.append(PG + G); hc.append(PG + G)
+    for base_p, base_q in ((PF, QF), (PT, QT)):
+        hr.append(np.stack([base_p + L, base_q + L], 1).ravel()); hc.append(np.stack([base_p + L, base_q + L], 1).ravel())
+    hr.append(np.stack([VR + I, VI + I], 1).ravel()); hc.append(np.stack([VR + I, VI + I], 1).ravel())          # w rows
+    hr.append(np.stack([VR + bp_j, VI + bp_j], 1).ravel()); hc.append(np.stack([VR + bp_i, VI + bp_i], 1).ravel())  # wr rows (j > i)
+    hr.append(np.stack([VR + bp_j, VR + bp_i], 1).ravel()); hc.append(np.stack([VI + bp_i, VI + bp_j], 1).ravel())  # wi rows
+    hrow = np.concatenate(hr).astype(np.int64) + 1
+    hcol = np.concatenate(hc).astype(np.int64) + 1
+    assert (hrow >= hcol).all()
+
+    inf = np.inf
+    vmin, vmax = net.vmin, net.vmax
+    lo_ij, hi_ij = vmin[bp_i] * vmin[bp_j], vmax[bp_i] * vmax[bp_j]
+    cmin = np.minimum(np.cos(amin), np.cos(amax))
+    wr_min = np.where(amin >= 0, lo_ij * np.cos(amax), np.where(amax <= 0, lo_ij * np.cos(amin), lo_ij * cmin))
+    wr_max = np.where(amin >= 0, hi_ij * np.cos(amin), np.where(amax <= 0, hi_ij * np.cos(amax), hi_ij))
+    wi_min = np.where(amin >= 0, lo_ij * np.sin(amin), hi_ij * np.sin(amin))
+    wi_max = np.where(amax <= 0, lo_ij * np.sin(amax), hi_ij * np.sin(amax))
+    xL = np.concatenate([np.full(2 * nb, -inf), vmin ** 2, wr_min, wi_min, net.pmin, net.qmin,
+                         -net.rate_a, -net.rate_a, -net.rate_a, -net.rate_a])
+    xU = np.concatenate([np.full(2 * nb, inf), vmax ** 2, wr_max, wi_max, net.pmax, net.qmax,
+                         net.rate_a, net.rate_a, net.rate_a, net.rate_a])
+    if ndc:
+        dc = net.dcline
+        a = dc["loss0"] - (1.0 - dc["loss1"]) * dc["pmaxf"]; b = dc["loss0"] - (1.0 - dc["loss1"]) * dc["pminf"]
+        xL = np.concatenate([xL, dc["pminf"], np.minimum(a, b), dc["qminf"], dc["qmint"]])
+        xU = np.concatenate([xU, dc["pmaxf"], np.maximum(a, b), dc["qmaxf"], dc["qmaxt"]])
+    gL = np.empty(m); gU = np.empty(m)
+    gL[0] = gU[0] = 0.0
+    gL[1:A0:2] = -net.pd; gU[1:A0:2] = -net.pd
+    gL[2:A0:2] = -net.qd; gU[2:A0:2] = -net.qd
+    gL[A0:O0:2] = -inf; gU[A0:O0:2] = 0.0
+    gL[A0 + 1:O0:2] = 0.0; gU[A0 + 1:O0:2] = inf
+    gL[O0:T0] = 0.0; gU[O0:T0] = 0.0
+    gL[T0:D0] = -inf
+    gU[T0:D0:2] = net.rate_a ** 2; gU[T0 + 1:D0:2] = net.rate_a ** 2
+    if ndc:
+        gL[D0:] = net.dcline["loss0"]; gU[D0:] = net.dcline["loss0"]
+    boxed = np.isfinite(xL) & np.isfinite(xU)
+    x0 = np.zeros(n)
+    x0[boxed] = 0.5 * (xL[boxed] + xU[boxed])
+    x0[VI:VI + nb] = 0.0; x0[VR:VR + nb] = 1.0; x0[W:W + nb] = 1.001; x0[WR:WR + nbp] = 1.0; x0[WI:WI + nbp] = 0.0
+    sh_bus, sh_gs, sh_bs = net.shunts()
+    return NlpLayout(n=n, m=m, num_linear=V0, jrow=jrow, jcol=jcol, hrow=hrow, hcol=hcol, xL=xL, xU=xU, gL=gL, gU=gU, x0=x0,
+                     bal_ptr=bal_ptr, bal_colP=colP.astype(np.int32), bal_colQ=colQ.astype(np.int32),
+                     bal_coef=np.asarray(coef), sh_bus=sh_bus, sh_gs=sh_gs, sh_bs=sh_bs,
+                     dc_loss1=(np.zeros(0) if ndc == 0 else np.asarray(net.dcline["loss1"], dtype=np.float64)),
+                     form="acwr", bp_i=bp_i.astype(np.int32), bp_j=bp_j.astype(np.int32), br_bp=br_bp.astype(np.int32),
+                     br_sig=sig, bp_tmin=np.tan(amin), bp_tmax=np.tan(amax))

@@ -144,12 +144,128 @@ static __device__ void acr_eval(const DV &d, int inst, const double *__restrict_
     }
 }
 
+// W-space form (/root/reference/examples/acopf/acwr.jl:1-37 over PowerModels' build_opf; layout: acopf_synth.py
+// acwr_layout): x = (vi, vr, w, wr, wi, pg, qg, flows, dc lines).  Balance, angle-difference and Ohm rows are linear in
+// (w, wr, wi) -- their Jacobian entries are constants of the instance --, constraint_model_voltage ties the lifted
+// variables to the rectangular voltages: w_i = vr_i^2 + vi_i^2, wr_k = vr_i vr_j + vi_i vi_j, wi_k = vi_i vr_j - vr_i vi_j.
+static __device__ void acwr_eval(const DV &d, int inst, const double *__restrict__ x, double sigma,
+                          const double *__restrict__ lam, double *f_out, double *grad, double *gv,
+                          double *jv, double *hv)
+{
+    const int nb = d.nb, ng = d.ng, nl = d.nl, nbp = d.nbp;
+    const int VI = 0, VR = nb, W = 2 * nb, WR = 3 * nb, WI = 3 * nb + nbp, PG = 3 * nb + 2 * nbp, PF = PG + 2 * ng;
+    const int PT = PF + nl, QF = PF + 2 * nl, QT = PF + 3 * nl, DCV = PF + 4 * nl;
+    const int A0 = 1 + 2 * nb, O0 = A0 + 2 * nbp, V0 = O0 + 4 * nl, T0 = V0 + nb + 2 * nbp, D0 = T0 + 2 * nl;
+    const int nbal = d.bal_ptr[nb];
+    const int JS = 1 + 2 * nbal, JA = JS + 2 * nb, JA2 = JA + 2 * nbp, JO = JA2 + 2 * nbp, JW = JO + 16 * nl,
+              JWR = JW + 3 * nb, JWI = JWR + 5 * nbp, JT = JWI + 5 * nbp, JD = JT + 4 * nl;
+    const int HT = ng, HW = ng + 4 * nl, HWR = HW + 2 * nb, HWI = HWR + 2 * nbp;
+    const double *ohm = d.br_ohm + (long)inst * nl * 12;
+    const double *c2 = d.c2 + (long)inst * ng, *c1 = d.c1 + (long)inst * ng;
+    if (f_out) {
+        double f = 0.0;
+        for (int g = threadIdx.x; g < ng; g += TPB) f += c2[g] * x[PG + g] * x[PG + g] + c1[g] * x[PG + g];
+        f = block_reduce<OpSum>(f);
+        if (threadIdx.x == 0) *f_out = f;
+    }
+    if (grad) {
+        for (int j = threadIdx.x; j < d.n; j += TPB) grad[j] = 0.0;
+        __syncthreads();
+        for (int g = threadIdx.x; g < ng; g += TPB) grad[PG + g] = 2 * c2[g] * x[PG + g] + c1[g];
+    }
+    if (hv) {
+        for (int g = threadIdx.x; g < ng; g += TPB) hv[g] = sigma * 2 * c2[g];
+    }
+    if (threadIdx.x == 0) {
+        if (gv) gv[0] = x[VI + d.ref_bus];
+        if (jv) jv[0] = 1.0;
+    }
+    for (int i = threadIdx.x; i < nb; i += TPB) {
+        const int s = d.bal_ptr[i], e = d.bal_ptr[i + 1];
+        const int sh = d.nsh > 0 ? d.sh_of_bus[i] : -1;
+        const double gs = sh >= 0 ? d.sh_gs[sh] : 0.0, bs = sh >= 0 ? d.sh_bs[sh] : 0.0;
+        const double vr = x[VR + i], vi = x[VI + i];
+        if (gv) {
+            double sp = 0.0, sq = 0.0;
+            for (int k = s; k < e; ++k) {
+                sp += d.bal_coef[k] * x[d.bal_colP[k]];
+                sq += d.bal_coef[k] * x[d.bal_colQ[k]];
+            }
+            gv[1 + 2 * i] = sp + gs * x[W + i]; gv[2 + 2 * i] = sq - bs * x[W + i];
+            gv[V0 + i] = x[W + i] - vr * vr - vi * vi;
+        }
+        if (jv) {
+            double *dst = jv + 1 + 2 * s;
+            for (int k = s; k < e; ++k) { dst[k - s] = d.bal_coef[k]; dst[(e - s) + (k - s)] = d.bal_coef[k]; }
+            jv[JS + 2 * i] = gs; jv[JS + 2 * i + 1] = -bs;
+            jv[JW + 3 * i] = 1.0; jv[JW + 3 * i + 1] = -2 * vr; jv[JW + 3 * i + 2] = -2 * vi;
+        }
+        if (hv) { const double w = -2 * lam[V0 + i]; hv[HW + 2 * i] = w; hv[HW + 2 * i + 1] = w; }
+    }
+    for (int k = threadIdx.x; k < nbp; k += TPB) {
+        const int i = d.bp_i[k], j = d.bp_j[k];
+        const double vri = x[VR + i], vii = x[VI + i], vrj = x[VR + j], vij = x[VI + j];
+        if (gv) {
+            gv[A0 + 2 * k] = x[WI + k] - d.bp_tmax[k] * x[WR + k];
+            gv[A0 + 2 * k + 1] = x[WI + k] - d.bp_tmin[k] * x[WR + k];
+            gv[V0 + nb + 2 * k] = x[WR + k] - (vri * vrj + vii * vij);
+            gv[V0 + nb + 2 * k + 1] = x[WI + k] - (vii * vrj - vri * vij);
+        }
+        if (jv) {
+            jv[JA + 2 * k] = 1.0; jv[JA + 2 * k + 1] = -d.bp_tmax[k];
+            jv[JA2 + 2 * k] = 1.0; jv[JA2 + 2 * k + 1] = -d.bp_tmin[k];
+            double *a = jv + JWR + 5 * k, *b = jv + JWI + 5 * k;
+            a[0] = 1.0; a[1] = -vrj; a[2] = -vri; a[3] = -vij; a[4] = -vii;
+            b[0] = 1.0; b[1] = -vrj; b[2] = -vii; b[3] = vij; b[4] = vri;
+        }
+        if (hv) {
+            const double wr = -lam[V0 + nb + 2 * k], wi = lam[V0 + nb + 2 * k + 1];
+            hv[HWR + 2 * k] = wr; hv[HWR + 2 * k + 1] = wr;
+            hv[HWI + 2 * k] = -wi; hv[HWI + 2 * k + 1] = wi;
+        }
+    }
+    for (int dl = threadIdx.x; dl < d.ndc; dl += TPB) {
+        if (gv) gv[D0 + dl] = (1.0 - d.dc_loss1[dl]) * x[DCV + dl] + x[DCV + d.ndc + dl];
+        if (jv) { jv[JD + 2 * dl] = 1.0 - d.dc_loss1[dl]; jv[JD + 2 * dl + 1] = 1.0; }
+    }
+    for (int l = threadIdx.x; l < nl; l += TPB) {
+        const double pf = x[PF + l], qf = x[QF + l], pt = x[PT + l], qt = x[QT + l];
+        const int k = d.br_bp[l];
+        const double sg = d.br_sig[l], wrk = x[WR + k], wik = x[WI + k];
+        const double wf = x[W + d.f_bus[l]], wt = x[W + d.t_bus[l]];
+        if (gv) {
+            gv[T0 + 2 * l] = pf * pf + qf * qf;
+            gv[T0 + 2 * l + 1] = pt * pt + qt * qt;
+        }
+        if (jv) {
+            jv[JT + 2 * l] = 2 * pf; jv[JT + 2 * l + 1] = 2 * qf;
+            jv[JT + 2 * nl + 2 * l] = 2 * pt; jv[JT + 2 * nl + 2 * l + 1] = 2 * qt;
+        }
+        if (hv) {
+            const double hf = 2 * lam[T0 + 2 * l], ht = 2 * lam[T0 + 2 * l + 1];
+            hv[HT + 2 * l] = hf; hv[HT + 2 * l + 1] = hf;
+            hv[HT + 2 * nl + 2 * l] = ht; hv[HT + 2 * nl + 2 * l + 1] = ht;
+        }
+        const double own[4] = {pf, qf, pt, qt};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const Ohm o = ohm_coef(ohm + 12 * l, c);
+            if (gv) gv[O0 + 4 * l + c] = own[c] - (o.A * (o.self_t ? wt : wf) + o.Bc * wrk + sg * o.Bs * wik);
+            if (jv) {
+                double *e = jv + JO + (long)c * 4 * nl + 4 * l;
+                e[0] = 1.0; e[1] = -o.A; e[2] = -o.Bc; e[3] = -sg * o.Bs;
+            }
+        }
+    }
+}
+
 // any of f_out, grad, gv, jv, hv may be null
 static __device__ void acopf_eval(const DV &d, int inst, const double *__restrict__ x, double sigma,
                            const double *__restrict__ lam, double *f_out, double *grad, double *gv,
                            double *jv, double *hv)
 {
     if (d.acr) { acr_eval(d, inst, x, sigma, lam, f_out, grad, gv, jv, hv); return; }   // uniform over the launch
+    if (d.acwr) { acwr_eval(d, inst, x, sigma, lam, f_out, grad, gv, jv, hv); return; }
     const int nb = d.nb, ng = d.ng, nl = d.nl;
     const int VA = 0, VM = nb, PG = 2 * nb, QG = 2 * nb + ng, PF = 2 * nb + 2 * ng;
     const int PT = PF + nl, QF = PF + 2 * nl, QT = PF + 3 * nl;

@@ -686,6 +686,15 @@ static int acopf_nnzj(int acr, int nb, int ng, int nl, int ndc)
     return acr ? 1 + 2 * nbal + 4 * nb + 24 * nl + 2 * ndc : 32 * nl + 2 * ng + 1 + 6 * ndc;
 }
 static int acopf_nnzh(int acr, int nb, int ng, int nl) { return acr ? ng + 28 * nl + 4 * nb : ng + 44 * nl; }
+// ... and of the W-space layout (acwr_layout): the shunt entries are part of the structure
+static int acwr_n(int nb, int nbp, int ng, int nl) { return 3 * nb + 2 * nbp + 2 * ng + 4 * nl; }
+static int acwr_m(int nb, int nbp, int nl) { return 1 + 3 * nb + 4 * nbp + 6 * nl; }
+static int acwr_nnzj(int nb, int nbp, int ng, int nl, int ndc)
+{
+    const int nbal = 2 * nl + ng + 2 * ndc;
+    return 1 + 2 * nbal + 2 * nb + 4 * nbp + 16 * nl + 3 * nb + 10 * nbp + 4 * nl + 2 * ndc;
+}
+static int acwr_nnzh(int nb, int nbp, int ng, int nl) { return ng + 4 * nl + 2 * nb + 4 * nbp; }
 
 static int acopf_attach_impl(sqphip_ctx *h, int acr, int32_t nb, int32_t ng, int32_t nl, const int32_t *f_bus,
                              const int32_t *t_bus, const int32_t *gen_bus, const int32_t *bal_ptr,
@@ -712,7 +721,7 @@ static int acopf_attach_impl(sqphip_ctx *h, int acr, int32_t nb, int32_t ng, int
     if (ref_bus < 0 || ref_bus >= nb) return SQPHIP_EINVAL;
     return guarded(h, [&](Ctx &C) {
         DV &d = C.d;
-        d.nb = nb; d.ng = ng; d.nl = nl; d.ref_bus = ref_bus; d.acr = acr;
+        d.nb = nb; d.ng = ng; d.nl = nl; d.ref_bus = ref_bus; d.acr = acr; d.acwr = 0;
         d.ndc = ndc;
         d.dc_loss1 = C.upload(std::vector<double>(ndc > 0 ? ndc : 1, 0.0));   // sqphip_acopf_set_dclines overrides
         d.f_bus = C.upload(std::vector<int>(f_bus, f_bus + nl));
@@ -747,6 +756,58 @@ extern "C" int sqphip_acopf_attach_acr(sqphip_ctx *h, int32_t nb, int32_t ng, in
     return acopf_attach_impl(h, 1, nb, ng, nl, f_bus, t_bus, gen_bus, bal_ptr, bal_colP, bal_colQ, bal_coef, ref_bus);
 }
 
+extern "C" int sqphip_acopf_attach_acwr(sqphip_ctx *h, int32_t nb, int32_t ng, int32_t nl, const int32_t *f_bus,
+                                        const int32_t *t_bus, const int32_t *gen_bus, const int32_t *bal_ptr,
+                                        const int32_t *bal_colP, const int32_t *bal_colQ, const double *bal_coef,
+                                        int32_t ref_bus, int32_t nbp, const int32_t *bp_i, const int32_t *bp_j,
+                                        const int32_t *br_bp, const double *br_sig, const double *bp_tmin,
+                                        const double *bp_tmax)
+{
+    if (!h || nb <= 0 || ng <= 0 || nl <= 0 || nbp <= 0 || nbp > nl) return SQPHIP_EINVAL;
+    if (!f_bus || !t_bus || !gen_bus || !bal_ptr || !bal_colP || !bal_colQ || !bal_coef) return SQPHIP_EINVAL;
+    if (!bp_i || !bp_j || !br_bp || !br_sig || !bp_tmin || !bp_tmax) return SQPHIP_EINVAL;
+    Ctx &C0 = h->c;
+    const int n_ac = acwr_n(nb, nbp, ng, nl);
+    if (C0.d.n < n_ac || (C0.d.n - n_ac) % 4 != 0) return SQPHIP_EINVAL;
+    const int ndc = (C0.d.n - n_ac) / 4;
+    if (C0.d.m != acwr_m(nb, nbp, nl) + ndc) return SQPHIP_EINVAL;
+    const int nbal = bal_ptr[nb];
+    if (C0.d.nnzj_coo != acwr_nnzj(nb, nbp, ng, nl, ndc) || C0.d.nnzh_coo != acwr_nnzh(nb, nbp, ng, nl) ||
+        nbal != 2 * nl + ng + 2 * ndc) return SQPHIP_EINVAL;
+    for (int l = 0; l < nl; ++l)
+        if (f_bus[l] < 0 || f_bus[l] >= nb || t_bus[l] < 0 || t_bus[l] >= nb || br_bp[l] < 0 || br_bp[l] >= nbp ||
+            !(br_sig[l] == 1.0 || br_sig[l] == -1.0)) return SQPHIP_EINVAL;
+    for (int k = 0; k < nbp; ++k)
+        if (bp_i[k] < 0 || bp_j[k] >= nb || bp_i[k] >= bp_j[k]) return SQPHIP_EINVAL;
+    for (int k = 0; k < nbal; ++k)
+        if (bal_colP[k] < 0 || bal_colP[k] >= C0.d.n || bal_colQ[k] < 0 || bal_colQ[k] >= C0.d.n) return SQPHIP_EINVAL;
+    if (ref_bus < 0 || ref_bus >= nb) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) {
+        DV &d = C.d;
+        d.nb = nb; d.ng = ng; d.nl = nl; d.ref_bus = ref_bus; d.acr = 0; d.acwr = 1; d.nbp = nbp;
+        d.ndc = ndc;
+        d.dc_loss1 = C.upload(std::vector<double>(ndc > 0 ? ndc : 1, 0.0));
+        d.f_bus = C.upload(std::vector<int>(f_bus, f_bus + nl));
+        d.t_bus = C.upload(std::vector<int>(t_bus, t_bus + nl));
+        d.gen_bus = C.upload(std::vector<int>(gen_bus, gen_bus + ng));
+        d.bal_ptr = C.upload(std::vector<int>(bal_ptr, bal_ptr + nb + 1));
+        d.bal_colP = C.upload(std::vector<int>(bal_colP, bal_colP + nbal));
+        d.bal_colQ = C.upload(std::vector<int>(bal_colQ, bal_colQ + nbal));
+        d.bal_coef = C.upload(std::vector<double>(bal_coef, bal_coef + nbal));
+        d.bp_i = C.upload(std::vector<int>(bp_i, bp_i + nbp)); d.bp_j = C.upload(std::vector<int>(bp_j, bp_j + nbp));
+        d.br_bp = C.upload(std::vector<int>(br_bp, br_bp + nl));
+        d.br_sig = C.upload(std::vector<double>(br_sig, br_sig + nl));
+        d.bp_tmin = C.upload(std::vector<double>(bp_tmin, bp_tmin + nbp));
+        d.bp_tmax = C.upload(std::vector<double>(bp_tmax, bp_tmax + nbp));
+        d.br_ohm = C.dalloc<double>((size_t)d.B * nl * 12);
+        d.c2 = C.dalloc<double>((size_t)d.B * ng); d.c1 = C.dalloc<double>((size_t)d.B * ng);
+        SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        C.acopf_attached = true;
+        make_lanes(C);
+        return SQPHIP_OK;
+    });
+}
+
 extern "C" int sqphip_acopf_set_shunts(sqphip_ctx *h, int32_t nsh, const int32_t *sh_bus, const double *gs,
                                        const double *bs)
 {
@@ -754,9 +815,11 @@ extern "C" int sqphip_acopf_set_shunts(sqphip_ctx *h, int32_t nsh, const int32_t
     Ctx &C0 = h->c;
     const int nl = C0.d.nl, ng = C0.d.ng, nb = C0.d.nb;
     const int acr = C0.d.acr;
-    if (C0.d.nnzj_coo != acopf_nnzj(acr, nb, ng, nl, C0.d.ndc) + (acr ? 4 : 2) * nsh ||
-        C0.d.nnzh_coo != acopf_nnzh(acr, nb, ng, nl) + (acr ? 2 : 1) * nsh) return SQPHIP_EINVAL;
-    if (nsh > 0 && C0.d.nlin != (acr ? 1 : 2 * nl + 1)) return SQPHIP_EINVAL;     // balance rows must not be declared linear
+    if (!C0.d.acwr) {                    // (the W-space structure carries the shunt entries of every bus already)
+        if (C0.d.nnzj_coo != acopf_nnzj(acr, nb, ng, nl, C0.d.ndc) + (acr ? 4 : 2) * nsh ||
+            C0.d.nnzh_coo != acopf_nnzh(acr, nb, ng, nl) + (acr ? 2 : 1) * nsh) return SQPHIP_EINVAL;
+        if (nsh > 0 && C0.d.nlin != (acr ? 1 : 2 * nl + 1)) return SQPHIP_EINVAL; // balance rows must not be declared linear
+    }
     std::vector<int> of(nb, -1);
     for (int s = 0; s < nsh; ++s) {
         if (sh_bus[s] < 0 || sh_bus[s] >= nb || of[sh_bus[s]] >= 0) return SQPHIP_EINVAL;

@@ -137,6 +137,9 @@ struct DV {
     int nb, ng, nl, ref_bus;
     StreamDev stream;
     int acr;                              // 1: rectangular voltage coordinates (acopf_dev.hpp acr_eval), 0: polar
+    int acwr, nbp;                        // 1: W-space form of examples/acopf/acwr.jl (acwr_eval); its bus pairs i < j
+    const int *bp_i, *bp_j, *br_bp;       // pair -> buses; branch -> pair
+    const double *br_sig, *bp_tmin, *bp_tmax;   // branch orientation in its pair (+-1); tan of the pairs' angle limits
     int ndc; const double *dc_loss1;   // HVDC lines (shared): 4 variables each behind all others, one loss row each at the end
     int nsh; const int *sh_bus, *sh_of_bus; const double *sh_gs, *sh_bs;   // bus shunts (shared): list, bus -> index or -1
     const int *f_bus, *t_bus, *gen_bus, *bal_ptr, *bal_colP, *bal_colQ;

@@ -238,8 +238,15 @@ class Context:
         keep = [np.ascontiguousarray(a, dtype=np.int32) for a in
                 (net.f_bus, net.t_bus, net.gen_bus, lay.bal_ptr, lay.bal_colP, lay.bal_colQ)]
         coef = _f(lay.bal_coef)
-        attach = self.L.sqphip_acopf_attach_acr if getattr(lay, "form", "polar") == "acr" else self.L.sqphip_acopf_attach
-        self._ck(attach(self.h, net.nb, net.ng, net.nl, *[_i(a) for a in keep], _d(coef), int(net.ref_bus)))
+        form = getattr(lay, "form", "polar")
+        if form == "acwr":
+            bp = [np.ascontiguousarray(a, dtype=np.int32) for a in (lay.bp_i, lay.bp_j, lay.br_bp)]
+            self._ck(self.L.sqphip_acopf_attach_acwr(self.h, net.nb, net.ng, net.nl, *[_i(a) for a in keep], _d(coef),
+                                                     int(net.ref_bus), len(bp[0]), *[_i(a) for a in bp], _d(_f(lay.br_sig)),
+                                                     _d(_f(lay.bp_tmin)), _d(_f(lay.bp_tmax))))
+        else:
+            attach = self.L.sqphip_acopf_attach_acr if form == "acr" else self.L.sqphip_acopf_attach
+            self._ck(attach(self.h, net.nb, net.ng, net.nl, *[_i(a) for a in keep], _d(coef), int(net.ref_bus)))
         if len(lay.dc_loss1):
             self._ck(self.L.sqphip_acopf_set_dclines(self.h, len(lay.dc_loss1), _d(_f(lay.dc_loss1))))
         if len(lay.sh_bus):

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import sqpsolver_jl_amd as pkg
-from sqpsolver_jl_amd.acopf_synth import acopf_synth, acopf_layout, acr_layout, contingency, CASES
+from sqpsolver_jl_amd.acopf_synth import acopf_synth, acopf_layout, acr_layout, acwr_layout, contingency, CASES
 from oracle import oracle as O
 
 
@@ -116,3 +116,83 @@ def test_symbolic_analysis_of_the_acr_structure(case):
             assert pos[lay.n + kpos[int(r)]] > pos[c]
     _, sp = pkg.kkt_symbolic(lp.n, lp.m, lp.jrow, lp.jcol, lp.hrow, lp.hcol, lp.gL, lp.gU)
     assert st["max_front"] <= 256 and st["nnz_l"] <= 1.5 * sp["nnz_l"] and st["flops"] <= 2.0 * sp["flops"]
+
+
+# ------------------------------------------------------------------ W-space form (examples/acopf/acwr.jl)
+def _lift(lay, va, vm, tail):
+    """(vi, vr, w, wr, wi, tail) of the polar point (va, vm)."""
+    nb = len(va)
+    vr, vi = vm * np.cos(va), vm * np.sin(va)
+    i, j = lay.bp_i, lay.bp_j
+    return np.concatenate([vi, vr, vm ** 2, vr[i] * vr[j] + vi[i] * vi[j], vi[i] * vr[j] - vr[i] * vi[j], tail])
+
+
+@pytest.mark.parametrize("shunts", [False, True])
+def test_acwr_layout_counts_and_polar_equivalence(shunts):
+    """Structure counts as sqphip_acopf_attach_acwr checks them; at a lifted polar point the model-voltage rows vanish
+    and the Ohm and balance rows have the polar values (shunts included: gs w_i = gs vm_i^2)."""
+    net = _net(shunts=shunts)
+    nb, ng, nl = net.nb, net.ng, net.nl
+    lp, lw = acopf_layout(net), acwr_layout(net)
+    nbp = len(lw.bp_i)
+    assert lw.form == "acwr" and lw.n == 3 * nb + 2 * nbp + 2 * ng + 4 * nl and lw.m == 1 + 3 * nb + 4 * nbp + 6 * nl
+    assert len(lw.jrow) == 1 + 2 * (2 * nl + ng) + 2 * nb + 4 * nbp + 16 * nl + 3 * nb + 10 * nbp + 4 * nl
+    assert len(lw.hrow) == ng + 4 * nl + 2 * nb + 4 * nbp and (lw.hrow >= lw.hcol).all()
+    assert lw.num_linear == 1 + 2 * nb + 2 * nbp + 4 * nl           # everything but model voltage and thermal limits
+    Pp, Pw = O.problem_acopf(net, lp), O.problem_acopf(net, lw)
+    rng = np.random.default_rng(0)
+    xp = lp.x0 + 0.05 * rng.standard_normal(lp.n)
+    xw = _lift(lw, xp[:nb], xp[nb:2 * nb], xp[2 * nb:])
+    gp, gw = Pp.eval_g(xp), Pw.eval_g(xw)
+    O0p, O0w = 2 * nl + 1 + 2 * nb + 2 * nl, 1 + 2 * nb + 2 * nbp
+    V0 = O0w + 4 * nl
+    assert np.abs(gp[O0p:O0p + 4 * nl] - gw[O0w:O0w + 4 * nl]).max() < 1e-13
+    assert np.abs(gp[2 * nl + 1:2 * nl + 1 + 2 * nb] - gw[1:1 + 2 * nb]).max() < 1e-13
+    assert np.abs(gw[V0:V0 + nb + 2 * nbp]).max() < 1e-14
+    # the angle rows are the polar angle limits in tangent form: same sign pattern of the slack
+    th = xp[net.f_bus] - xp[net.t_bus]
+    up = gw[1 + 2 * nb:O0w:2][lw.br_bp]; lo = gw[2 + 2 * nb:O0w:2][lw.br_bp]
+    assert ((up <= 0) == (th * lw.br_sig <= np.arctan(lw.bp_tmax[lw.br_bp]) + 1e-12)).all()
+    assert ((lo >= 0) == (th * lw.br_sig >= np.arctan(lw.bp_tmin[lw.br_bp]) - 1e-12)).all()
+
+
+def test_acwr_derivatives_against_finite_differences():
+    net = _net(shunts=True)
+    lay = acwr_layout(net)
+    P = O.problem_acopf(net, lay)
+    rng = np.random.default_rng(1)
+    x = lay.x0 + 0.05 * rng.standard_normal(lay.n); lam = rng.standard_normal(lay.m); sig = 0.7
+    h = 1e-6
+    J = _dense(lay, P.eval_jac_g(x), "J")
+    Jfd = np.zeros_like(J)
+    for j in range(lay.n):
+        e = np.zeros(lay.n); e[j] = h
+        Jfd[:, j] = (P.eval_g(x + e) - P.eval_g(x - e)) / (2 * h)
+    assert np.abs(J - Jfd).max() < 1e-7
+    H = _dense(lay, P.eval_h(x, sig, lam), "H")
+
+    def lag_grad(z):
+        return sig * P.eval_grad_f(z) + _dense(lay, P.eval_jac_g(z), "J").T @ lam
+    Hfd = np.zeros_like(H)
+    for j in range(lay.n):
+        e = np.zeros(lay.n); e[j] = h
+        Hfd[:, j] = (lag_grad(x + e) - lag_grad(x - e)) / (2 * h)
+    assert np.abs(H - Hfd).max() < 1e-5 * max(1.0, np.abs(H).max())
+    # the first num_linear rows are linear: their Jacobian entries do not depend on the point
+    lin = lay.jrow <= lay.num_linear
+    assert np.array_equal(P.eval_jac_g(x)[lin], P.eval_jac_g(lay.x0)[lin])
+
+
+def test_acwr_reaches_the_polar_optimum():
+    """The W-space model carries the polar model's constraints (voltage and angle limits included): same optimum."""
+    net = _net()
+    nb, ng = net.nb, net.ng
+    kw = dict(max_iter=100, tol_infeas=1e-6, tol_residual=1e-4, literal_quirks=0, use_soc=1)
+    rp = O.sqp_solve(O.problem_acopf(net, acopf_layout(net)), O.default_options(**kw))
+    lw = acwr_layout(net)
+    rw = O.sqp_solve(O.problem_acopf(net, lw), O.default_options(**kw))
+    assert rp["status"] == rw["status"] == 0
+    assert abs(rp["obj_val"] - rw["obj_val"]) <= 1e-6 * abs(rp["obj_val"])
+    assert np.abs(np.sqrt(rw["x"][2 * nb:3 * nb]) - rp["x"][nb:2 * nb]).max() < 1e-4          # sqrt(w) = vm
+    PG = 3 * nb + 2 * len(lw.bp_i)
+    assert np.abs(rw["x"][PG:PG + ng] - rp["x"][2 * nb:2 * nb + ng]).max() < 1e-4
