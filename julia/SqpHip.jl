@@ -168,6 +168,17 @@ function hip_acopf_attach(ctx::Ptr{Cvoid}, nb, ng, nl, f_bus::Vector{Int32}, t_b
                        ccall((:sqphip_acopf_attach, LIBSQPHIP), Cint, T, args...)
     _check(ctx, rc)
 end
+# the W-space model of examples/acopf/acwr.jl (ACWRPowerModel): bus pairs i < j, pair / orientation of every branch,
+# tan of the pairs' angle limits (0-based indices, as everything at this boundary below the COO structure)
+hip_acopf_attach_acwr(ctx::Ptr{Cvoid}, nb, ng, nl, f_bus::Vector{Int32}, t_bus::Vector{Int32}, gen_bus::Vector{Int32},
+                      bal_ptr::Vector{Int32}, bal_colP::Vector{Int32}, bal_colQ::Vector{Int32}, bal_coef::Vector{Float64},
+                      ref_bus, bp_i::Vector{Int32}, bp_j::Vector{Int32}, br_bp::Vector{Int32}, br_sig::Vector{Float64},
+                      bp_tmin::Vector{Float64}, bp_tmax::Vector{Float64}) =
+    _check(ctx, ccall((:sqphip_acopf_attach_acwr, LIBSQPHIP), Cint,
+                      (Ptr{Cvoid}, Int32, Int32, Int32, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32},
+                       Ptr{Cdouble}, Int32, Int32, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+                      ctx, nb, ng, nl, f_bus, t_bus, gen_bus, bal_ptr, bal_colP, bal_colQ, bal_coef, ref_bus,
+                      length(bp_i), bp_i, bp_j, br_bp, br_sig, bp_tmin, bp_tmax))
 hip_sqp_run(ctx::Ptr{Cvoid}, max_outer::Integer = 0) =
     _check(ctx, ccall((:sqphip_sqp_run, LIBSQPHIP), Cint, (Ptr{Cvoid}, Int32), ctx, max_outer))
 hip_stream_begin(ctx::Ptr{Cvoid}, n_scenarios::Integer) =
