@@ -299,6 +299,81 @@ def test_acopf_optimum_agrees_with_scipy_trust_constr():
     assert np.abs(res.x - r["x"]).max() < 1e-5
 
 
+@pytest.mark.parametrize("case,delta", [("case14", 0.1), ("case14", 0.02), ("case118", 0.05)])
+def test_restoration_subproblem_agrees_with_highs(case, delta):
+    """The feasibility-restoration sub-problem (sub_optimize_FR!, subproblem_JuMP.jl:352-393) is a linear programme:
+    minimise the slack mass of the nonlinear rows subject to the linearised constraints, the linear rows held exactly
+    and the step inside the trust-region box.  Its optimal VALUE is unique, so an unrelated solver must find it: HiGHS
+    (scipy.optimize.linprog) on the LP written out independently here, against the restatement's interior-point
+    answer.  This pins the sub-problem arithmetic -- which the reference delegates to an un-vendored Ipopt -- to a
+    second external solver, next to the trust-constr check of the NLP above."""
+    from scipy.optimize import linprog
+    nb, ng, nl, seed = CASES[case]
+    net = contingency(acopf_synth(nb, ng, nl, seed), 4, seed); lay = acopf_layout(net)
+    P = O.problem_acopf(net, lay)
+    n, m, nlin = lay.n, lay.m, lay.num_linear
+    jcp, jrv, jslot, _ = O.coo_to_csc(n, lay.jrow, lay.jcol)
+    hcp, hrv, _, _ = O.coo_to_csc(n, lay.hrow, lay.hcol, sym=True)
+    q = O.QpSolver(n, m, nlin, jcp, jrv, hcp, hrv, lay.xL, lay.xU, lay.gL, lay.gU, O.default_options())
+    # a point that satisfies the linear rows (the linear phase of run!, mode 3, returns it), so that what is left to
+    # restore are the nonlinear rows
+    jv0 = np.zeros(len(jrv)); np.add.at(jv0, jslot, P.eval_jac_g(lay.x0))
+    r0 = q.solve(3, lay.x0, np.inf, 1.0, None, None, jv0, None)
+    assert r0["status"] == 4
+    xk = r0["p"]
+    E = P.eval_g(xk); jcoo = P.eval_jac_g(xk)
+    jv = np.zeros(len(jrv)); np.add.at(jv, jslot, jcoo)
+    r = q.solve(1, xk, delta, 1.0, P.eval_grad_f(xk), E, jv, np.zeros(len(hrv)), want_slack=True)
+    assert r["status"] == 4
+    soft = np.arange(nlin, m)
+    val = r["slack"][soft].sum() + r["slack"][m + soft].sum()
+    # the same LP for HiGHS: variables (p, t+, t-); rows lo <= J p + t+ - t- <= hi (soft), lo <= J p <= hi (linear)
+    J = sp.coo_matrix((jcoo, (lay.jrow - 1, lay.jcol - 1)), shape=(m, n)).tocsr()
+    ns = len(soft)
+    Sel = sp.coo_matrix((np.ones(ns), (soft, np.arange(ns))), shape=(m, ns)).tocsr()
+    A = sp.hstack([J, Sel, -Sel]).tocsr()
+    lo, hi = lay.gL - E, lay.gU - E
+    rows_u = np.flatnonzero(np.isfinite(hi)); rows_l = np.flatnonzero(np.isfinite(lo))
+    A_ub = sp.vstack([A[rows_u], -A[rows_l]]); b_ub = np.concatenate([hi[rows_u], -lo[rows_l]])
+    pl = np.maximum(-delta, lay.xL - xk); pu = np.minimum(delta, lay.xU - xk)
+    bad = pl > pu                                              # the repair of subproblem_JuMP.jl:439-447
+    pl = np.where(bad, np.maximum(-delta, np.minimum(0.0, lay.xL - xk)), pl)
+    pu = np.where(bad, np.minimum(delta, np.maximum(0.0, lay.xU - xk)), pu)
+    bounds = [(a, b) for a, b in zip(pl, pu)] + [(0, None)] * (2 * ns)
+    res = linprog(np.concatenate([np.zeros(n), np.ones(2 * ns)]), A_ub=A_ub, b_ub=b_ub, bounds=bounds, method="highs")
+    assert res.status == 0
+    assert abs(res.fun - val) <= 1e-6 * max(1.0, abs(res.fun)), (res.fun, val)
+    assert val > 1e-3                                          # a real restoration problem: the linearisation is infeasible in the box
+
+
+def test_linear_phase_subproblem_agrees_with_scipy():
+    """The linear phase of run! (sub_optimize_lp!, subproblem_JuMP.jl:185-244) is a convex QP with a unique solution:
+    the point of the bound box closest to x_k that satisfies the linear rows.  scipy's trust-constr on the same QP
+    (written out here) must land on the restatement's answer."""
+    from scipy.optimize import Bounds, LinearConstraint, minimize
+    nb, ng, nl, seed = CASES["case14"]
+    net = contingency(acopf_synth(nb, ng, nl, seed), 2, seed); lay = acopf_layout(net)
+    P = O.problem_acopf(net, lay)
+    n, m, nlin = lay.n, lay.m, lay.num_linear
+    jcp, jrv, jslot, _ = O.coo_to_csc(n, lay.jrow, lay.jcol)
+    hcp, hrv, _, _ = O.coo_to_csc(n, lay.hrow, lay.hcol, sym=True)
+    q = O.QpSolver(n, m, nlin, jcp, jrv, hcp, hrv, lay.xL, lay.xU, lay.gL, lay.gU, O.default_options())
+    jcoo = P.eval_jac_g(lay.x0)
+    jv = np.zeros(len(jrv)); np.add.at(jv, jslot, jcoo)
+    r = q.solve(3, lay.x0, np.inf, 1.0, None, None, jv, None)
+    assert r["status"] == 4
+    J = sp.coo_matrix((jcoo, (lay.jrow - 1, lay.jcol - 1)), shape=(m, n)).tocsr()[:nlin]
+    # linear rows: g_i(x) = g_i(x0) + J_i (x - x0) exactly
+    g0 = P.eval_g(lay.x0)[:nlin] - J @ lay.x0
+    res = minimize(lambda x: float(np.sum((x - lay.x0) ** 2)), lay.x0, jac=lambda x: 2 * (x - lay.x0), hess=lambda x: 2 * sp.eye(n),
+                   method="trust-constr", bounds=Bounds(lay.xL, lay.xU),
+                   constraints=[LinearConstraint(J, lay.gL[:nlin] - g0, lay.gU[:nlin] - g0)],
+                   options=dict(gtol=1e-10, xtol=1e-12, maxiter=3000))
+    assert res.constr_violation < 1e-9
+    assert np.abs(res.x - r["p"]).max() < 1e-5
+    assert abs(res.fun - np.sum((r["p"] - lay.x0) ** 2)) <= 1e-7 * max(1.0, res.fun)
+
+
 def test_predictor_corrector_and_monotone_rule_agree_on_the_qp_solution():
     """options.ipm_corrector only changes the path to the solution: both barrier strategies must return the same
     status, multipliers and optimal value on every sub-problem mode (and the same step p where the Hessian of the
