@@ -21,7 +21,7 @@ static __device__ __forceinline__ Ohm ohm_coef(const double *__restrict__ oc, in
 //   F_k = A (vr_s^2 + vi_s^2) + Bc (vr_f vr_t + vi_f vi_t) + Bs (vi_f vr_t - vr_f vi_t)
 // (the polar F_k with v_f v_t cos th and v_f v_t sin th written out, same twelve coefficients per branch): every row is
 // quadratic, no trigonometry, the Hessian entries are multipliers times constants.
-static __device__ void acr_eval(const DV &d, int inst, const double *__restrict__ x, double sigma,
+static __device__ __forceinline__ void acr_eval(const DV &d, int inst, const double *__restrict__ x, double sigma,
                          const double *__restrict__ lam, double *f_out, double *grad, double *gv,
                          double *jv, double *hv)
 {
@@ -148,7 +148,7 @@ static __device__ void acr_eval(const DV &d, int inst, const double *__restrict_
 // acwr_layout): x = (vi, vr, w, wr, wi, pg, qg, flows, dc lines).  Balance, angle-difference and Ohm rows are linear in
 // (w, wr, wi) -- their Jacobian entries are constants of the instance --, constraint_model_voltage ties the lifted
 // variables to the rectangular voltages: w_i = vr_i^2 + vi_i^2, wr_k = vr_i vr_j + vi_i vi_j, wi_k = vi_i vr_j - vr_i vi_j.
-static __device__ void acwr_eval(const DV &d, int inst, const double *__restrict__ x, double sigma,
+static __device__ __forceinline__ void acwr_eval(const DV &d, int inst, const double *__restrict__ x, double sigma,
                           const double *__restrict__ lam, double *f_out, double *grad, double *gv,
                           double *jv, double *hv)
 {
@@ -260,7 +260,7 @@ static __device__ void acwr_eval(const DV &d, int inst, const double *__restrict
 }
 
 // any of f_out, grad, gv, jv, hv may be null
-static __device__ void acopf_eval(const DV &d, int inst, const double *__restrict__ x, double sigma,
+static __device__ __forceinline__ void acopf_eval(const DV &d, int inst, const double *__restrict__ x, double sigma,
                            const double *__restrict__ lam, double *f_out, double *grad, double *gv,
                            double *jv, double *hv)
 {

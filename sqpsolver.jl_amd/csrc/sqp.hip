@@ -53,7 +53,7 @@ static __device__ __forceinline__ bool isapprox_d(double a, double b)
 }
 
 // common.jl:54-77 with p = 1
-static __device__ double viol1(const DV &d, const double *E, const double *gL, const double *gU,
+static __device__ __forceinline__ double viol1(const DV &d, const double *E, const double *gL, const double *gU,
                                const double *x, const double *xL, const double *xU)
 {
     double acc = 0.0;
@@ -68,14 +68,14 @@ static __device__ double viol1(const DV &d, const double *E, const double *gL, c
     return block_reduce<OpSum>(acc);
 }
 
-static __device__ double norm_inf(const double *v, int k)
+static __device__ __forceinline__ double norm_inf(const double *v, int k)
 {
     double a = 0.0;
     for (int i = threadIdx.x; i < k; i += TPB) a = fmax(a, fabs(v[i]));
     return block_reduce<OpMax>(a);
 }
 
-static __device__ void gather_csc(const DV &d, const double *jcoo, const double *hcoo, double *jv, double *hv)
+static __device__ __forceinline__ void gather_csc(const DV &d, const double *jcoo, const double *hcoo, double *jv, double *hv)
 {
     for (int s = threadIdx.x; s < d.nnzjc; s += TPB) {
         double a = 0.0;
@@ -91,7 +91,7 @@ static __device__ void gather_csc(const DV &d, const double *jcoo, const double 
 }
 
 // common.jl:14-23 on the CSC Jacobian; sgn = +1 literal, -1 textbook (lambda and mult_x_U negated)
-static __device__ double kt_residuals(const DV &d, const double *df, const double *lam, const double *mxU,
+static __device__ __forceinline__ double kt_residuals(const DV &d, const double *df, const double *lam, const double *mxU,
                                       const double *mxL, const double *jv, double sgn, double *rowsq)
 {
     for (int i = threadIdx.x; i < d.m; i += TPB) {
@@ -113,7 +113,7 @@ static __device__ double kt_residuals(const DV &d, const double *df, const doubl
     return res / sc;
 }
 
-static __device__ void push_trace(const DV &d, int inst, SqpState &S, double pn)
+static __device__ __forceinline__ void push_trace(const DV &d, int inst, SqpState &S, double pn)
 {
     if (threadIdx.x == 0) {
         if (S.trace_len < SQPHIP_TRACE_CAP) {
@@ -127,7 +127,7 @@ static __device__ void push_trace(const DV &d, int inst, SqpState &S, double pn)
 }
 
 // work of a finished sub-problem, booked under its mode (sqphip_get_mode_counters)
-static __device__ void book_mode(SqpState &S, const IpmState &I)
+static __device__ __forceinline__ void book_mode(SqpState &S, const IpmState &I)
 {
     const int k = I.mode & 3;
     S.md_qp[k]++; S.md_ipm[k] += I.ipm_iters; S.md_fac[k] += I.n_factor;
@@ -136,14 +136,14 @@ static __device__ void book_mode(SqpState &S, const IpmState &I)
     S.qlog_n++;
 }
 
-static __device__ void qp_request(IpmState &I, int mode, double delta, double mu_pen)
+static __device__ __forceinline__ void qp_request(IpmState &I, int mode, double delta, double mu_pen)
 {
     I.mode = mode; I.delta = delta; I.mu_pen = mu_pen;
     I.stage = 0; I.rho_big = 1e4; I.start = 1; I.ipm_iters = 0; I.n_factor = 0; I.n_solve = 0; I.status = 0;
 }
 
 // sqp_trust_region.jl:215-222
-static __device__ void finalize(const DV &d, int inst, SqpState &S, const double *x)
+static __device__ __forceinline__ void finalize(const DV &d, int inst, SqpState &S, const double *x)
 {
     double f;
     __shared__ double fsh;
@@ -155,7 +155,7 @@ static __device__ void finalize(const DV &d, int inst, SqpState &S, const double
 
 // ---------------------------------------------------------------------------------------------
 // state of a run about to start from x0; keep_totals: the cumulative work counters survive (a slot of the scenario queue)
-static __device__ void reset_instance(const DV &d, int inst, bool keep_totals)
+static __device__ __forceinline__ void reset_instance(const DV &d, int inst, bool keep_totals)
 {
     SQP_PTRS
     const double *x0 = d.x0 + on;
@@ -179,7 +179,7 @@ static __device__ void reset_instance(const DV &d, int inst, bool keep_totals)
 __global__ __launch_bounds__(TPB) void k_sqp_reset(DV d) { reset_instance(d, blockIdx.x, false); }
 
 // run! prologue: sqp_trust_region.jl:100-122
-static __device__ void b_sqp_begin(const DV &d)
+static __device__ __forceinline__ void b_sqp_begin(const DV &d)
 {
     const int inst = blockIdx.x;
     SQP_PTRS
@@ -209,7 +209,7 @@ static __device__ void b_sqp_begin(const DV &d)
 
 __global__ __launch_bounds__(TPB) void k_sqp_begin(DV d) { b_sqp_begin(d); }
 
-static __device__ void b_sqp_lp_finish(const DV &d)
+static __device__ __forceinline__ void b_sqp_lp_finish(const DV &d)
 {
     const int inst = blockIdx.x;
     SQP_PTRS
@@ -231,7 +231,7 @@ static __device__ void b_sqp_lp_finish(const DV &d)
 
 // top of the loop: iteration limit, eval_functions!, infeasibility measures, QP request
 // (sqp_trust_region.jl:126-141)
-static __device__ void b_sqp_top(const DV &d)
+static __device__ __forceinline__ void b_sqp_top(const DV &d)
 {
     const int inst = blockIdx.x;
     SQP_PTRS
@@ -268,7 +268,7 @@ static __device__ void b_sqp_top(const DV &d)
 }
 
 // q(p) of sqp_trust_region.jl:487-508 (with_step = true); tmpx/tmpE are scratch
-static __device__ double qmodel_step(const DV &d, int inst, const SqpState &S, const double *p,
+static __device__ __forceinline__ double qmodel_step(const DV &d, int inst, const SqpState &S, const double *p,
                                      const double *x, const double *df, const double *E, const double *jv,
                                      const double *hv, const double *gL, const double *gU, const double *xL,
                                      const double *xU, double *tmpx, double *tmpE)
@@ -290,7 +290,7 @@ static __device__ double qmodel_step(const DV &d, int inst, const SqpState &S, c
     return acc + S.mu * viol1(d, tmpE, gL, gU, tmpx, xL, xU);
 }
 
-static __device__ void accept_step(const DV &d, double *x, double *lam, double *mxL, double *mxU,
+static __device__ __forceinline__ void accept_step(const DV &d, double *x, double *lam, double *mxL, double *mxU,
                                    const double *step, const double *plam, const double *pmxL,
                                    const double *pmxU)
 {
@@ -300,7 +300,7 @@ static __device__ void accept_step(const DV &d, double *x, double *lam, double *
 
 // after the QP: compute_step!, status branches, phi, termination tests, do_step!
 // (sqp_trust_region.jl:141-213, :370-380, :515-579)
-static __device__ void b_sqp_mid(const DV &d)
+static __device__ __forceinline__ void b_sqp_mid(const DV &d)
 {
     const int inst = blockIdx.x;
     SQP_PTRS
@@ -427,7 +427,7 @@ static __device__ void b_sqp_mid(const DV &d)
 }
 
 // second half of do_step! for instances that requested a second-order correction (:551-572)
-static __device__ void b_sqp_soc_finish(const DV &d)
+static __device__ __forceinline__ void b_sqp_soc_finish(const DV &d)
 {
     const int inst = blockIdx.x;
     SQP_PTRS
@@ -583,7 +583,7 @@ static void sqp_run_lane(Ctx &C, int max_outer)
 // Scenario queue (ctx.hpp StreamDev): a slot whose run has terminated files its result under its scenario id, takes the
 // next id, loads that scenario and runs the prologue of run! -- all inside the stage kernel of the sweep in which the
 // run ended, so the slot never idles while scenarios are left.
-static __device__ void b_sqp_stream(const DV &d)
+static __device__ __forceinline__ void b_sqp_stream(const DV &d)
 {
     const int inst = blockIdx.x;
     SQP_PTRS
