@@ -5,6 +5,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
+import sys
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 SO_PATH = os.path.join(_CSRC, "libsqphip.so")
@@ -26,11 +27,39 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if stale:
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-Wno-unused-value", "-Wno-pass-failed", "-o", SO_PATH] + srcs + ["-ldl"]
+               "-Wno-unused-value", "-Wno-pass-failed", "-Rpass-analysis=kernel-resource-usage",
+               "-o", SO_PATH] + srcs + ["-ldl"]
         if verbose:
             print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        proc = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+        other = [ln for ln in proc.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in ln]
+        if proc.returncode != 0 or verbose:
+            sys.stderr.write("\n".join(other) + "\n")
+        if proc.returncode != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+        _write_kernel_resources(proc.stderr)
     return SO_PATH
+
+
+RESOURCES_PATH = os.path.join(_CSRC, "kernel_resources.json")
+
+
+def _write_kernel_resources(remarks: str) -> None:
+    """Registers, scratch and LDS of every kernel as the compiler reports them (tests/test_abi.py guards the scratch: a
+    kernel that stops being inlined in one piece takes its 1 KB argument struct through scratch memory)."""
+    import json
+    import re
+    out, cur = {}, None
+    for ln in remarks.splitlines():
+        m = re.search(r"Function Name: (\S+)", ln)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|LDS Size \[bytes/block\]|Occupancy \[waves/SIMD\]): (\d+)", ln)
+        if m and cur is not None:
+            cur[m.group(1).split(" [")[0]] = int(m.group(2))
+    with open(RESOURCES_PATH, "w") as fh:
+        json.dump(out, fh, indent=0, sort_keys=True)
 
 
 class Options(C.Structure):

@@ -159,3 +159,21 @@ def test_julia_shim_mirrors_the_options_struct():
     L = _lib.lib()
     for sym in set(re.findall(r"\(:(sqphip_\w+), LIBSQPHIP\)", jl)):
         assert hasattr(L, sym), sym
+
+
+def test_no_kernel_takes_its_arguments_through_scratch():
+    """Every kernel takes the 1 KB device view `DV` by value.  A kernel whose helpers stop being inlined in one piece gets
+    that struct copied to scratch memory for the outlined parts -- 2 KB per lane on the stage kernel when the third
+    evaluator went in, -12 % QP/s with identical results.  The build records what the compiler
+    reports (sqpsolver.jl_amd/csrc/kernel_resources.json); a few hundred bytes of ordinary spills are tolerated."""
+    import json
+    if not os.path.exists(_lib.RESOURCES_PATH):
+        _lib.build(force=True)
+    res = json.load(open(_lib.RESOURCES_PATH))
+    assert len(res) >= 40
+    worst = {k: v["ScratchSize"] for k, v in res.items() if v.get("ScratchSize", 0) > 256}
+    assert not worst, worst
+    # the fused vector stages must leave room for one workgroup of 1024 threads per CU
+    for k, v in res.items():
+        if any(t in k for t in ("k_ipm_head", "k_ipm_mid", "k_ipm_tail", "k_sqp_stage")):
+            assert v["VGPRs"] <= 128, (k, v)
