@@ -177,3 +177,14 @@ def test_no_kernel_takes_its_arguments_through_scratch():
     for k, v in res.items():
         if any(t in k for t in ("k_ipm_head", "k_ipm_mid", "k_ipm_tail", "k_sqp_stage")):
             assert v["VGPRs"] <= 128, (k, v)
+
+
+def test_bench_refuses_a_rank_count_it_was_not_launched_with():
+    """`python bench.py --gpus N` with N != WORLD_SIZE must not quietly measure one GPU and call it N:
+    exit code 2 and the torch.distributed.run command line, before anything touches a GPU."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True)
+    assert r.returncode == 2 and "torch.distributed.run" in r.stderr and r.stdout.strip() == ""
