@@ -146,6 +146,12 @@ def main():
     # the status gather: RCCL inside the library (sqphip_gather_status); torch.distributed only carries the unique id
     use_lib_comm = False
     if world > 1 and args.backend == "nccl" and not args.one_device:
+        # sqphip_comm_init is collective: agree that every rank can load RCCL before any rank enters it
+        can = torch.tensor([1 if pkg.Context.comm_available() else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(can, op=dist.ReduceOp.MIN)
+        if not bool(can.item()):
+            print(f"[bench] rank {rank}: RCCL not loadable on every rank; status gather through torch.distributed", file=sys.stderr)
+    if world > 1 and args.backend == "nccl" and not args.one_device and bool(can.item()):
         try:
             idt = torch.zeros(128, dtype=torch.uint8, device=dev)
             if rank == 0:

@@ -312,8 +312,12 @@ int sqphip_sqp_status(sqphip_ctx *ctx, int32_t *ret_codes, int32_t *iters, int32
  * all-gather of int32 (ret, iter, done) per instance over RCCL on a communicator the library owns: rank 0 obtains the
  * 128-byte ncclUniqueId with sqphip_comm_unique_id and ships it to the other ranks by whatever channel the host has
  * (MPI, a file, torch.distributed, Julia's Distributed), every rank then calls sqphip_comm_init.  RCCL is loaded with
- * dlopen on the first of these calls; a single-rank host never needs it and sqphip_gather_status then returns the
- * local table.  Outputs: length `total`, ordered by global instance id; any may be NULL. */
+ * dlopen on the first of these calls; a context without a communicator returns the local table from
+ * sqphip_gather_status, one with a communicator always runs the collective (also for world = 1).  `total` must be the
+ * same on every rank of a call (the all-gather counts derive from it).  sqphip_comm_init is collective: call
+ * sqphip_comm_available (1 = librccl loads in this process) on every rank and agree on the minimum before entering it.
+ * Outputs: length `total`, ordered by global instance id; any may be NULL. */
+int sqphip_comm_available(void);
 int sqphip_comm_unique_id(void *id128);
 int sqphip_comm_init(sqphip_ctx *ctx, const void *id128, int32_t world, int32_t rank);
 int sqphip_gather_status(sqphip_ctx *ctx, int32_t total, int32_t *ret_codes, int32_t *iters, int32_t *done);

@@ -4,8 +4,8 @@
 # (src/algorithms/subproblem.jl:30-31).  It adds `QpHip <: AbstractSubOptimizer`, the sub-problem seat of
 # src/algorithms/subproblem.jl:1 as QpJuMP fills it (subproblem_JuMP.jl:127-183 QP, :185-244 LP phase, :283-347
 # L1QP, :352-393 feasibility restoration, :398-429 infeasibility problem), plus thin wrappers of the merit path and of
-# the multi-GPU status gather.  The only edit to existing code is the dispatch at
-# src/algorithms/sqp_trust_region.jl:314-331 (see `sub_optimize!(sqp)` at the end of this file).
+# the multi-GPU status gather.  The only edits to existing code are three one-line branches in
+# src/algorithms/sqp_trust_region.jl (:264, :314, :341; see "dispatch" at the end of this file).
 #
 # No Julia toolchain exists in the image this project is built in: this file is UNEXERCISED.  The call sequence and
 # the struct layouts are exercised through the same C ABI by tests/c_abi_smoke.c (plain C, dlopen) and by the Python
@@ -147,6 +147,7 @@ function hip_comm_unique_id()
     rc == 0 || error("sqphip_comm_unique_id failed ($rc)")
     return id
 end
+hip_comm_available() = ccall((:sqphip_comm_available, LIBSQPHIP), Cint, ()) == 1     # ask on every rank before hip_comm_init
 hip_comm_init(qp::QpHip, id::Vector{UInt8}, world::Integer, rank::Integer) =
     _check(qp.ctx, ccall((:sqphip_comm_init, LIBSQPHIP), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Int32, Int32), qp.ctx, id, world, rank))
 function hip_gather_status(qp::QpHip, total::Integer)
@@ -201,30 +202,64 @@ function hip_sqp_work(ctx::Ptr{Cvoid}, batch::Integer)
     return qp, ipm, fac
 end
 
-# ---- dispatch: replaces the body of sub_optimize!(sqp) at sqp_trust_region.jl:314-331 when the user passes
-# `"external_optimizer" => SqpHipBackend` (optimizer_with_attributes(SqpSolver.Optimizer, ...)) --------------------------
+# ---- dispatch ----------------------------------------------------------------------------------------------------------
+# The user selects the device path with
+#     optimizer_with_attributes(SqpSolver.Optimizer, "external_optimizer" => SqpSolver.SqpHipBackend, ...)
+# (`external_optimizer::Union{Nothing,DataType,...}`, src/parameters.jl:6-7: a struct type is a DataType).  Three call
+# sites of src/algorithms/sqp_trust_region.jl then branch on `uses_hip(sqp)`, one line each (INTEGRATION.md has the diff):
+#     :264  sub_optimize_lp!(sqp)   -> uses_hip(sqp) && return sub_optimize_lp_hip!(sqp)
+#     :314  sub_optimize!(sqp)      -> uses_hip(sqp) && return sub_optimize_hip!(sqp)
+#     :341  sub_optimize_soc!(sqp)  -> uses_hip(sqp) && return sub_optimize_soc_hip!(sqp)
 struct SqpHipBackend end
 
-function sub_optimize_hip!(sqp::AbstractSqpTrOptimizer)
+uses_hip(sqp::AbstractSqpOptimizer) = sqp.options.external_optimizer === SqpHipBackend
+
+# the context is created on first use and lives as long as the SqpTR object (sqp.optimizer, as upstream at :315-320)
+function _hip_seat!(sqp::AbstractSqpTrOptimizer)
     if isnothing(sqp.optimizer)
         sqp.optimizer = QpHip(sqp)
-    else
-        sqp.optimizer.data = QpData(sqp)                     # as :322; c, b are read from data, dE / h_val from sqp
     end
+    return sqp.optimizer
+end
+
+# sub_optimize!(sqp), sqp_trust_region.jl:314-331
+function sub_optimize_hip!(sqp::AbstractSqpTrOptimizer)
+    qp = _hip_seat!(sqp)
+    qp.data = QpData(sqp)                                   # as :322; c, b are read from data, dE / h_val from sqp
     if sqp.feasibility_restoration
-        return sub_optimize_FR!(sqp.optimizer, sqp.x, sqp.Δ)
+        return sub_optimize_FR!(qp, sqp.x, sqp.Δ)
     else
-        return sub_optimize!(sqp.optimizer, sqp.x, sqp.Δ)
+        return sub_optimize!(qp, sqp.x, sqp.Δ)
     end
 end
 
-# second-order correction (sqp_trust_region.jl:341-360): the same seat in mode 2 with b = E_soc
+# sub_optimize_soc!(sqp), sqp_trust_region.jl:341-360: the same seat in mode 2 with b = E_soc.  Upstream builds a FRESH
+# QpData around E_soc (:344-355); QpData(sqp) aliases b === sqp.E (sqp.jl:66-79), so writing E_soc through it would
+# overwrite the constraint values of the current iterate.
 function sub_optimize_soc_hip!(sqp::AbstractSqpTrOptimizer)
+    qp = _hip_seat!(sqp)
     sqp.problem.eval_g(sqp.x + sqp.p, sqp.E_soc)
-    sqp.E_soc .-= sqp.Jacobian * sqp.p
-    sqp.optimizer.data = QpData(sqp)
-    sqp.optimizer.data.b .= sqp.E_soc                        # QpData carries b by reference upstream: copy instead
-    p, _, _, _, _, _ = _solve(sqp.optimizer, 2, sqp.x, sqp.Δ)
+    sqp.E_soc -= sqp.Jacobian * sqp.p
+    qp.data = QpData(MOI.MIN_SENSE, sqp.Hessian, sqp.df, sqp.Jacobian, sqp.E_soc, sqp.problem.g_L, sqp.problem.g_U,
+                     sqp.problem.x_L, sqp.problem.x_U, sqp.problem.num_linear_constraints)
+    p, _, _, _, _, _ = _solve(qp, 2, sqp.x, sqp.Δ)
     sqp.p_soc .= sqp.p .+ p
     return nothing
+end
+
+# sub_optimize_lp!(sqp), sqp_trust_region.jl:264-304: the projection of the start point onto the linear rows and the
+# variable bounds (subproblem_JuMP.jl:185-244) through the seat's mode 3; the Jacobian values travel in sqp.dE
+# (eval_Jacobian!, sqp.jl:111-117), the result is the absolute point, small entries are dropped as upstream (:299-302)
+function sub_optimize_lp_hip!(sqp::AbstractSqpTrOptimizer)
+    sqp.f = sqp.problem.eval_f(sqp.x)
+    sqp.problem.eval_grad_f(sqp.x, sqp.df)
+    eval_Jacobian!(sqp)
+    qp = _hip_seat!(sqp)
+    qp.data = QpData(sqp)
+    sqp.x, sqp.lambda, sqp.mult_x_U, sqp.mult_x_L, sqp.sub_status = sub_optimize_lp(qp, sqp.x)
+    dropzeros!(sqp.x)
+    dropzeros!(sqp.lambda)
+    dropzeros!(sqp.mult_x_U)
+    dropzeros!(sqp.mult_x_L)
+    return
 end

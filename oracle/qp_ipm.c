@@ -441,7 +441,12 @@ static void kkt_sparse_setup(ora_qp *q)
         bp[u + 1] = o;          /* rows are visited in ascending u, variables (u < n) have empty lists */
     }
     for (int64_t u = n; u < Nf; ++u) if (bp[u + 1] < bp[u]) bp[u + 1] = bp[u];
-    q->sl = ora_sldl_analyse(Nf, q->nt, ti, tj, bp, bi, 0);
+    {
+        const char *ra = getenv("ORA_ROWS_AFTER");
+        const int unconstrained = ra && atoi(ra) == 0;
+        q->sl = ora_sldl_analyse(Nf, q->nt, ti, tj, unconstrained ? NULL : bp, unconstrained ? NULL : bi, 0);
+        if (getenv("ORA_SYM_STATS")) fprintf(stderr, "oracle: sparse order %ld nnz(L) %ld\n", (long)Nf, (long)ora_sldl_nnz_l(q->sl));
+    }
     q->tv = dalloc(q->nt);
     free(ti); free(tj); free(bp); free(bi);
 }
@@ -488,6 +493,22 @@ static int kkt_factor(ora_qp *q, double dw_floor, double *delta_w_out)
         if (np == q->n) {
             if (!q->sparse) for (int64_t j = 0; j < Nf; ++j) if (!isfinite(q->dinv[j]) || q->dinv[j] == 0.0) ++bad;
             if (!bad) {
+                if (q->sparse && getenv("ORA_KKT_DUMP")) {      /* experiment aid: every 16th accepted matrix as triplets */
+                    static long ndump = 0;
+                    if (ndump++ % 16 == 0) {
+                        char path[512];
+                        snprintf(path, sizeof path, "%s_%05ld.bin", getenv("ORA_KKT_DUMP"), ndump / 16);
+                        FILE *fh = fopen(path, "wb");
+                        if (fh) {
+                            int64_t *ti = (int64_t *)malloc(sizeof(int64_t) * (size_t)q->nt), *tj = (int64_t *)malloc(sizeof(int64_t) * (size_t)q->nt);
+                            kkt_triplets(q, dw, ti, tj, NULL);
+                            int64_t hdr[4] = { Nf, q->nt, q->n, (int64_t)attempt };
+                            fwrite(hdr, sizeof(int64_t), 4, fh); fwrite(ti, sizeof(int64_t), (size_t)q->nt, fh);
+                            fwrite(tj, sizeof(int64_t), (size_t)q->nt, fh); fwrite(q->tv, sizeof(double), (size_t)q->nt, fh);
+                            fclose(fh); free(ti); free(tj);
+                        }
+                    }
+                }
                 if (dw > 0.0) q->delta_w_last = dw;
                 *delta_w_out = dw;
                 return 0;
@@ -507,6 +528,11 @@ static int kkt_factor(ora_qp *q, double dw_floor, double *delta_w_out)
     }
     return -1;
 }
+
+/* experiment counters (not thread safe: run single-threaded when reading them) */
+static double g_dbg_solves, g_dbg_refines, g_dbg_maxres0, g_dbg_maxres1, g_dbg_bad0, g_dbg_bad1;
+void ora_dbg_counts(double *out) { out[0] = g_dbg_solves; out[1] = g_dbg_refines; out[2] = g_dbg_maxres0; out[3] = g_dbg_maxres1; out[4] = g_dbg_bad0; out[5] = g_dbg_bad1;
+    g_dbg_solves = g_dbg_refines = g_dbg_maxres0 = g_dbg_maxres1 = g_dbg_bad0 = g_dbg_bad1 = 0.0; }
 
 /* sol = K^-1 rhs through the factors in q->K (full or condensed form) */
 static void kkt_apply(ora_qp *q, const double *rhs, double *sol)
@@ -560,6 +586,8 @@ static double kkt_solve(ora_qp *q, double delta_w, const double *rhs, double *so
      * digits two implementations need to stay on one trajectory; one step of refinement against the FULL sparse
      * operator, taken when the residual is above 1e-11 relative, restores them. */
     en = kkt_residual(q, delta_w, rhs, sol, q->res);
+    g_dbg_solves += 1.0; if (en / rn > g_dbg_maxres0) g_dbg_maxres0 = en / rn;
+    if (en / rn > 1e-8) g_dbg_bad0 += 1.0;
     const char *rt_env = getenv("ORA_REFINE_TOL");
     const double rtol = rt_env ? atof(rt_env) : 1e-11;
     if (q->opt.kkt_condense && !no_refine && en > rtol * rn) {
@@ -570,7 +598,10 @@ static double kkt_solve(ora_qp *q, double delta_w, const double *rhs, double *so
         for (int64_t i = 0; i < N; ++i) sol[i] += corr[i];
         en = kkt_residual(q, delta_w, rhs, sol, q->res);
         free(corr); free(r0);
+        g_dbg_refines += 1.0;
     }
+    if (en / rn > g_dbg_maxres1) g_dbg_maxres1 = en / rn;
+    if (en / rn > 1e-10) g_dbg_bad1 += 1.0;
     return en / rn;
 }
 

@@ -69,7 +69,9 @@ static void min_degree(int64_t n, const int64_t *ap, const int64_t *ai, const in
         memcpy(adj[v], ai + ap[v], sizeof(int64_t) * (size_t)len[v]);
     }
     if (bp) {       /* after[v] = the rows waiting for v */
-        for (int64_t u = 0; u < n; ++u) { need[u] = bp[u + 1] - bp[u]; for (int64_t k = bp[u]; k < bp[u + 1]; ++k) afp[bi[k] + 2]++; }
+        const char *wk = getenv("ORA_ROWS_AFTER");
+        const int weak = wk && atoi(wk) == 2;     /* experiment: a row is eligible behind ANY ONE of its variables */
+        for (int64_t u = 0; u < n; ++u) { need[u] = bp[u + 1] - bp[u]; if (weak) { const char *sl = getenv("ORA_ROWS_SLACK"); if (sl) { if (need[u] > 0) { need[u] -= atoi(sl); if (need[u] < 1) need[u] = 1; } } else if (need[u] > 1) need[u] = 1; } for (int64_t k = bp[u]; k < bp[u + 1]; ++k) afp[bi[k] + 2]++; }
         for (int64_t v = 0; v < n; ++v) afp[v + 2] += afp[v + 1];
         afi = (int64_t *)malloc(sizeof(int64_t) * (size_t)(bp[n] + 1));
         for (int64_t u = 0; u < n; ++u) for (int64_t k = bp[u]; k < bp[u + 1]; ++k) afi[afp[bi[k] + 1]++] = u;
@@ -102,7 +104,7 @@ static void min_degree(int64_t n, const int64_t *ap, const int64_t *ai, const in
             if (need[u] == 0) { hent e = {o, u}; hpush(&H, e); }
         }
         if (bp)
-            for (int64_t t = afp[v]; t < afp[v + 1]; ++t) { const int64_t u = afi[t]; if (--need[u] == 0) { hent e = {len[u], u}; hpush(&H, e); } }
+            for (int64_t t = afp[v]; t < afp[v + 1]; ++t) { const int64_t u = afi[t]; if (gone[u] || need[u] <= 0) continue; if (--need[u] == 0) { hent e = {len[u], u}; hpush(&H, e); } }
         free(adj[v]); adj[v] = NULL;
     }
     for (int64_t v = 0; v < n; ++v) free(adj[v]);

@@ -1091,6 +1091,10 @@ extern "C" int sqphip_sqp_stream_begin(sqphip_ctx *h, int32_t n_scenarios)
         Q.ohm = C.dalloc<double>(M * d.nl * 12); Q.c2 = C.dalloc<double>(M * d.ng); Q.c1 = C.dalloc<double>(M * d.ng);
         Q.rx = C.dalloc<double>(M * d.n); Q.robj = C.dalloc<double>(M);
         Q.rstat = C.dalloc<int>(M); Q.riter = C.dalloc<int>(M);
+        // every slot starts as "queue exhausted" (-1): the stage kernel's queue step stays off until
+        // sqphip_sqp_stream_run arms the slots (-2), so a plain sqp_reset / sqp_run between _begin and _stream_run
+        // behaves as if no queue existed (dalloc zero-fills, and 0 is a valid scenario id)
+        SQPHIP_HIP_OK(hipMemsetAsync(Q.slot_scen, 0xff, sizeof(int) * (size_t)d.B, C.stream));
         SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
         make_lanes(C);
         return SQPHIP_OK;

@@ -55,6 +55,11 @@ void block_of(int total, int world, int rank, int &lo, int &hi)
 
 }  // namespace
 
+// 1 when librccl can be loaded in this process, else 0.  Hosts call it on every rank and agree (MIN over ranks, by their
+// own channel) BEFORE anybody enters sqphip_comm_init, which is collective: a rank that cannot load RCCL would otherwise
+// leave the others waiting inside ncclCommInitRank.
+extern "C" int sqphip_comm_available(void) { return g_rccl.load() ? 1 : 0; }
+
 extern "C" int sqphip_comm_unique_id(void *id128)
 {
     if (!id128) return SQPHIP_EINVAL;
@@ -116,9 +121,11 @@ extern "C" int sqphip_gather_status(sqphip_ctx *h, int32_t total, int32_t *ret_c
         SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
         std::vector<int32_t> loc(3 * (size_t)cap, 0), all(3 * (size_t)cap * world, 0);
         for (int b = 0; b < C.d.B; ++b) { loc[3 * b] = S[b].ret; loc[3 * b + 1] = S[b].iter; loc[3 * b + 2] = S[b].done; }
-        if (world == 1) all = loc;
+        if (!C.comm) all = loc;                 // no communicator: the local table.  With one, the collective runs even for world == 1
         else {
-            if (!C.comm_buf) SQPHIP_HIP_OK(hipMalloc(&C.comm_buf, sizeof(int32_t) * 3 * (size_t)cap * (world + 1)));
+            // the device buffer grows with the largest block seen (a later call may name a larger `total`)
+            if (C.comm_buf && C.comm_cap < cap) { SQPHIP_HIP_OK(hipFree(C.comm_buf)); C.comm_buf = nullptr; }
+            if (!C.comm_buf) { SQPHIP_HIP_OK(hipMalloc(&C.comm_buf, sizeof(int32_t) * 3 * (size_t)cap * (world + 1))); C.comm_cap = cap; }
             int32_t *send = (int32_t *)C.comm_buf, *recv = send + 3 * (size_t)cap;
             SQPHIP_HIP_OK(hipMemcpyAsync(send, loc.data(), sizeof(int32_t) * 3 * (size_t)cap, hipMemcpyHostToDevice, C.stream));
             const ncclResult_t r = g_rccl.AllGather(send, recv, 3 * (size_t)cap, ncclInt32, (ncclComm_t)C.comm, C.stream);

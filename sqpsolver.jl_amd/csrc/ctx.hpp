@@ -173,7 +173,7 @@ struct Ctx {
     bool acopf_attached = false;
     // RCCL communicator for the status gather (comm.hip); null: single rank
     void *comm = nullptr, *comm_buf = nullptr;
-    int comm_world = 1, comm_rank = 0;
+    int comm_world = 1, comm_rank = 0, comm_cap = 0;   // comm_cap: block capacity comm_buf was sized for
     // host copies of structure for misc use
     int64_t n = 0, m = 0;
     // counters

@@ -521,13 +521,23 @@ void sqp_run(Ctx &C, int max_outer)
     if (C.lanes.empty()) { sqp_run_lane(C, max_outer); return; }
     std::vector<std::thread> th;
     std::vector<std::string> errs(C.lanes.size());
-    for (size_t g = 0; g < C.lanes.size(); ++g)
-        th.emplace_back([&, g] {
-            try {
-                SQPHIP_HIP_OK(hipSetDevice(C.opt.device));
-                sqp_run_lane(*C.lanes[g], max_outer);
-            } catch (const std::string &e) { errs[g] = e; }
-        });
+    // nothing may leave a lane thread as an exception (std::terminate would take the host application down), and a
+    // failure to start thread k must not destroy the joinable threads 0..k-1
+    try {
+        for (size_t g = 0; g < C.lanes.size(); ++g)
+            th.emplace_back([&, g] {
+                try {
+                    SQPHIP_HIP_OK(hipSetDevice(C.opt.device));
+                    sqp_run_lane(*C.lanes[g], max_outer);
+                } catch (const std::string &e) { errs[g] = e; }
+                catch (const std::bad_alloc &) { errs[g] = "sqphip: out of host memory in an instance group"; }
+                catch (const std::exception &e) { errs[g] = std::string("sqphip: instance group: ") + e.what(); }
+                catch (...) { errs[g] = "sqphip: unknown exception in an instance group"; }
+            });
+    } catch (...) {
+        for (auto &t : th) t.join();
+        throw std::string("sqphip: could not start the instance-group threads");
+    }
     for (auto &t : th) t.join();
     for (auto &e : errs) if (!e.empty()) throw e;
 }

@@ -71,6 +71,7 @@ std::vector<int> amd_order(int nu, const std::vector<std::vector<int>> &adj, con
     if (!before.empty())
         for (int u = 0; u < nu; ++u) {
             need[u] = (int)before[u].size();
+            if (getenv("SQPHIP_SYM_SLACK") && need[u] > 0) need[u] = std::max(1, need[u] - atoi(getenv("SQPHIP_SYM_SLACK")));   // experiment
             for (int v : before[u]) after[v].push_back(u);
         }
     Buckets B(nu);
@@ -131,7 +132,7 @@ std::vector<int> amd_order(int nu, const std::vector<std::vector<int>> &adj, con
             if (B.where[i] >= 0) { B.remove(i); B.insert(i, deg[i]); }
         }
         M[p] = Lp;
-        for (int u : after[p]) if (--need[u] == 0) B.insert(u, std::min(deg[u], nleft > 0 ? nleft - 1 : 0));
+        for (int u : after[p]) if (state[u] == 0 && need[u] > 0 && --need[u] == 0) B.insert(u, std::min(deg[u], nleft > 0 ? nleft - 1 : 0));
     }
     return order;
 }
@@ -243,7 +244,7 @@ SparseSym sparse_symbolic(int nu, const std::vector<std::vector<int>> &adj, cons
     // merged front stays within `chain_front` rows, whatever the zeros cost.  The fronts along the spine are eliminated
     // and solved one after the other by construction (each waits for its child): fewer, larger fronts there trade flops
     // that run in parallel for per-front latency that does not.
-    static const int chain_front = getenv("SQPHIP_SYM_CHAIN") ? atoi(getenv("SQPHIP_SYM_CHAIN")) : opt.chain_front;
+    const int chain_front = getenv("SQPHIP_SYM_CHAIN") ? atoi(getenv("SQPHIP_SYM_CHAIN")) : opt.chain_front;   // read per call
     if (chain_front > 0) {
         std::vector<std::vector<int>> kids(ns0);
         std::vector<int> height(ns0, 0), par(ns0, -1);

@@ -308,6 +308,11 @@ class Context:
 
     # ---- multi-GPU status gather (RCCL inside the library)
     @staticmethod
+    def comm_available() -> bool:
+        """librccl loads in this process (ask on every rank and agree before the collective comm_init)"""
+        return bool(_lib.lib().sqphip_comm_available())
+
+    @staticmethod
     def comm_unique_id() -> bytes:
         buf = C.create_string_buffer(128)
         rc = _lib.lib().sqphip_comm_unique_id(C.cast(buf, C.c_void_p))
