@@ -56,10 +56,12 @@ def main():
                     help="ACOPF evaluator: polar (ACP, default), rectangular (ACR, the one examples/acopf/opf.jl:46 runs) "
                          "or the W-space model of examples/acopf/acwr.jl")
     ap.add_argument("--batch", type=int, default=None, help="instances of the whole job (default 512 for case118)")
+    ap.add_argument("--quick", action="store_true", help="development runs: timed steps only (implies --no-cpu-baseline --no-termination --no-dense-ldlt --no-screening)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-termination", action="store_true", help="skip the run-to-termination legs")
     ap.add_argument("--no-dense-ldlt", action="store_true", help="skip the dense LDL^T record")
     ap.add_argument("--no-screening", action="store_true", help="skip the scenario-queue record")
+    ap.add_argument("--no-batch-curve", action="store_true", help="skip the 64 / 128 / 256-scenario runs behind `scaling_prediction`")
     ap.add_argument("--screening-factor", type=int, default=4, help="scenario-queue record: scenarios = factor x slots")
     ap.add_argument("--literal-quirks", type=int, default=1)
     ap.add_argument("--kkt-mode", type=int, default=0, help="options.kkt_mode: 0 auto (sparse here), 1 dense MFMA, 2 sparse")
@@ -69,13 +71,15 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event timing of the factor / solve kernels")
     ap.add_argument("--sqp-options", default="example", choices=["example", "defaults"],
                     help="example: tol_infeas 1e-6, tol_residual 1e-4, use_soc (examples/acopf/opf.jl:76-79, the headline); "
-                         "defaults: the reference's Parameters defaults (parameters.jl:17-29: tol_residual 1e-6, no SOC)")
+                         "defaults: the reference's Parameters defaults (parameters.jl:17-29: tol_direction = tol_residual = tol_infeas = 1e-8, no SOC)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank flow "
                          "on a box with fewer GPUs than ranks, together with --one-device)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--dump-status", default=None, help="rank 0 writes the gathered (ret, iter, done) table to this JSON file")
     args = ap.parse_args()
+    if args.quick:
+        args.no_cpu_baseline = args.no_termination = args.no_dense_ldlt = args.no_screening = args.no_batch_curve = True
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -130,13 +134,15 @@ def main():
             scen[s_id] = (net, acopf_layout(net))
         return scen[s_id]
 
-    def make_ctx(literal_quirks, max_iter=3000):
+    def make_ctx(literal_quirks, max_iter=3000, first=None):
+        """context over this rank's block of scenarios, or (first = k) over the scenarios 0..k-1"""
+        ids = range(lo, hi) if first is None else range(first)
         opts = pkg.default_options(max_iter=max_iter, literal_quirks=literal_quirks, device=local_rank,
                                    ipm_corrector=args.ipm_corrector, **lin_kw, **sqp_kw)
         ctx = pkg.Context(lay0.n, lay0.m, lay0.num_linear, lay0.jrow, lay0.jcol, lay0.hrow, lay0.hcol,
-                          lay0.xL, lay0.xU, lay0.gL, lay0.gU, opts, batch=B)
+                          lay0.xL, lay0.xU, lay0.gL, lay0.gU, opts, batch=len(ids))
         ctx.acopf_attach(base, lay0)
-        for b, s_id in enumerate(range(lo, hi)):
+        for b, s_id in enumerate(ids):
             ctx.acopf_set_instance(b, *scenario(s_id))
         ctx.sqp_reset()
         return ctx, opts
@@ -238,17 +244,23 @@ def main():
         # the same with every solve counted (corrector and refinement solves read L again: 16 nnz(L) + 16 N each)
         loc_sol = c1["n_solve"] - c0["n_solve"]
         b_all = loc_fac * (12.0 * c1["nnz_k"] + 8.0 * c1["nnz_l"] + 16.0 * N) + loc_sol * (16.0 * c1["nnz_l"] + 16.0 * N)
-        traffic = None
-        tpath = os.path.join(_ROOT, "profiles", "mf_traffic.json")
-        if os.path.exists(tpath):
+        # HBM bytes per instance-factorisation from the PMC passes (profiles/mf_traffic_<workload>.json, written by
+        # scripts/make_traffic_profile.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of THIS workload and build);
+        # null when none was collected for this workload -- never another workload's constant
+        traffic, traffic_src = None, None
+        tpath = os.path.join(_ROOT, "profiles", f"mf_traffic_{args.workload}.json")
+        if os.path.exists(tpath) and args.formulation == "polar" and args.kkt_mode in (0, 2):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_instance_factorisation")
+                tj = json.load(open(tpath))
+                if int(tj.get("nnz_l", -1)) == int(c1["nnz_l"]):          # same plan as the one measured
+                    traffic = tj.get("hbm_bytes_per_instance_factorisation")
+                    traffic_src = os.path.relpath(tpath, _ROOT)
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": "k_mf_values + k_mf_factor2<*> (factor, v_mfma_f64_16x16x4_f64 rank-4 blocks) + "
                                               "k_mf_fwd / k_mf_bwd (solves)",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic, "traffic_static": True,
+                    "traffic": traffic, "traffic_static": True, "traffic_source": traffic_src,
                     "bytes_per_instance_factorisation": b_sparse, "nnz_k_lower": int(c1["nnz_k"]), "nnz_l": int(c1["nnz_l"]),
                     "instance_factorisations": int(loc_fac), "instance_solves": int(loc_sol),
                     "achieved_counting_all_solves": b_all / ksec / 1e9 if ksec > 0 else 0.0,
@@ -285,6 +297,33 @@ def main():
         except Exception as e:       # an optional leg must never cost the headline line
             print(f"[bench] optional record 'dense' failed: {e!r}", file=sys.stderr)
             dense = {"error": repr(e)}
+
+    # Batch curve on this one GPU: the same K timed steps over the first 64 / 128 / 256 scenarios.  A rank of an N-GPU job
+    # of the 512-scenario workload holds 512 / N scenarios, so these figures predict the strong-scaling curve the driver
+    # measures on a whole node (no data crosses ranks; the status gather is a few KB): speedup(N) = N x QP/s(512 / N) / QP/s(512).
+    scaling_prediction = None
+    if rank == 0 and world == 1 and not args.no_batch_curve and small and args.workload == "case118":
+        try:
+            curve = {str(total): n_qp / elapsed}
+            for bk in (total // 2, total // 4, total // 8):
+                kctx, _ = make_ctx(args.literal_quirks, first=bk)
+                if args.warmup > 0:
+                    kctx.sqp_run(args.warmup)
+                k0 = kctx.counters()
+                torch.cuda.synchronize()
+                ta = time.perf_counter()
+                kctx.sqp_run(args.steps)
+                torch.cuda.synchronize()
+                tb = time.perf_counter()
+                curve[str(bk)] = (kctx.counters()["n_qp"] - k0["n_qp"]) / (tb - ta)
+                kctx.close()
+            scaling_prediction = {
+                "qp_per_s_by_resident_scenarios": curve,
+                "predicted_strong_scaling_speedup": {str(g): g * curve[str(total // g)] / curve[str(total)] for g in (2, 4, 8)},
+                "note": "one GPU, same steps / warm-up; a prediction from the batch curve, not a multi-GPU measurement"}
+        except Exception as e:
+            print(f"[bench] optional record 'scaling_prediction' failed: {e!r}", file=sys.stderr)
+            scaling_prediction = {"error": repr(e)}
 
     termination = None
     if rank == 0 and world == 1 and not args.no_termination and small:
@@ -407,6 +446,9 @@ def main():
                        "by_mode": by_mode,
                        "busiest_instance_over_mean": float(wfac.max() / max(1.0, wfac.mean())),
                        "instances_done_in_timed_steps": int(np.sum(g_done)),
+                       "parity_note": "this configuration (literal_quirks = 1) is compared with the oracle by exact decisions and "
+                                      "per-sub-problem replays (tests/test_gpu_parity_depth.py); iterates at 1e-8 are "
+                                      "asserted on converging runs (literal_quirks = 0), DESIGN.md section 8",
                        "note": "with literal_quirks = 1 (the reference's JuMP-sign Hessian, SURVEY.md App. C #2) the "
                                "sub-problems are non-convex and most scenarios never meet the termination test; see "
                                "`termination` for both sign conventions run to the end"},
@@ -414,6 +456,7 @@ def main():
             "dense_ldlt": dense,
             "termination": termination,
             "screening": screening,
+            "scaling_prediction": scaling_prediction,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))

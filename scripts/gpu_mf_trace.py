@@ -8,7 +8,7 @@ from sqpsolver_jl_amd import _lib
 so = "/tmp/libsqphip_trace.so"
 srcs = [os.path.join(_lib._CSRC, s) for s in _lib.SOURCES]
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w",
-                       "-DSQPHIP_MF_TRACE", "-o", so] + srcs)
+                       "-DSQPHIP_MF_TRACE", "-mllvm", "-amdgpu-mfma-vgpr-form", "-o", so] + srcs + ["-ldl"])
 _lib.SO_PATH = so
 import sqpsolver_jl_amd as pkg
 from sqpsolver_jl_amd.acopf_synth import acopf_synth, acopf_layout, contingency, CASES
@@ -52,3 +52,14 @@ for lo, hi in ((0, 8), (8, 15), (15, 30), (30, 1e9)):
         print(f"  fronts with total in [{lo},{hi}) us: {int(sel.sum()):4d}  mean phases " + " ".join(f"{n}={v:.1f}" for n, v in zip(names, d[sel].mean(axis=0))))
 t0 = buf[:, 0].min()
 print("span of the last factorisation (us):", (buf[:, 5].max() - t0) * 10e-3)
+
+# shader-clock stamps inside the static front kernel (wave 0): tiles loaded | barrier | block 0: A | barrier | B | barrier | C ... | results
+buf2 = np.zeros((ns, 16), dtype=np.int64)
+L.sqphip_mf_trace2_read.argtypes = [C.POINTER(C.c_longlong), C.c_int]
+if L.sqphip_mf_trace2_read(buf2.ctypes.data_as(C.POINTER(C.c_longlong)), ns) == 0:
+    print("static front kernel, wave 0, cycles: load | bar | A(blk0) | bar | B(blk0) | bar | C(blk0)=to blk1 start | ... all blocks | bar | results")
+    for srow in list(order[:8]) + list(order[60:64]):
+        t = buf2[srow]
+        if t[0] == 0: continue
+        seg = [t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5], (t[9] - t[6]) if t[9] > 0 else -1, t[7] - t[2], t[8] - t[7], t[10] - t[8]]
+        print(f"  front {srow:4d}: " + " ".join(f"{int(v):7d}" for v in seg))

@@ -16,28 +16,59 @@ HEADERS = ["sqphip_internal.hpp", "ctx.hpp", "sparse.hpp", "dev_util.hpp", "acop
 _lib = None
 
 
+# per-file extra flags.  mfront.hip: keep the MFMA accumulators of the front kernels in VGPRs -- the elimination works on
+# the accumulator tiles with ordinary vector instructions between the MFMAs, and with the accumulators homed in AGPRs
+# the compiler copied all of them (72 v_accvgpr_read per four-column step) in and out at every step
+EXTRA_FLAGS = {"mfront.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+_OBJ = os.path.join(_CSRC, "build")
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 every translation unit into csrc/libsqphip.so (in-tree)."""
-    srcs = [os.path.join(_CSRC, s) for s in SOURCES if os.path.exists(os.path.join(_CSRC, s))]
-    deps = srcs + [os.path.join(_CSRC, h) for h in HEADERS if os.path.exists(os.path.join(_CSRC, h))]
-    stale = force or not os.path.exists(SO_PATH)
-    if not stale:
-        t = os.path.getmtime(SO_PATH)
-        stale = any(os.path.getmtime(d) > t for d in deps)
-    if stale:
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-Wno-unused-value", "-Wno-pass-failed", "-Rpass-analysis=kernel-resource-usage",
-               "-o", SO_PATH] + srcs + ["-ldl"]
+    """hipcc --offload-arch=gfx950: every translation unit to an object (only the stale ones, in parallel), then linked
+    into csrc/libsqphip.so (in-tree)."""
+    from concurrent.futures import ThreadPoolExecutor
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(_CSRC, s))]
+    hdrs = [os.path.join(_CSRC, h) for h in HEADERS if os.path.exists(os.path.join(_CSRC, h))]
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(_OBJ, exist_ok=True)
+    hdr_t = max([os.path.getmtime(h) for h in hdrs] + [os.path.getmtime(os.path.abspath(__file__))])
+    jobs = []
+    for sname in srcs:
+        src, obj = os.path.join(_CSRC, sname), os.path.join(_OBJ, sname + ".o")
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            jobs.append((sname, src, obj))
+
+    def compile_one(job):
+        sname, src, obj = job
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-Wno-unused-value", "-Wno-pass-failed",
+               "-Rpass-analysis=kernel-resource-usage"] + EXTRA_FLAGS.get(sname, []) + ["-o", obj, src]
         if verbose:
             print(" ".join(cmd))
         proc = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
-        other = [ln for ln in proc.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in ln]
-        if proc.returncode != 0 or verbose:
-            sys.stderr.write("\n".join(other) + "\n")
-        if proc.returncode != 0:
-            raise subprocess.CalledProcessError(proc.returncode, cmd)
-        _write_kernel_resources(proc.stderr)
+        with open(obj + ".remarks", "w") as fh:
+            fh.write(proc.stderr if proc.returncode == 0 else "")
+        return sname, proc.returncode, proc.stderr, cmd
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            results = list(ex.map(compile_one, jobs))
+        for sname, rc, err, cmd in results:
+            other = [ln for ln in err.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in ln]
+            if rc != 0 or verbose:
+                sys.stderr.write("\n".join(other) + "\n")
+            if rc != 0:
+                raise subprocess.CalledProcessError(rc, cmd)
+    objs = [os.path.join(_OBJ, sname + ".o") for sname in srcs]
+    if jobs or not os.path.exists(SO_PATH) or any(os.path.getmtime(o) > os.path.getmtime(SO_PATH) for o in objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO_PATH] + objs + ["-ldl"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        remarks = ""
+        for o in objs:
+            if os.path.exists(o + ".remarks"):
+                remarks += open(o + ".remarks").read()
+        _write_kernel_resources(remarks)
     return SO_PATH
 
 

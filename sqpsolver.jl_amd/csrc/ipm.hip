@@ -936,7 +936,10 @@ void ipm_sweep(Ctx &C, bool sqp_level)
     // and, with hundreds of instances in flight, 2 forward + 3 backward passes nearly every sweep, each as long as its
     // slowest front chain however few instances took part.)
     const int last = d.condense != 0 ? 0 : 1;          // full form: no refinement
+    // (the solve timer brackets the two solve slots separately: the vector stage between them is not a solve kernel)
+    if (C.tm.enabled) { hipEventRecord(ev.second, s); C.tm.pending_solve.push_back(ev); }
     hipLaunchKernelGGL(k_ipm_mid, gB, bT, 0, s, d, last);
+    if (C.tm.enabled) { ev = C.tm.get(); hipEventRecord(ev.first, s); }
     lin_solve(PH_RESOLVE, false);
     if (C.tm.enabled) { hipEventRecord(ev.second, s); C.tm.pending_solve.push_back(ev); }
     hipLaunchKernelGGL(k_ipm_tail, gB, bT, 0, s, d, last);

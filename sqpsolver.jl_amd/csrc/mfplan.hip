@@ -144,17 +144,14 @@ MfPlan mf_build_plan(int n, int m, const std::vector<int> &kpos, int mk, const s
         }
         for (int s = 0; s < S.ns; ++s) P.ev_ptr[s + 1] += P.ev_ptr[s];
     }
-    // launch schedule: level by level (leaves first); inside a level the fronts are split by size class = kernel
-    // variant of mfront.hip (T = 16-row tiles of the front with its right-hand-side row):
-    //   class 0: T <= 2    1 wave,  front image in LDS          class 3: T <= 8    4 waves, image in the front arena
-    //   class 1: T <= 4    2 waves, front image in LDS          class 4: T <= 13   8 waves, image in the front arena
-    //   class 2: T == 5    4 waves, front image in LDS          class 5: larger    rank-1 kernel in place (no MFMA)
+    // launch schedule: level by level (leaves first); inside a level one launch per front height in 16-row tiles T (the
+    // front with its right-hand-side row): the front kernels of mfront.hip are compiled per T (k_mf_front<T, ...>, T <= 8);
+    // taller fronts share the generic kernels: class 8 = T <= 13 (k_mf_factor2<8, 12>), class 9 = larger (rank-1 kernel)
     auto tiles = [&](int s) { return (S.sn_nc[s] + S.sn_nr[s] + 1 + 15) / 16; };
-    auto cls = [&](int s) { const int T = tiles(s); return T <= 2 ? 0 : (T <= 4 ? 1 : (T <= 5 ? 2 : (T <= 8 ? 3 : (T <= 13 ? 4 : 5)))); };
-    static const int cls_threads[6] = {64, 128, 256, 256, 512, 256};
+    auto cls = [&](int s) { const int T = tiles(s); return T <= 8 ? T - 1 : (T <= 13 ? 8 : 9); };
     for (int l = 0; l < S.nlevels; ++l) {
-        for (int c = 0; c < 6; ++c) {
-            MfLaunch L{(int)P.sched.size(), 0, cls_threads[c], 0, c, 0};
+        for (int c = 0; c < 10; ++c) {
+            MfLaunch L{(int)P.sched.size(), 0, 0, 0, c, 0};
             for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; ++q) {
                 const int s = S.level_sn[q];
                 if (cls(s) != c) continue;
@@ -163,10 +160,7 @@ MfPlan mf_build_plan(int n, int m, const std::vector<int> &kpos, int mk, const s
                 L.tiles = std::max(L.tiles, tiles(s));
             }
             if (!L.count) continue;
-            // dynamic LDS: [image (16 T)^2 for classes 0-2][panel X and L: 2 x 4 x 16 T][4 x 4 block: 16][1 / D of the columns: 16 T]
-            const int R = 16 * L.tiles;
-            L.lds_bytes = c == 5 ? 0 : 8 * ((c <= 2 ? R * R : 0) + 8 * R + 16 + R);
-            P.fac.push_back(L);
+            P.fac.push_back(L);                       // threads and LDS are the kernel's business (mf_factor)
         }
     }
     // solves: one launch per level; a workgroup of four waves takes one front of more than 64 rows or four smaller ones

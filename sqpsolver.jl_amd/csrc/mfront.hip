@@ -63,8 +63,12 @@ __device__ __forceinline__ double mf_item_value(const MfItem &it, const double *
 #ifdef SQPHIP_MF_TRACE
 __device__ long long g_mf_trace[1 << 16][8];
 #define MF_TR(i) if (inst == 0 && threadIdx.x == 0 && s < (1 << 16)) g_mf_trace[s][i] = (long long)wall_clock64();
+// shader-clock stamps inside the static front kernel (wave 0 of instance 0): [front][16]
+__device__ long long g_mf_trace2[1 << 12][16];
+#define MF_TRW(i) if (W == 0 && trs >= 0 && trs < (1 << 12) && lane == 0) g_mf_trace2[trs][i] = (long long)clock64();
 #else
 #define MF_TR(i)
+#define MF_TRW(i)
 #endif
 
 // Thread layout inside a front: RL row lanes x (NT / RL) column groups; RL = 16 / 32 / 64 by front height so that a
@@ -156,6 +160,10 @@ __global__ __launch_bounds__(NT) void k_mf_factor(DV d, int sbegin, int want, in
 extern "C" int sqphip_mf_trace_read(long long *out, int nfronts)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mf_trace), sizeof(long long) * 8 * (size_t)nfronts);
+}
+extern "C" int sqphip_mf_trace2_read(long long *out, int nfronts)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mf_trace2), sizeof(long long) * 16 * (size_t)nfronts);
 }
 #endif
 
@@ -364,6 +372,316 @@ __global__ __launch_bounds__(64 * NW) void k_mf_factor2(DV d, int sbegin, int wa
         }
     }
     for (int k = tid; k < nc; k += NT) dinv[k] = dl[k];
+    MF_TR(5)
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The static front kernel (round 3): k_mf_front<T, NW, LDSIMG>, T = 16-row tiles of the front (compile time).
+//
+// What the trace of k_mf_factor2 showed (scripts/gpu_mf_trace.py, scripts/probes/latency_probe.hip): ~2 us per four-column
+// step on a front of four or eight waves, 1 us on a single wave, where the dependent chain of a step -- 4 x 4 block to
+// every lane, its LDL^T (43 cycles per reciprocal), three wave shuffles (85 cycles each), one MFMA (81 cycles) -- accounts
+// for a third of that.  The rest is code generation: the tiles of a wave are found by runtime predicates over a register
+// array (a ladder of exec-mask branches per phase, scalar registers spilled into vector lanes, the accumulators copied
+// between the two halves of the register file every step).  Here NOTHING about the tiles is decided at run time:
+//   * the front has T tile rows, tile row r belongs to wave r mod NW, every wave runs its own specialisation of the code
+//     (template parameter W) in which the loop over the sixteen-column blocks is unrolled: which tile is the diagonal
+//     tile, which are solved against it and which receive the update is known to the compiler, every register index is
+//     a constant, there is no branch but the two on the number of live columns;
+//   * a block of sixteen columns costs two workgroup barriers (four-column steps: eight):
+//       A. the wave that owns the diagonal tile factorises it alone, in registers: four sub-steps of four columns --
+//          the 4 x 4 diagonal block through a 64-entry LDS scratch of the wave (10 readlanes of a double cost 216
+//          cycles, the LDS round trip 130), its LDL^T, the tile's rows times the inverse of the unit 4 x 4 factor (three
+//          INDEPENDENT shuffles: 114 cycles instead of 3 x 85), one rank-4 MFMA on the tile itself; it publishes the
+//          scaled tile, the four 4 x 4 records and the pivot reciprocals;
+//       B. every tile below solves its sixteen columns the same way (per sub-block the 4 x 4 product, then one MFMA
+//          against the published diagonal tile for the later columns) and publishes its rows of L; X = L D stays in
+//          the registers of the row's owner;
+//       C. every tile to the right receives the rank-16 update as four MFMAs, A operand from LDS, B operand from the
+//          registers of the row.
+// Same arithmetic as k_mf_factor2 up to the order of a few roundings (the substitution inside a 4 x 4 block is a product
+// with the block's inverse); the host reference of mfplan.hip holds both to 1e-11.
+struct MfBlk4 { double i0, i1, i2, i3, m10, m20, m21, m30, m31, m32; };
+
+// LDL^T of a 4 x 4 diagonal block known to every lane (uniform arithmetic); bw live columns (a partial last block
+// eliminates nothing beyond them).  m = strictly lower part of the inverse of the unit factor.
+__device__ __forceinline__ MfBlk4 mf_ldl4(double a00, double a10, double a11, double a20, double a21, double a22, double a30,
+                                           double a31, double a32, double a33, int bw)
+{
+    double i1 = 0.0, i2 = 0.0, i3 = 0.0, l21 = 0.0, l31 = 0.0, l32 = 0.0;
+    const double i0 = mf_rcp(a00);
+    const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
+    a11 -= l10 * a10; a21 -= l10 * a20; a22 -= l20 * a20; a31 -= l10 * a30; a32 -= l20 * a30; a33 -= l30 * a30;
+    if (bw > 1) { i1 = mf_rcp(a11); l21 = a21 * i1; l31 = a31 * i1; a22 -= l21 * a21; a32 -= l21 * a31; a33 -= l31 * a31; }
+    if (bw > 2) { i2 = mf_rcp(a22); l32 = a32 * i2; a33 -= l32 * a32; }
+    if (bw > 3) i3 = mf_rcp(a33);
+    MfBlk4 B;
+    B.i0 = i0; B.i1 = i1; B.i2 = i2; B.i3 = i3;
+    B.m10 = -l10; B.m21 = -l21; B.m32 = -l32;
+    B.m20 = -(l20 + l21 * B.m10);
+    B.m31 = -(l31 + l32 * B.m21);
+    B.m30 = -(l30 + l31 * B.m10 + l32 * B.m20);
+    return B;
+}
+
+// rows of a tile through a 4 x 4 sub-block: x <- x L4^-T, the four entries of a row sitting in the lane groups l4 = 0..3.
+// The lane-group selection is arithmetic (s1, s2, s3 = 1.0 in the lane group of that number, else 0.0): written as nested
+// ?: on l4 the compiler built a tree of exec-mask branches per use.
+struct MfLaneSel { double s0, s1, s2, s3; };
+__device__ __forceinline__ MfLaneSel mf_lane_sel(int l4)
+{
+    return {l4 == 0 ? 1.0 : 0.0, l4 == 1 ? 1.0 : 0.0, l4 == 2 ? 1.0 : 0.0, l4 == 3 ? 1.0 : 0.0};
+}
+__device__ __forceinline__ double mf_sel_ic(const MfLaneSel &S, const MfBlk4 &B)
+{
+    return fma(S.s3, B.i3, fma(S.s2, B.i2, fma(S.s1, B.i1, S.s0 * B.i0)));
+}
+__device__ __forceinline__ double mf_apply4(double x, int l15, const MfLaneSel &S, const MfBlk4 &B)
+{
+    const double v0 = __shfl(x, l15), v1 = __shfl(x, l15 + 16), v2 = __shfl(x, l15 + 32);
+    const double c0 = fma(S.s3, B.m30, fma(S.s2, B.m20, S.s1 * B.m10));
+    const double c1 = fma(S.s3, B.m31, S.s2 * B.m21);
+    const double c2 = S.s3 * B.m32;
+    return fma(c2, v2, fma(c1, v1, fma(c0, v0, x)));
+}
+
+__device__ __forceinline__ void wave_sync_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// LDS of the static front kernel (doubles): [image R x R (LDSIMG), later the rows of L: 16 x R][scaled diagonal tile 256]
+// [4 x 10 block records][1 / D: R][one 64-entry scratch per wave]
+__host__ __device__ constexpr int mf_front_lds_doubles(int T, int NW, bool ldsimg)
+{
+    const int R = 16 * T, u = (ldsimg ? R * R : 0) > 16 * R ? R * R : 16 * R;
+    return u + 256 + 40 + R + 64 * NW;
+}
+
+// everything wave W of NW does for one front of T tile rows: tiles into registers, the unrolled elimination, results
+template <int T, int NW, int W, bool LDSIMG>
+__device__ __forceinline__ void mf_front_wave(const double *F, int LD, double *G, int ld, int fs, int nc, int with_rhs,
+                                              double *lds, double *dinv, double *vv, int lane, int trs)
+{
+    constexpr int R = 16 * T;
+    constexpr int U = (LDSIMG ? R * R : 0) > 16 * R ? R * R : 16 * R;
+    MF_TRW(0)
+    constexpr int NROWS = W < T ? (T - W + NW - 1) / NW : 0;
+    double *Lp = lds, *dtile = lds + U, *rec = dtile + 256, *dl = rec + 40, *dsc = dl + R + 64 * W;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const MfLaneSel LS = mf_lane_sel(l4);
+    // tiles of my rows: row slot s <-> tile row ti = W + s NW, tiles tj = 0..ti at acc[off(s) + tj]
+    constexpr int NTILES = NROWS > 0 ? NROWS * (2 * W + (NROWS - 1) * NW + 2) / 2 : 1;
+    d4 acc[NTILES];
+    {
+        int o = 0;
+#pragma unroll
+        for (int s = 0; s < NROWS; ++s) {
+            const int ti = W + s * NW;
+#pragma unroll
+            for (int tj = 0; tj <= ti; ++tj)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int col = 16 * tj + l4 + 4 * rr, row = 16 * ti + l15;
+                    const bool in = LDSIMG || (row <= fs && col < fs);
+                    acc[o + tj][rr] = in ? F[col * LD + row] : 0.0;
+                }
+            o += ti + 1;
+        }
+    }
+    MF_TRW(1)
+    __syncthreads();                      // the image is dead from here on: its LDS carries the rows of L
+    MF_TRW(2)
+#pragma unroll
+    for (int tk = 0; tk < T; ++tk) {
+        if (16 * tk >= nc) break;
+        if (tk == 1) { MF_TRW(9) }
+        const int live = nc - 16 * tk;    // columns of this block that are eliminated (>= 1)
+        // A. the diagonal tile, by its owner alone
+        if (tk % NW == W) {
+            constexpr int dummy = 0; (void)dummy;
+            const int sd = (tk - W) / NW;                                   // my row slot of tile row tk
+            const int od = sd * (2 * W + (sd - 1) * NW + 2) / 2 + tk;       // off(sd) + tk
+            d4 dt = acc[od];
+            d4 ls = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) {
+                if (4 * sub >= live) break;
+                const int bw = live - 4 * sub < 4 ? live - 4 * sub : 4, b0 = 4 * sub;
+                const double dv = dt[sub];
+                dsc[lane] = dv;
+                wave_sync_lds();
+                const double a00 = dsc[b0], a10 = dsc[b0 + 1], a11 = dsc[b0 + 17], a20 = dsc[b0 + 2], a21 = dsc[b0 + 18],
+                             a22 = dsc[b0 + 34], a30 = dsc[b0 + 3], a31 = dsc[b0 + 19], a32 = dsc[b0 + 35], a33 = dsc[b0 + 51];
+                wave_sync_lds();
+                const MfBlk4 B = mf_ldl4(a00, a10, a11, a20, a21, a22, a30, a31, a32, a33, bw);
+                const double x = mf_apply4(dv, l15, LS, B);
+                const double ic = mf_sel_ic(LS, B);
+                dt[sub] = x;
+                ls[sub] = x * ic;
+                dt = __builtin_amdgcn_mfma_f64_16x16x4f64(l15 >= b0 + 4 ? -ls[sub] : 0.0, x, dt, 0, 0, 0);
+                if (lane == 0) {
+                    double *o = rec + 10 * sub;
+                    o[0] = B.i0; o[1] = B.i1; o[2] = B.i2; o[3] = B.i3; o[4] = B.m10; o[5] = B.m20; o[6] = B.m21; o[7] = B.m30;
+                    o[8] = B.m31; o[9] = B.m32;
+                }
+                if (l15 == 0 && l4 < bw) dl[16 * tk + b0 + l4] = ic;          // lane group l4 holds 1 / d of column b0 + l4
+            }
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) dtile[64 * sub + lane] = ls[sub];
+            acc[od] = dt;
+        }
+        if (tk == 0) { MF_TRW(3) }
+        __syncthreads();
+        if (tk == 0) { MF_TRW(4) }
+        // B. my tiles below the diagonal tile: sixteen columns of every row; the rows of L go to LDS, X = L D stays here
+        {
+            int o = 0;
+#pragma unroll
+            for (int s = 0; s < NROWS; ++s) {
+                const int ti = W + s * NW;
+                if (ti > tk) {
+                    d4 pt = acc[o + tk];
+#pragma unroll
+                    for (int sub = 0; sub < 4; ++sub) {
+                        if (4 * sub >= live) break;
+                        const double *q = rec + 10 * sub;
+                        MfBlk4 B;
+                        B.i0 = q[0]; B.i1 = q[1]; B.i2 = q[2]; B.i3 = q[3]; B.m10 = q[4]; B.m20 = q[5]; B.m21 = q[6]; B.m30 = q[7];
+                        B.m31 = q[8]; B.m32 = q[9];
+                        const double x = mf_apply4(pt[sub], l15, LS, B);
+                        const double ic = mf_sel_ic(LS, B);
+                        pt[sub] = x;
+                        Lp[(4 * sub + l4) * R + 16 * ti + l15] = x * ic;
+                        if (sub < 3) pt = __builtin_amdgcn_mfma_f64_16x16x4f64(l15 >= 4 * sub + 4 ? -dtile[64 * sub + lane] : 0.0, x, pt, 0, 0, 0);
+                    }
+                    acc[o + tk] = pt;
+                }
+                o += ti + 1;
+            }
+        }
+        if (tk == 0) { MF_TRW(5) }
+        __syncthreads();
+        if (tk == 0) { MF_TRW(6) }
+        // C. rank-16 update of my tiles to the right
+        {
+            int o = 0;
+#pragma unroll
+            for (int s = 0; s < NROWS; ++s) {
+                const int ti = W + s * NW;
+                if (ti > tk) {
+                    const d4 xr = acc[o + tk];
+#pragma unroll
+                    for (int tj = tk + 1; tj <= ti; ++tj)
+#pragma unroll
+                        for (int sub = 0; sub < 4; ++sub) {
+                            if (4 * sub >= live) break;
+                            acc[o + tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lp[(4 * sub + l4) * R + 16 * tj + l15], xr[sub], acc[o + tj], 0, 0, 0);
+                        }
+                }
+                o += ti + 1;
+            }
+        }
+    }
+    MF_TRW(7)
+    __syncthreads();
+    MF_TRW(8)
+    // results: L (scaled), D^-1 L^-1 b, the contribution block with its right-hand-side row
+    {
+        int o = 0;
+#pragma unroll
+        for (int s = 0; s < NROWS; ++s) {
+            const int ti = W + s * NW;
+#pragma unroll
+            for (int tj = 0; tj <= ti; ++tj) {
+                // tiles strictly below the diagonal tiles whose rows all lie inside the front and whose columns are all
+                // eliminated (L) or all kept (contribution block) need no test per lane: most tiles of a large front
+                const bool inside = ti > tj && 16 * ti + 15 < fs;
+                if (inside && 16 * tj + 15 < nc) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int col = 16 * tj + l4 + 4 * rr;
+                        G[(long)col * ld + 16 * ti + l15] = acc[o + tj][rr] * dl[col];
+                    }
+                } else if (inside && 16 * tj >= nc) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) G[(long)(16 * tj + l4 + 4 * rr) * ld + 16 * ti + l15] = acc[o + tj][rr];
+                } else {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int col = 16 * tj + l4 + 4 * rr, row = 16 * ti + l15;
+                        const double v = acc[o + tj][rr];
+                        if (col < nc) {
+                            if (row > col && row < fs) G[(long)col * ld + row] = v * dl[col];
+                            else if (row == fs && with_rhs) vv[col] = v * dl[col];
+                        } else if (col < fs && row >= col && row <= fs) G[(long)col * ld + row] = v;
+                    }
+                }
+            }
+            o += ti + 1;
+        }
+    }
+    if (W == 0) for (int k = lane; k < nc; k += 64) dinv[k] = dl[k];
+    MF_TRW(10)
+}
+
+template <int T, int NW, int W, bool LDSIMG>
+__device__ __forceinline__ void mf_front_dispatch(int wave, const double *F, int LD, double *G, int ld, int fs, int nc,
+                                                  int with_rhs, double *lds, double *dinv, double *vv, int lane, int trs)
+{
+    if (wave == W) mf_front_wave<T, NW, W, LDSIMG>(F, LD, G, ld, fs, nc, with_rhs, lds, dinv, vv, lane, trs);
+    else if constexpr (W + 1 < NW) mf_front_dispatch<T, NW, W + 1, LDSIMG>(wave, F, LD, G, ld, fs, nc, with_rhs, lds, dinv, vv, lane, trs);
+}
+
+template <int T, int NW, bool LDSIMG>
+__global__ __launch_bounds__(64 * NW) void k_mf_front(DV d, int sbegin, int want, int with_rhs)
+{
+    constexpr int NT = 64 * NW, R = 16 * T;
+    int inst, cand;
+    if (!mf_candidate(d, want, inst, cand)) return;
+    const MfDev &M = d.mf;
+    const int s = M.sched[sbegin + blockIdx.x];
+    const MfFrontDesc Fd = M.desc[s];
+    const int nc = Fd.nc, nr = Fd.nr, fs = nc + nr, ld = fs + 1, f0 = Fd.first;
+    const double *arena = mf_arena(d, inst, cand);
+    double *G = mf_arena(d, inst, cand) + Fd.off;
+    extern __shared__ double mf_lds[];
+    double *F = LDSIMG ? mf_lds : G;
+    const int LD = LDSIMG ? R : ld;
+    const int tid = threadIdx.x;
+    MF_TR(0)
+    // image: zero, assembled values, right-hand-side row, contribution blocks of the children
+    if (LDSIMG) for (int e = tid; e < R * R; e += NT) F[e] = 0.0;
+    else for (int e = tid; e < ld * fs; e += NT) F[e] = 0.0;
+    __syncthreads();
+    MF_TR(1)
+    {
+        const double *vals = mf_vals(d, inst, cand);
+        for (int e = Fd.asm_begin + tid; e < Fd.asm_end; e += NT) {
+            const int rc = M.dest_rc[e];
+            F[(rc >> 16) * LD + (rc & 0xffff)] = vals[e];
+        }
+        if (with_rhs) {
+            const double *b = d.xv + (long)inst * d.Fpad + f0;
+            for (int j = tid; j < nc; j += NT) F[j * LD + fs] = b[j];
+        }
+    }
+    __syncthreads();
+    MF_TR(2)
+    for (int t = Fd.ea_begin + tid; t < Fd.ea_end; t += NT) {
+        const MfGather g = M.ea_ent[t];
+        double a = arena[g.src0];
+        for (int q = g.src_begin + 1; q < g.src_end; ++q) a += arena[M.ea_src[q]];
+        const int rc = g.where;
+        F[(rc >> 16) * LD + (rc & 0xffff)] += a;
+    }
+    __syncthreads();
+    MF_TR(3)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    mf_front_dispatch<T, NW, 0, LDSIMG>(wave, F, LD, G, ld, fs, nc, with_rhs, mf_lds, mf_dinv(d, inst, cand) + f0,
+                                        mf_vv(d, inst, cand) + f0, tid & 63, inst == 0 ? s : -1);
+    MF_TR(4)
     MF_TR(5)
 }
 
@@ -722,17 +1040,35 @@ void mf_factor(Ctx &C, int want, bool with_rhs)
     const int wr = (int)with_rhs;
     const int nb = d.mf.fronts1 ? 2 * d.B : d.B;         // with the second candidate the factor side runs over 2 B "instances"
     if (!v1) hipLaunchKernelGGL(k_mf_values, dim3((d.mf.nnzK + 255) / 256, nb), dim3(256), 0, s, d, want);
+    // static front kernels (k_mf_front<T, NW, LDSIMG>) unless SQPHIP_MF_STATIC=0 asks for the generic ones (cross-check)
+    static const bool stat = !(getenv("SQPHIP_MF_STATIC") && atoi(getenv("SQPHIP_MF_STATIC")) == 0);
     for (const MfLaunch &L : C.mfp().fac) {
         const dim3 grid(L.count, nb);
-        const int cls = v1 ? 5 : L.cls;
-        switch (cls) {
-        case 0: hipLaunchKernelGGL((k_mf_factor2<1, 3, true>), grid, dim3(64), L.lds_bytes, s, d, L.begin, want, wr, L.tiles); break;
-        case 1: hipLaunchKernelGGL((k_mf_factor2<2, 5, true>), grid, dim3(128), L.lds_bytes, s, d, L.begin, want, wr, L.tiles); break;
-        case 2: hipLaunchKernelGGL((k_mf_factor2<4, 4, true>), grid, dim3(256), L.lds_bytes, s, d, L.begin, want, wr, L.tiles); break;
-        case 3: hipLaunchKernelGGL((k_mf_factor2<4, 9, false>), grid, dim3(256), L.lds_bytes, s, d, L.begin, want, wr, L.tiles); break;
-        case 4: hipLaunchKernelGGL((k_mf_factor2<8, 12, false>), grid, dim3(512), L.lds_bytes, s, d, L.begin, want, wr, L.tiles); break;
-        default: hipLaunchKernelGGL((k_mf_factor<256, true>), grid, dim3(256), 0, s, d, L.begin, want, wr); break;
+        const int T = L.tiles, R = 16 * T;
+        if (v1 || T > 13) { hipLaunchKernelGGL((k_mf_factor<256, true>), grid, dim3(256), 0, s, d, L.begin, want, wr); continue; }
+        // generic kernels: dynamic LDS = [image (16 T)^2 when it lives in LDS][panel X and L: 2 x 4 x 16 T][4 x 4 block][1 / D: 16 T]
+#define MF_GENERIC(NW, MAXT, IMG) hipLaunchKernelGGL((k_mf_factor2<NW, MAXT, IMG>), grid, dim3(64 * NW), 8 * (size_t)((IMG ? R * R : 0) + 9 * R + 16), s, d, L.begin, want, wr, T)
+#define MF_STATIC(TT, NW, IMG) hipLaunchKernelGGL((k_mf_front<TT, NW, IMG>), grid, dim3(64 * NW), 8 * (size_t)mf_front_lds_doubles(TT, NW, IMG), s, d, L.begin, want, wr)
+        if (!stat || T > 8) {
+            if (T <= 2) MF_GENERIC(1, 3, true);
+            else if (T <= 4) MF_GENERIC(2, 5, true);
+            else if (T <= 5) MF_GENERIC(4, 4, true);
+            else if (T <= 8) MF_GENERIC(4, 9, false);
+            else MF_GENERIC(8, 12, false);
+            continue;
         }
+        switch (T) {
+        case 1: MF_STATIC(1, 1, true); break;
+        case 2: MF_STATIC(2, 1, true); break;
+        case 3: MF_STATIC(3, 1, true); break;
+        case 4: MF_STATIC(4, 2, true); break;
+        case 5: MF_STATIC(5, 2, true); break;
+        case 6: MF_STATIC(6, 4, false); break;
+        case 7: MF_STATIC(7, 4, false); break;
+        default: MF_STATIC(8, 4, false); break;
+        }
+#undef MF_GENERIC
+#undef MF_STATIC
     }
     C.mf_factor_launches += (long)C.mfp().fac.size();
 }
