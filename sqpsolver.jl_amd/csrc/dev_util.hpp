@@ -11,6 +11,12 @@ namespace sqphip {
 #define SQPHIP_VEC_THREADS 1024
 #endif
 #define TPB SQPHIP_VEC_THREADS
+// Occupancy target of the per-sweep vector kernels (second __launch_bounds__ argument, waves per SIMD): 4 = one workgroup
+// of 1024 threads per CU with up to 128 registers per lane.  8 (two workgroups per CU, 64 registers) was measured in
+// round 3: the fused stages then spill 160 - 400 bytes per lane and 512 x IEEE-118 loses 8 % (5407 -> 4970 QP/s).
+#ifndef SQPHIP_VEC_WAVES_PER_EU
+#define SQPHIP_VEC_WAVES_PER_EU 4
+#endif
 
 struct OpSum { __device__ static double f(double a, double b) { return a + b; } };
 struct OpMax { __device__ static double f(double a, double b) { return fmax(a, b); } };

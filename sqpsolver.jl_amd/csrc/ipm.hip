@@ -501,7 +501,7 @@ static __device__ void b_build_rhs(const DV &d)
 // Sparse path: the sweep has factorised the shift st.dw AND -- for the instances mf_speculates() names -- the next shift
 // of the schedule.  The bookkeeping below is that of a run that factorises one shift per sweep (same counters, same
 // decisions as the oracle); the second candidate only saves the sweep a failed first shift would have cost.
-__global__ __launch_bounds__(TPB) void k_inertia(DV d)
+__global__ __launch_bounds__(TPB, SQPHIP_VEC_WAVES_PER_EU) void k_inertia(DV d)
 {
     const int inst = blockIdx.x;
     if (d.phase[inst] != PH_FACTOR) return;
@@ -743,7 +743,7 @@ static __device__ void b_ipm_step(const DV &d)
 // ---------------------------------------------------------------------------------------------
 // outcome of a finished interior-point run: accept, phase 1, penalty escalation, or infeasible;
 // final results in the JuMP sign convention (collect_solution!, subproblem_JuMP.jl:514-563)
-__global__ __launch_bounds__(TPB) void k_qp_finish(DV d)
+__global__ __launch_bounds__(TPB, SQPHIP_VEC_WAVES_PER_EU) void k_qp_finish(DV d)
 {
     const int inst = blockIdx.x;
     if (d.phase[inst] != PH_DONE) return;
@@ -846,7 +846,7 @@ __global__ void k_count(DV d)
 __global__ __launch_bounds__(TPB) void k_qp_gather(DV d) { b_qp_gather(d); }
 
 // start of a sub-problem (COO -> CSC values, canonical programme), first convergence test, Newton right-hand side
-__global__ __launch_bounds__(TPB) void k_ipm_head(DV d)
+__global__ __launch_bounds__(TPB, SQPHIP_VEC_WAVES_PER_EU) void k_ipm_head(DV d)
 {
     b_qp_gather(d);
     __syncthreads();
@@ -858,7 +858,7 @@ __global__ __launch_bounds__(TPB) void k_ipm_head(DV d)
 }
 
 // behind solve slot A: residual check of the first solve, then the corrector's system in predictor-corrector mode
-__global__ __launch_bounds__(TPB) void k_ipm_mid(DV d, int last)
+__global__ __launch_bounds__(TPB, SQPHIP_VEC_WAVES_PER_EU) void k_ipm_mid(DV d, int last)
 {
     b_refine(d, last, PH_SOLVE);
     if (!d.ipm_corrector) return;
@@ -867,7 +867,7 @@ __global__ __launch_bounds__(TPB) void k_ipm_mid(DV d, int last)
 }
 
 // behind solve slot B: residual check of the second solve, the step, and the convergence test of the new iterate
-__global__ __launch_bounds__(TPB) void k_ipm_tail(DV d, int last)
+__global__ __launch_bounds__(TPB, SQPHIP_VEC_WAVES_PER_EU) void k_ipm_tail(DV d, int last)
 {
     b_refine(d, last, PH_RESOLVE);
     __syncthreads();

@@ -651,25 +651,58 @@ __global__ __launch_bounds__(64 * NW) void k_mf_front(DV d, int sbegin, int want
     const int LD = LDSIMG ? R : ld;
     const int tid = threadIdx.x;
     MF_TR(0)
-    // image: zero, assembled values, right-hand-side row, contribution blocks of the children
+    // image: zero, assembled values, right-hand-side row, contribution blocks of the children.  Everything that comes
+    // from global memory -- the front's assembled values with their destinations, the receiving entries of the extend-add
+    // with the first source of each, the right-hand side -- is requested BEFORE the image is zeroed (the first PV / PE
+    // entries of every thread live in registers meanwhile): one exposed memory round trip per front instead of three
+    // (a front is a chain of dependent round trips of 1 - 2 us each; the arithmetic in between is short).
+    constexpr int PV = 4, PE = 8;
+    int vrc[PV]; double vval[PV]; int ew[PE], eb[PE], ee[PE]; double ea[PE];
+    {
+        const double *vals = mf_vals(d, inst, cand);
+#pragma unroll
+        for (int k = 0; k < PV; ++k) {
+            const int e = Fd.asm_begin + tid + k * NT;
+            vrc[k] = -1; vval[k] = 0.0;
+            if (e < Fd.asm_end) { vrc[k] = M.dest_rc[e]; vval[k] = vals[e]; }
+        }
+#pragma unroll
+        for (int k = 0; k < PE; ++k) {
+            const int t = Fd.ea_begin + tid + k * NT;
+            ew[k] = -1; eb[k] = 0; ee[k] = 0; ea[k] = 0.0;
+            if (t < Fd.ea_end) { const MfGather g = M.ea_ent[t]; ew[k] = g.where; eb[k] = g.src_begin; ee[k] = g.src_end; ea[k] = arena[g.src0]; }
+        }
+    }
+    double brhs = 0.0;
+    if (with_rhs && tid < nc) brhs = d.xv[(long)inst * d.Fpad + f0 + tid];
     if (LDSIMG) for (int e = tid; e < R * R; e += NT) F[e] = 0.0;
     else for (int e = tid; e < ld * fs; e += NT) F[e] = 0.0;
     __syncthreads();
     MF_TR(1)
     {
         const double *vals = mf_vals(d, inst, cand);
-        for (int e = Fd.asm_begin + tid; e < Fd.asm_end; e += NT) {
+#pragma unroll
+        for (int k = 0; k < PV; ++k) if (vrc[k] >= 0) F[(vrc[k] >> 16) * LD + (vrc[k] & 0xffff)] = vval[k];
+        for (int e = Fd.asm_begin + tid + PV * NT; e < Fd.asm_end; e += NT) {
             const int rc = M.dest_rc[e];
             F[(rc >> 16) * LD + (rc & 0xffff)] = vals[e];
         }
         if (with_rhs) {
+            if (tid < nc) F[tid * LD + fs] = brhs;
             const double *b = d.xv + (long)inst * d.Fpad + f0;
-            for (int j = tid; j < nc; j += NT) F[j * LD + fs] = b[j];
+            for (int j = tid + NT; j < nc; j += NT) F[j * LD + fs] = b[j];
         }
     }
     __syncthreads();
     MF_TR(2)
-    for (int t = Fd.ea_begin + tid; t < Fd.ea_end; t += NT) {
+#pragma unroll
+    for (int k = 0; k < PE; ++k)
+        if (ew[k] >= 0) {
+            double a = ea[k];
+            for (int q = eb[k] + 1; q < ee[k]; ++q) a += arena[M.ea_src[q]];        // (most entries have one source)
+            F[(ew[k] >> 16) * LD + (ew[k] & 0xffff)] += a;
+        }
+    for (int t = Fd.ea_begin + tid + PE * NT; t < Fd.ea_end; t += NT) {
         const MfGather g = M.ea_ent[t];
         double a = arena[g.src0];
         for (int q = g.src_begin + 1; q < g.src_end; ++q) a += arena[M.ea_src[q]];
@@ -724,7 +757,7 @@ __device__ __forceinline__ void mf_front_fwd(const DV &d, int inst, int s, doubl
 #pragma unroll 8
         for (int k = 0; k < nc - 1; ++k) {
             const double l = (lane > k && lane < nc) ? G[(long)k * ld + lane] : 0.0;
-            const double yk = __shfl(yi, k);
+            const double yk = mf_readlane(yi, k);
             yi -= l * yk;
         }
         if (lane < nc) { y[lane] = yi; vv[lane] = yi * dinv[lane]; }
@@ -770,7 +803,7 @@ __device__ __forceinline__ void mf_front_bwd(const DV &d, int inst, int s, doubl
 #pragma unroll 8
         for (int i = nc - 1; i > 0; --i) {
             const double l = lane < i ? G[(long)lane * ld + i] : 0.0;
-            const double xi = __shfl(t, i);
+            const double xi = mf_readlane(t, i);
             t -= l * xi;
         }
         if (lane < nc) xg[f0 + lane] = t;
@@ -825,7 +858,7 @@ __device__ __forceinline__ void mf_front_fwd_big(const DV &d, int inst, int s, d
             for (int c = 0; c < 15; ++c) l[c] = (c < nb - 1 && lane > c && lane < nb) ? L[(long)(kb + c) * ll + kb + lane] : 0.0;
             double yi = lane < nb ? y[kb + lane] : 0.0;
 #pragma unroll
-            for (int c = 0; c < 15; ++c) yi -= l[c] * __shfl(yi, c);
+            for (int c = 0; c < 15; ++c) yi -= l[c] * mf_readlane(yi, c);      // v_readlane: ~20 cycles; __shfl (ds_bpermute): 85
             if (lane < nb) { y[kb + lane] = yi; vv[kb + lane] = yi * dinv[kb + lane]; }
         }
         __syncthreads();
@@ -924,7 +957,7 @@ __device__ __forceinline__ void mf_front_bwd_big(const DV &d, int inst, int s, d
             for (int c = 1; c < 16; ++c) l[c - 1] = (c < nb && lane < c) ? L[(long)(kb + lane) * ll + kb + c] : 0.0;
             double t = lane < nb ? x[kb + lane] - part[lane] : 0.0;
 #pragma unroll
-            for (int c = 15; c > 0; --c) t -= l[c - 1] * __shfl(t, c);
+            for (int c = 15; c > 0; --c) t -= l[c - 1] * mf_readlane(t, c);
             if (lane < nb) { x[kb + lane] = t; xg[f0 + kb + lane] = t; }
         }
         __syncthreads();

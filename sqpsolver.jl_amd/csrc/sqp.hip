@@ -635,7 +635,7 @@ static __device__ __forceinline__ void b_sqp_stream(const DV &d)
 
 // SQP-level stages of a sweep in dependency order, one kernel (one workgroup owns one instance: its stages run one
 // after the other, a barrier in between publishes the stage word thread 0 wrote; every stage keeps its own gate)
-__global__ __launch_bounds__(TPB) void k_sqp_stage(DV d)
+__global__ __launch_bounds__(TPB, SQPHIP_VEC_WAVES_PER_EU) void k_sqp_stage(DV d)
 {
     b_sqp_lp_finish(d);
     __syncthreads();
