@@ -55,6 +55,9 @@ def main():
     ap.add_argument("--formulation", default="polar", choices=["polar", "acr", "acwr"],
                     help="ACOPF evaluator: polar (ACP, default), rectangular (ACR, the one examples/acopf/opf.jl:46 runs) "
                          "or the W-space model of examples/acopf/acwr.jl")
+    ap.add_argument("--topology", default=None, choices=["chain", "geo"],
+                    help="synthetic network recipe: chain = SURVEY.md section 8d (default for case14 / case118), geo = lattice strip "
+                         "with local generation (default for case1354 / case9241: the chain recipe gives no convergent NLP there)")
     ap.add_argument("--batch", type=int, default=None, help="instances of the whole job (default 512 for case118)")
     ap.add_argument("--quick", action="store_true", help="development runs: timed steps only (implies --no-cpu-baseline --no-termination --no-dense-ldlt --no-screening)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -76,6 +79,11 @@ def main():
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank flow "
                          "on a box with fewer GPUs than ranks, together with --one-device)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--shared-queue", type=int, default=0, metavar="M",
+                    help="instead of the timed steps: M scenarios through a queue shared between the ranks (every rank holds all "
+                         "tables, --batch slots per rank, --queue-split of the ids start on rank 0; run to termination, "
+                         "literal_quirks as given); prints one JSON line, --dump-status gets the per-scenario results")
+    ap.add_argument("--queue-split", type=float, default=None, help="fraction of the M ids assigned to rank 0 at the start (default: even)")
     ap.add_argument("--dump-status", default=None, help="rank 0 writes the gathered (ret, iter, done) table to this JSON file")
     args = ap.parse_args()
     if args.quick:
@@ -106,7 +114,7 @@ def main():
     dev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")   # collective buffers
 
     import sqpsolver_jl_amd as pkg
-    from sqpsolver_jl_amd.acopf_synth import acopf_synth, acopf_layout, acr_layout, acwr_layout, contingency, CASES
+    from sqpsolver_jl_amd.acopf_synth import synth_case, acopf_layout, acr_layout, acwr_layout, contingency, CASES
     if args.formulation != "polar":
         acopf_layout = {"acr": acr_layout, "acwr": acwr_layout}[args.formulation]
     from sqpsolver_jl_amd.shard import shard_range, gather_status
@@ -116,7 +124,8 @@ def main():
     total = args.batch or DEFAULT_BATCH[args.workload]
     lo, hi = shard_range(total, world, rank)
     B = hi - lo
-    base = acopf_synth(nb, ng, nl, seed)
+    base = synth_case(args.workload, args.topology)
+    topology = args.topology or ("chain" if nb <= 118 else "geo")
     lay0 = acopf_layout(base)
     use_soc = 1 if args.sqp_options == "example" else 0
     sqp_kw = dict(tol_infeas=1e-6, tol_residual=1e-4, use_soc=1) if use_soc else {}
@@ -146,6 +155,67 @@ def main():
             ctx.acopf_set_instance(b, *scenario(s_id))
         ctx.sqp_reset()
         return ctx, opts
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.shared_queue > 0:
+        # ---- a screening job over a queue shared between the ranks (no timed steps, no roofline: a functional mode)
+        from sqpsolver_jl_amd.shard import run_shared_queue
+        M, slots = args.shared_queue, (args.batch or 8)
+        qopts = pkg.default_options(max_iter=60, literal_quirks=args.literal_quirks, device=local_rank,
+                                    ipm_corrector=args.ipm_corrector, **lin_kw, **sqp_kw)
+        qctx = pkg.Context(lay0.n, lay0.m, lay0.num_linear, lay0.jrow, lay0.jcol, lay0.hrow, lay0.hcol,
+                           lay0.xL, lay0.xU, lay0.gL, lay0.gU, qopts, batch=slots)
+        qctx.acopf_attach(base, lay0)
+        qctx.stream_begin(M)
+        for s_id in range(M):
+            qctx.stream_set(s_id, *scenario(s_id))
+        if world == 1:
+            mine = list(range(M))
+        else:
+            cut0 = int(round(M * args.queue_split)) if args.queue_split is not None else shard_range(M, world, 0)[1]
+            rest = [cut0 + shard_range(M - cut0, world - 1, r)[0] for r in range(world - 1)] + [M]
+            mine = list(range(0, cut0)) if rank == 0 else list(range(rest[rank - 1], rest[rank]))
+        qctx.stream_assign(mine)
+        sync()
+        ta = time.perf_counter()
+        rounds = run_shared_queue(qctx, rank, world, slots, chunk=5)
+        sync()
+        tb = time.perf_counter()
+        # every scenario was solved by exactly one rank: merge the per-scenario tables (the unsolved entries are -99)
+        qc = qctx.counters()
+        st = np.full(M, -99, dtype=np.int64); it = np.zeros(M, dtype=np.int64); obj = np.zeros(M)
+        solved_here = 0
+        for s_id in range(M):
+            r_ = qctx.stream_get(s_id)
+            if r_["iter"] > 0:
+                st[s_id], it[s_id], obj[s_id] = r_["status"], r_["iter"], r_["obj_val"]; solved_here += 1
+        tabs = [(st, it, obj, solved_here, int(qc["n_qp"]))]
+        if world > 1:
+            tabs = [None] * world
+            dist.all_gather_object(tabs, (st, it, obj, solved_here, int(qc["n_qp"])))
+        if rank == 0:
+            owner = np.full(M, -1)
+            for r_, (s_, i_, o_, _, _) in enumerate(tabs):
+                sel = s_ != -99
+                assert not np.any(owner[sel] >= 0), "a scenario was solved twice"
+                owner[sel] = r_; st[sel] = s_[sel]; it[sel] = i_[sel]; obj[sel] = o_[sel]
+            assert np.all(owner >= 0), "a scenario was not solved"
+            if args.dump_status:
+                with open(args.dump_status, "w") as fh:
+                    json.dump({"status": st.tolist(), "iter": it.tolist(), "obj_hex": [float(v).hex() for v in obj]}, fh)
+            print(json.dumps({"mode": "shared_queue", "scenarios": M, "n_gpus": world, "slots_per_rank": slots, "rounds": rounds,
+                              "seconds": tb - ta, "scenarios_per_s": M / (tb - ta), "initial_ids_by_rank": [len(mine)] if world == 1 else None,
+                              "solved_by_rank": [t[3] for t in tabs], "qp_by_rank": [t[4] for t in tabs],
+                              "converged": int(np.sum(st == 0))}))
+        qctx.close()
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     ctx, opts = make_ctx(args.literal_quirks)
 
@@ -326,10 +396,10 @@ def main():
             scaling_prediction = {"error": repr(e)}
 
     termination = None
-    if rank == 0 and world == 1 and not args.no_termination and small:
+    if rank == 0 and world == 1 and not args.no_termination and (small or topology == "geo"):
         try:
             termination = {}
-            for lq in (1, 0):
+            for lq in ((1, 0) if small else (0,)):      # the large shapes: textbook sign only (they converge in ~15 iterations)
                 tctx, _ = make_ctx(lq, max_iter=60)
                 torch.cuda.synchronize()
                 ta = time.perf_counter()
@@ -435,7 +505,7 @@ def main():
                                    + (", multifrontal LDL^T" if c1["sparse"] else ", dense MFMA LDL^T")
                                    + ", fp64, SQP-TR outer iterations",
                        "instances_total": total, "instances_per_gpu": B, "kkt_order": N, "kkt_order_full": N_full,
-                       "formulation": args.formulation, "use_soc": use_soc, "sqp_options": args.sqp_options,
+                       "formulation": args.formulation, "topology": topology, "use_soc": use_soc, "sqp_options": args.sqp_options,
                        "literal_quirks": args.literal_quirks, "ipm_corrector": args.ipm_corrector,
                        "kkt_mode": args.kkt_mode, "sparse_solver": int(c1["sparse"]), "kkt_condense": int(opts.kkt_condense),
                        "status_gather": "sqphip_gather_status (RCCL)" if use_lib_comm else

@@ -299,6 +299,17 @@ int sqphip_sqp_stream_begin(sqphip_ctx *ctx, int32_t n_scenarios);
 int sqphip_sqp_stream_set(sqphip_ctx *ctx, int32_t scenario, const double *xL, const double *xU, const double *gL,
                           const double *gU, const double *ohm, const double *c2, const double *c1, const double *x0);
 int sqphip_sqp_stream_run(sqphip_ctx *ctx);
+/* A queue shared between ranks (multi-GPU screening): every rank uploads the tables of ALL
+ * scenarios (_begin with the total, _set for each) but hands out only the ids assigned to it (_assign: ids in hand-out
+ * order).  _run_some lets every slot perform up to max_outer more outer iterations and reports how many ids of this
+ * rank's queue nobody has drawn yet and how many slots have a run in progress; between such runs the host may take
+ * unstarted ids off the tail of a rank's queue (_release) and hand them to a rank whose queue ran dry (_append) --
+ * sqpsolver.jl_amd/shard.py run_shared_queue does that with one small host-side exchange per round.  No iterate crosses
+ * ranks, and the result of a scenario does not depend on the rank or slot that solved it. */
+int sqphip_sqp_stream_assign(sqphip_ctx *ctx, int32_t n, const int32_t *ids);
+int sqphip_sqp_stream_append(sqphip_ctx *ctx, int32_t n, const int32_t *ids);
+int sqphip_sqp_stream_release(sqphip_ctx *ctx, int32_t n, int32_t *ids_out, int32_t *n_out);
+int sqphip_sqp_stream_run_some(sqphip_ctx *ctx, int32_t max_outer, int32_t *n_unstarted, int32_t *n_active);
 int sqphip_sqp_stream_get(sqphip_ctx *ctx, int32_t scenario, double *x, double *obj_val, int32_t *status, int32_t *iter);
 int sqphip_sqp_get(sqphip_ctx *ctx, int32_t inst, double *x, double *g, double *mult_g,
                    double *mult_x_L, double *mult_x_U, double *obj_val, int32_t *status,

@@ -211,6 +211,6 @@ EXPORTS = [
     "sqphip_kkt_order", "sqphip_kkt_symbolic", "sqphip_mf_host_solve", "sqphip_mf_solve_test", "sqphip_acopf_attach", "sqphip_acopf_attach_acr", "sqphip_acopf_attach_acwr", "sqphip_acopf_set_shunts", "sqphip_acopf_set_dclines", "sqphip_acopf_set_instance", "sqphip_acopf_eval", "sqphip_sqp_reset",
     "sqphip_sqp_run", "sqphip_sqp_get", "sqphip_sqp_status", "sqphip_sqp_trace",
     "sqphip_comm_available", "sqphip_comm_unique_id", "sqphip_comm_init", "sqphip_gather_status", "sqphip_comm_destroy",
-    "sqphip_get_counters", "sqphip_get_mode_counters", "sqphip_sqp_work", "sqphip_sqp_stream_begin", "sqphip_sqp_stream_set", "sqphip_sqp_stream_run", "sqphip_sqp_stream_get", "sqphip_sqp_last_request", "sqphip_sqp_qp_log", "sqphip_reset_counters", "sqphip_set_timing", "sqphip_ldlt_factor_host",
+    "sqphip_get_counters", "sqphip_get_mode_counters", "sqphip_sqp_work", "sqphip_sqp_stream_begin", "sqphip_sqp_stream_set", "sqphip_sqp_stream_run", "sqphip_sqp_stream_get", "sqphip_sqp_stream_assign", "sqphip_sqp_stream_append", "sqphip_sqp_stream_release", "sqphip_sqp_stream_run_some", "sqphip_sqp_last_request", "sqphip_sqp_qp_log", "sqphip_reset_counters", "sqphip_set_timing", "sqphip_ldlt_factor_host",
     "sqphip_ldlt_solve_host", "sqphip_ldlt_bench", "sqphip_ldlt_stress", "sqphip_mfma_f64_peak", "sqphip_armijo_alpha", "sqphip_compute_mu_rule",
 ]

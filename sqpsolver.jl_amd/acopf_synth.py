@@ -28,7 +28,7 @@ from __future__ import annotations
 import dataclasses
 import numpy as np
 
-__all__ = ["Network", "acopf_synth", "contingency", "renumber_buses", "NlpLayout", "acopf_layout", "acr_layout", "acwr_layout",
+__all__ = ["Network", "acopf_synth", "acopf_synth_geo", "synth_case", "contingency", "renumber_buses", "NlpLayout", "acopf_layout", "acr_layout", "acwr_layout",
            "CASES"]
 
 # nb, ng, nl per SURVEY.md section 8 table
@@ -229,6 +229,116 @@ def acopf_synth(nb: int, ng: int, nl: int, seed: int, load_scale: float | None =
         f_bus=f_bus, t_bus=t_bus, r=r, x=x, bc=bc, rate_a=rate_a,
         angmin=-ang, angmax=ang.copy(), status=np.ones(nl),
     )
+
+
+def acopf_synth_geo(nb: int, ng: int, nl: int, seed: int, width: int | None = None, load_scale: float = 0.5,
+                    qd_frac: float = 0.1, x_scale: float = 0.25, compensate: float = 0.0) -> Network:
+    """Synthetic transmission network with a geography (round 3; VERDICT r2 "missing" #2): the large shapes of
+    `acopf_synth` are chains hundreds of branches long that SQP-TR cannot bring to feasibility from a flat start inside
+    any reasonable iteration budget.  Here the buses sit on a strip of a square lattice, `width`
+    buses across (default 5: fronts of up to 134 rows at 1354 buses, 382 at 9241; 8 across gives 208 / 548), numbered column by column; branches are lattice edges -- a random
+    spanning tree of the lattice plus random further lattice edges up to nl -- so every branch is short, the graph is
+    planar and its separators are `width` buses wide (fronts of the multifrontal factorisation stay below ~200 rows);
+    generators are spread evenly along the strip (every (nb / ng)-th bus, jittered) with capacity proportional to the
+    demand of their neighbourhood, so power is consumed where it is produced; line charging is light and every
+    generator can absorb its share of it.  Series impedances are a quarter of `acopf_synth`'s (x in 0.0125 .. 0.075 p.u.:
+    short high-voltage lines) and the reactive demand is a tenth of the active one (power factor 0.995: compensated loads)
+    -- reactive power cannot travel through a +-6 % voltage band over reactances of 0.3 p.u., which is what kept the
+    large shapes of `acopf_synth` away from feasibility; measured with the oracle at 1354 buses: x_scale 1.0 / 0.4 /
+    0.25 with 5 buses across -> no convergence in 40 iterations / none / converged in 14.  Costs, voltage band, angle
+    limits and the thermal ratings from a DC power flow are those of `acopf_synth`.  Deterministic per seed."""
+    assert nl >= nb - 1 and ng <= nb
+    rng = np.random.default_rng(seed)
+    W = int(width) if width else 5
+    L = (nb + W - 1) // W
+
+    def bus(r, c):
+        return c * W + r
+
+    cand = []                                       # lattice edges among the nb buses (the last column may be short)
+    for c in range(L):
+        for r in range(W):
+            a = bus(r, c)
+            if a >= nb:
+                continue
+            if r + 1 < W and bus(r + 1, c) < nb:
+                cand.append((a, bus(r + 1, c)))
+            if c + 1 < L and bus(r, c + 1) < nb:
+                cand.append((a, bus(r, c + 1)))
+    assert len(cand) >= nl, "the lattice has fewer edges than nl: choose a wider strip"
+    order = rng.permutation(len(cand))
+    parent = list(range(nb))
+
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+
+    tree, rest = [], []
+    for k in order:                                 # randomised Kruskal: a uniform-ish random spanning tree
+        a, b = cand[k]
+        ra, rb = find(a), find(b)
+        if ra != rb:
+            parent[ra] = rb
+            tree.append((a, b))
+        else:
+            rest.append((a, b))
+    assert len(tree) == nb - 1
+    edges = tree + rest[:nl - (nb - 1)]
+    f_bus = np.asarray([min(a, b) for a, b in edges], dtype=np.int32)
+    t_bus = np.asarray([max(a, b) for a, b in edges], dtype=np.int32)
+    r = rng.uniform(0.005, 0.05, nl) * x_scale
+    x = np.maximum(rng.uniform(0.05, 0.3, nl) * x_scale, 3.0 * r)
+    bc = rng.uniform(0.0, 0.04, nl)
+    pd = rng.uniform(0.1, 1.0, nb) * load_scale
+    qd = qd_frac * pd
+    # generators: one per stretch of nb / ng buses, at a random bus of the stretch; capacity 1.6 x the demand of the stretch
+    cuts = np.linspace(0, nb, ng + 1).astype(int)
+    gen_bus = np.asarray([int(rng.integers(cuts[g], max(cuts[g] + 1, cuts[g + 1]))) for g in range(ng)], dtype=np.int32)
+    area = np.asarray([pd[cuts[g]:cuts[g + 1]].sum() for g in range(ng)])
+    pmax = 1.6 * np.maximum(area, 0.2 * area.mean()) * rng.uniform(0.9, 1.1, ng)
+    pmin = np.zeros(ng)
+    qmax = 0.6 * pmax
+    qmin = -0.6 * pmax
+    base = 100.0
+    c2 = rng.uniform(0.01, 0.1, ng) * base * base
+    c1 = rng.uniform(10.0, 40.0, ng) * base
+    # thermal ratings from a DC power flow with proportional dispatch (sparse: the lattice Laplacian)
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    pg0 = pmax * (pd.sum() / pmax.sum())
+    inj = -pd.copy()
+    np.add.at(inj, gen_bus, pg0)
+    w = 1.0 / x
+    Bm = sp.coo_matrix((np.concatenate([w, w, -w, -w]),
+                        (np.concatenate([f_bus, t_bus, f_bus, t_bus]), np.concatenate([f_bus, t_bus, t_bus, f_bus]))),
+                       shape=(nb, nb)).tocsc()
+    theta = np.zeros(nb)
+    theta[1:] = spla.spsolve(Bm[1:, 1:], inj[1:])
+    flow = (theta[f_bus] - theta[t_bus]) / x
+    rate_a = 1.5 * np.abs(flow) + 0.3 * max(1.0, float(np.median(np.abs(flow))))
+    ang = np.full(nl, np.pi / 6)
+    return Network(
+        nb=nb, ng=ng, nl=nl, pd=pd, qd=qd,
+        vmin=np.full(nb, 0.94), vmax=np.full(nb, 1.06), ref_bus=0,
+        gen_bus=gen_bus, pmin=pmin, pmax=pmax, qmin=qmin, qmax=qmax, c2=c2, c1=c1,
+        f_bus=f_bus, t_bus=t_bus, r=r, x=x, bc=bc, rate_a=rate_a,
+        angmin=-ang, angmax=ang.copy(), status=np.ones(nl),
+        bs=(compensate * qd if compensate > 0.0 else None),
+    )
+
+
+def synth_case(case: str, topology: str | None = None) -> Network:
+    """The synthetic network of a BASELINE.json case shape.  topology "chain": the SURVEY.md section 8d recipe
+    (`acopf_synth`; what the 14- and 118-bus workloads and every test pinned before round 3 use); "geo": `acopf_synth_geo`.
+    Default: chain up to 118 buses, geo beyond -- the chain recipe does not give convergent NLPs at 1354 / 9241 buses."""
+    nb, ng, nl, seed = CASES[case]
+    if topology is None:
+        topology = "chain" if nb <= 118 else "geo"
+    if topology not in ("chain", "geo"):
+        raise ValueError(f"unknown topology {topology!r}")
+    return acopf_synth(nb, ng, nl, seed) if topology == "chain" else acopf_synth_geo(nb, ng, nl, seed)
 
 
 def contingency(net: Network, s: int, base_seed: int) -> Network:

@@ -1086,6 +1086,14 @@ extern "C" int sqphip_sqp_stream_begin(sqphip_ctx *h, int32_t n_scenarios)
         const size_t M = (size_t)n_scenarios;
         Q.M = n_scenarios;
         Q.next = C.dalloc<int>(1); Q.slot_scen = C.dalloc<int>((size_t)d.B);
+        Q.qend = C.dalloc<int>(1);
+        {   // hand-out order: identity, all M scenarios (sqphip_sqp_stream_assign changes it)
+            std::vector<int> ids(M);
+            for (size_t k = 0; k < M; ++k) ids[k] = (int)k;
+            Q.qids = C.upload(ids);
+            SQPHIP_HIP_OK(hipMemcpyAsync(Q.qend, &Q.M, sizeof(int), hipMemcpyHostToDevice, C.stream));
+        }
+        C.stream_started = false;
         Q.xL = C.dalloc<double>(M * d.n); Q.xU = C.dalloc<double>(M * d.n); Q.x0 = C.dalloc<double>(M * d.n);
         Q.gL = C.dalloc<double>(M * d.m); Q.gU = C.dalloc<double>(M * d.m);
         Q.ohm = C.dalloc<double>(M * d.nl * 12); Q.c2 = C.dalloc<double>(M * d.ng); Q.c1 = C.dalloc<double>(M * d.ng);
@@ -1135,8 +1143,99 @@ extern "C" int sqphip_sqp_stream_run(sqphip_ctx *h)
         auto t0 = std::chrono::steady_clock::now();
         SQPHIP_HIP_OK(hipMemsetAsync(C.d.stream.next, 0, sizeof(int), C.stream));
         sqp_stream_arm(C);
+        C.stream_started = true;
         sqp_run(C, 0);
         C.total_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return SQPHIP_OK;
+    });
+}
+
+// ---- a queue shared between ranks (SURVEY.md section 8f-4 remainder): every rank holds the tables of ALL scenarios
+// (sqphip_sqp_stream_set) but hands out only the ids assigned to it; between budgeted runs the host moves unstarted ids
+// from a rank that still has many to one whose queue ran dry (sqpsolver.jl_amd/shard.py, run_shared_queue).  No iterate
+// crosses ranks: a scenario is solved from start to end by the rank that drew it, and its result does not depend on
+// which rank or slot that was.
+static int stream_state(Ctx &C, int &next, int &end)
+{
+    SQPHIP_HIP_OK(hipMemcpyAsync(&next, C.d.stream.next, sizeof(int), hipMemcpyDeviceToHost, C.stream));
+    SQPHIP_HIP_OK(hipMemcpyAsync(&end, C.d.stream.qend, sizeof(int), hipMemcpyDeviceToHost, C.stream));
+    SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+    if (next > end) next = end;                     // slots that found the queue empty overshoot by one each
+    return SQPHIP_OK;
+}
+
+extern "C" int sqphip_sqp_stream_assign(sqphip_ctx *h, int32_t n, const int32_t *ids)
+{
+    if (!h || h->c.d.stream.M <= 0 || n < 0 || n > h->c.d.stream.M || (n > 0 && !ids)) return SQPHIP_EINVAL;
+    for (int k = 0; k < n; ++k) if (ids[k] < 0 || ids[k] >= h->c.d.stream.M) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) {
+        const int zero = 0;
+        if (n > 0) SQPHIP_HIP_OK(hipMemcpyAsync(C.d.stream.qids, ids, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, C.stream));
+        SQPHIP_HIP_OK(hipMemcpyAsync(C.d.stream.qend, &n, sizeof(int), hipMemcpyHostToDevice, C.stream));
+        SQPHIP_HIP_OK(hipMemcpyAsync(C.d.stream.next, &zero, sizeof(int), hipMemcpyHostToDevice, C.stream));
+        SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        C.stream_started = false;
+        return SQPHIP_OK;
+    });
+}
+
+extern "C" int sqphip_sqp_stream_append(sqphip_ctx *h, int32_t n, const int32_t *ids)
+{
+    if (!h || h->c.d.stream.M <= 0 || n < 0 || (n > 0 && !ids)) return SQPHIP_EINVAL;
+    for (int k = 0; k < n; ++k) if (ids[k] < 0 || ids[k] >= h->c.d.stream.M) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) {
+        int next, end;
+        stream_state(C, next, end);
+        if (end + n > C.d.stream.M) { C.err = "sqphip_sqp_stream_append: more ids than scenario tables"; return SQPHIP_EINVAL; }
+        if (n > 0) SQPHIP_HIP_OK(hipMemcpyAsync(C.d.stream.qids + end, ids, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, C.stream));
+        const int ne = end + n;
+        SQPHIP_HIP_OK(hipMemcpyAsync(C.d.stream.qend, &ne, sizeof(int), hipMemcpyHostToDevice, C.stream));
+        SQPHIP_HIP_OK(hipMemcpyAsync(C.d.stream.next, &next, sizeof(int), hipMemcpyHostToDevice, C.stream));   // undo the overshoot
+        SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        return SQPHIP_OK;
+    });
+}
+
+extern "C" int sqphip_sqp_stream_release(sqphip_ctx *h, int32_t n, int32_t *ids_out, int32_t *n_out)
+{
+    if (!h || h->c.d.stream.M <= 0 || n < 0 || !n_out || (n > 0 && !ids_out)) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) {
+        int next, end;
+        stream_state(C, next, end);
+        const int k = std::min(n, end - next), ne = end - k;
+        if (k > 0) SQPHIP_HIP_OK(hipMemcpyAsync(ids_out, C.d.stream.qids + ne, sizeof(int) * (size_t)k, hipMemcpyDeviceToHost, C.stream));
+        SQPHIP_HIP_OK(hipMemcpyAsync(C.d.stream.qend, &ne, sizeof(int), hipMemcpyHostToDevice, C.stream));
+        SQPHIP_HIP_OK(hipMemcpyAsync(C.d.stream.next, &next, sizeof(int), hipMemcpyHostToDevice, C.stream));
+        SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        *n_out = k;
+        return SQPHIP_OK;
+    });
+}
+
+// every slot performs up to `max_outer` more outer iterations (of whatever scenarios it holds or draws); afterwards
+// n_unstarted = ids of this rank's queue nobody has drawn yet, n_active = slots with a run in progress
+extern "C" int sqphip_sqp_stream_run_some(sqphip_ctx *h, int32_t max_outer, int32_t *n_unstarted, int32_t *n_active)
+{
+    if (!h || !h->c.acopf_attached || h->c.d.stream.M <= 0 || max_outer < 1) return SQPHIP_ESTATE;
+    return guarded(h, [&](Ctx &C) {
+        auto t0 = std::chrono::steady_clock::now();
+        if (!C.stream_started) { sqp_stream_arm(C); C.stream_started = true; }
+        else sqp_stream_rearm(C);
+        sqp_run(C, max_outer);
+        C.total_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        int next, end;
+        stream_state(C, next, end);
+        if (n_unstarted) *n_unstarted = end - next;
+        if (n_active) {
+            std::vector<int> slot(C.d.B);
+            std::vector<SqpState> S(C.d.B);
+            SQPHIP_HIP_OK(hipMemcpyAsync(slot.data(), C.d.stream.slot_scen, sizeof(int) * C.d.B, hipMemcpyDeviceToHost, C.stream));
+            SQPHIP_HIP_OK(hipMemcpyAsync(S.data(), C.d.sst, sizeof(SqpState) * C.d.B, hipMemcpyDeviceToHost, C.stream));
+            SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+            int a = 0;
+            for (int b = 0; b < C.d.B; ++b) a += slot[b] >= 0 && !S[b].done;
+            *n_active = a;
+        }
         return SQPHIP_OK;
     });
 }

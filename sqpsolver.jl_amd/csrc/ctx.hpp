@@ -77,7 +77,9 @@ struct MfDev {
 // starts over -- inside the stage kernel, no host involvement; the batch stays full until the queue is empty.
 struct StreamDev {
     int M;                                            // scenarios (0: no queue)
-    int *next;                                        // next scenario id to hand out
+    int *next;                                        // position in qids of the next scenario to hand out
+    int *qend;                                        // [1] positions < *qend are valid (the queue may grow or shrink between runs)
+    int *qids;                                        // [M] scenario ids in hand-out order (identity after _begin)
     int *slot_scen;                                   // [B] scenario a slot works on; -2 fresh slot, -1 queue exhausted
     const double *xL, *xU, *gL, *gU, *ohm, *c2, *c1, *x0;   // [M][.] scenario tables
     double *rx, *robj;                                // results: final point [M][n], objective
@@ -171,6 +173,7 @@ struct Ctx {
     int *h_counters = nullptr;  // pinned
     std::vector<int> h_kpos;    // host copy of DV::kpos (row -> kept position or -1)
     bool acopf_attached = false;
+    bool stream_started = false;    // scenario queue: the slots have been armed (sqphip_sqp_stream_run / _run_some)
     // RCCL communicator for the status gather (comm.hip); null: single rank
     void *comm = nullptr, *comm_buf = nullptr;
     int comm_world = 1, comm_rank = 0, comm_cap = 0;   // comm_cap: block capacity comm_buf was sized for
@@ -204,6 +207,7 @@ void ipm_run_all(Ctx &C);            // runs every instance whose IpmState.start
 void ipm_sweep(Ctx &C, bool sqp_level);
 void sqp_stage_kernels(Ctx &C);      // sqp.hip: SQP-level kernels of a sweep
 void sqp_stream_arm(Ctx &C);          // scenario queue: every slot draws its first scenario in the first sweep
+void sqp_stream_rearm(Ctx &C);        // ... slots that found the queue empty look again (ids were appended)
 void launch_qp_gather(Ctx &C);       // COO -> CSC for instances with start set (stage 0)
 // comm.hip
 void comm_release(Ctx &C);

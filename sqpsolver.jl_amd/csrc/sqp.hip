@@ -502,6 +502,19 @@ void sqp_stream_arm(Ctx &C)
     SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
 }
 
+// slots that found the queue empty (-1) look again: ids may have been appended since (sqphip_sqp_stream_append)
+__global__ void k_sqp_stream_rearm(DV d)
+{
+    for (int i = threadIdx.x; i < d.B; i += blockDim.x)
+        if (d.stream.slot_scen[i] == -1) d.stream.slot_scen[i] = -2;
+}
+
+void sqp_stream_rearm(Ctx &C)
+{
+    hipLaunchKernelGGL(k_sqp_stream_rearm, dim3(1), dim3(256), 0, C.stream, C.d);
+    SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+}
+
 void sqp_reset(Ctx &C)
 {
     hipLaunchKernelGGL(k_sqp_reset, dim3(C.d.B), dim3(TPB), 0, C.stream, C.d);
@@ -608,10 +621,13 @@ static __device__ __forceinline__ void b_sqp_stream(const DV &d)
         if (threadIdx.x == 0) { Q.robj[cur] = S.obj_val; Q.rstat[cur] = S.ret; Q.riter[cur] = S.iter; }
     }
     __shared__ int nxt;
-    if (threadIdx.x == 0) nxt = atomicAdd(Q.next, 1);
+    if (threadIdx.x == 0) {
+        const int k = atomicAdd(Q.next, 1);
+        nxt = k < *Q.qend ? Q.qids[k] : -1;
+    }
     __syncthreads();
     const int sc = nxt;
-    if (sc >= Q.M) {
+    if (sc < 0) {
         if (threadIdx.x == 0) Q.slot_scen[inst] = -1;
         return;
     }

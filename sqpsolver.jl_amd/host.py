@@ -376,6 +376,27 @@ class Context:
     def stream_run(self):
         self._ck(self.L.sqphip_sqp_stream_run(self.h))
 
+    # ... shared between ranks: this rank's part of the queue as an explicit id list
+    def stream_assign(self, ids):
+        a = np.ascontiguousarray(ids, dtype=np.int32)
+        self._ck(self.L.sqphip_sqp_stream_assign(self.h, len(a), _i(a)))
+
+    def stream_append(self, ids):
+        a = np.ascontiguousarray(ids, dtype=np.int32)
+        self._ck(self.L.sqphip_sqp_stream_append(self.h, len(a), _i(a)))
+
+    def stream_release(self, n):
+        """take up to n unstarted ids off the tail of this rank's queue"""
+        out = np.zeros(max(1, int(n)), dtype=np.int32); k = C.c_int32()
+        self._ck(self.L.sqphip_sqp_stream_release(self.h, int(n), _i(out), C.byref(k)))
+        return out[:k.value].copy()
+
+    def stream_run_some(self, max_outer):
+        """every slot performs up to max_outer more outer iterations; returns (unstarted ids of this rank, slots still running)"""
+        u, a = C.c_int32(), C.c_int32()
+        self._ck(self.L.sqphip_sqp_stream_run_some(self.h, int(max_outer), C.byref(u), C.byref(a)))
+        return u.value, a.value
+
     def stream_get(self, scen):
         x = np.zeros(self.n); obj = C.c_double(); st = C.c_int32(); it = C.c_int32()
         self._ck(self.L.sqphip_sqp_stream_get(self.h, int(scen), _d(x), C.byref(obj), C.byref(st), C.byref(it)))

@@ -668,10 +668,13 @@ def test_case118_sqp_first_iterations_match_oracle():
     default of the linear algebra: condensed matrix of order 2069 through the multifrontal path): the first four outer
     iterations of the base case and of two contingencies against the oracle, which factorises with its own sparse
     LDL^T in its own minimum-degree order -- every accept / reject / restoration decision and sub-problem status
-    equal, interior-point iteration counts as above.  The iterates: a truncated trajectory that went through a
-    degenerate restoration LP is reproducible only as far as the oracle reproduces ITSELF under a re-ordering, so the
-    device is held to the spread between the oracle's sparse and dense runs (never tighter than the truncated-
-    trajectory tolerance); trajectories without that ambiguity agree to 1e-10."""
+    equal, interior-point iteration counts as above.  The fourth iteration solves a degenerate restoration LP, whose
+    optimal face is not a point: the ITERATES behind it are not comparable between two correct solvers (round 2 held
+    them to three times the spread between the oracle's own sparse and dense runs -- not falsifiable).
+    What is asserted about the iterates instead, in tests/test_gpu_parity_depth.py: the point at 1e-8 after the three
+    iterations in front of that LP (test_case118_prefix_before_the_first_restoration_is_exact), and for every
+    sub-problem along the device's trajectory, restoration LPs included, parity with the oracle of step, multipliers
+    or optimal value (test_subproblems_of_the_bench_run_replay_through_both_seats)."""
     nb, ng, nl, seed = CASES["case118"]
     base = acopf_synth(nb, ng, nl, seed)
     nets = [base, contingency(base, 7, seed), contingency(base, 3, seed)]
@@ -680,17 +683,12 @@ def test_case118_sqp_first_iterations_match_oracle():
     ctx = _run_batch(nets, lays, kw)
     c = ctx.counters()
     assert c["sparse"] == 1 and c["kkt_order"] == 2069 and c["max_front"] < 128
-    tight = 0
     for b in range(len(nets)):
         ro = O.sqp_solve(O.problem_acopf(nets[b], lays[b]), O.default_options(kkt_mode=2, **kw))
-        rd = O.sqp_solve(O.problem_acopf(nets[b], lays[b]), O.default_options(kkt_mode=1, num_threads=host_threads(), **kw))
         rg = ctx.sqp_get(b); tr = ctx.sqp_trace(b)
-        assert (rg["status"], rg["iter"]) == (ro["status"], ro["iter"]) == (rd["status"], rd["iter"])
+        assert (rg["status"], rg["iter"]) == (ro["status"], ro["iter"])
         assert _same_decisions(ro, tr) and _ipm_counts_close(ro, tr)
-        spread = rel(rd["x"], ro["x"])
-        assert rel(rg["x"], ro["x"]) <= max(TOL_TRAJ, 3.0 * spread), (b, spread)
-        tight += spread < 1e-8
-    assert tight >= 1                         # at least one of the three runs is unambiguous and compared at 1e-5
+        assert any(t["fr"] and t["sub_status"] == O.MOI_LOCALLY_SOLVED for t in tr)      # the restoration LP is in the window
     ctx.close()
 
 

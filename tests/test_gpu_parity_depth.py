@@ -1,0 +1,236 @@
+"""Parity in depth (run with -m gpu on an MI355X; VERDICT r2 "what's weak" 2-4): what the oracle and the device can be
+held to on the configuration the bench times (reference Hessian sign, 512 resident scenarios), on the large shapes and
+on networks no other test pins.  Everything goes through the C ABI of libsqphip.so; the oracle (oracle/) is the checker.
+
+The invariant on the headline workload.  With the reference's JuMP-sign Hessian the sub-problems
+are non-convex and every run passes through degenerate feasibility-restoration LPs whose optimal face is not a point: two
+correct solvers leave such an LP at different points and the trajectories separate (measured with
+scripts/gpu_decisions_depth.py: 4 of 12 random bench scenarios take a different accept / reject decision somewhere
+between iterations 13 and 23, |dx| up to 0.18 at iteration 25).  What does hold, and is asserted here, is parity of
+every sub-problem along the device's own trajectory: the request the batched run worked on is fetched from the device
+and solved again by the drop-in seat of a fresh context (must reproduce the batched run's status and work counters
+exactly) and by the oracle's seat (same status; step and multipliers at 1e-8 / 1e-7 for the trust-region and correction
+QPs; the optimal VALUE for restoration LPs).  Data behind the tolerances: scripts/gpu_replay_depth.py, 200 sub-problems:
+status 200 / 200, counters 196 / 200 equal, max |dp| 4.3e-9, max |dlambda| 1.1e-8, restoration optimal value 1.9e-7."""
+import os
+
+import numpy as np
+import pytest
+
+import sqpsolver_jl_amd as pkg
+from sqpsolver_jl_amd.acopf_synth import acopf_synth, acopf_layout, acr_layout, contingency, synth_case, CASES
+from oracle import oracle as O
+from test_gpu_parity import _ipm_counts_close, _oracle_qp, _run_batch, _same_decisions, host_threads, rel, TOL
+
+pytestmark = pytest.mark.gpu
+
+
+def _structure(lay):
+    return dict(n=lay.n, m=lay.m, num_linear=lay.num_linear, jrow=lay.jrow, jcol=lay.jcol, hrow=lay.hrow, hcol=lay.hcol,
+                xL=lay.xL, xU=lay.xU, gL=lay.gL, gU=lay.gU)
+
+
+def _ctx(lay, opts, batch=1):
+    return pkg.Context(lay.n, lay.m, lay.num_linear, lay.jrow, lay.jcol, lay.hrow, lay.hcol, lay.xL, lay.xU, lay.gL, lay.gU,
+                       opts, batch=batch)
+
+
+def test_subproblems_of_the_bench_run_replay_through_both_seats():
+    """The bench configuration itself: 512 resident IEEE-118-shaped scenarios, the example's SQP options, the reference's
+    Hessian sign.  Eight scenarios drawn at random, 25 outer iterations: after every iteration the sub-problem each of
+    them worked on last (trust-region QP, second-order correction or restoration LP) is replayed -- see the module text."""
+    nb, ng, nl, seed = CASES["case118"]
+    base = acopf_synth(nb, ng, nl, seed)
+    lay0 = acopf_layout(base)
+    B, iters = 512, 25
+    kw = dict(max_iter=3000, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=1)
+    ctx = _ctx(lay0, pkg.default_options(**kw), batch=B)
+    ctx.acopf_attach(base, lay0)
+    lays = {}
+    for b in range(B):
+        net = base if b == 0 else contingency(base, b, seed)
+        lays[b] = acopf_layout(net)
+        ctx.acopf_set_instance(b, net, lays[b])
+    ids = sorted(np.random.default_rng(5).choice(B, size=8, replace=False).tolist())
+    seats = {b: _ctx(lays[b], pkg.default_options(**kw)) for b in ids}
+    oseats = {b: _oracle_qp(None, _structure(lays[b]), O.default_options(kkt_mode=2, **kw)) for b in ids}
+    ctx.sqp_reset()
+    nlog = {b: 0 for b in ids}
+    n_sub = n_equal_counts = 0
+    modes = set()
+    for _ in range(iters):
+        ctx.sqp_run(1)
+        for b in ids:
+            log = ctx.sqp_qp_log(b)
+            if len(log) == nlog[b]:
+                continue
+            nlog[b] = len(log)
+            rq = ctx.sqp_last_request(b)
+            args = (rq["mode"], rq["x_k"], rq["delta"], rq["mu_pen"], rq["c"], rq["b"], rq["jac_coo"], rq["hess_coo"])
+            rg, ro = seats[b].qp_solve(*args), oseats[b](*args)
+            # the batched run and the seat are one code path: same status, same work, bit for bit
+            assert (rg["status"], rg["ipm_iters"], rg["n_factor"]) == tuple(log[-1][1:]), (b, log[-1])
+            assert rg["status"] == ro["status"], (b, rq["mode"])
+            n_sub += 1
+            modes.add(rq["mode"])
+            n_equal_counts += (rg["ipm_iters"], rg["n_factor"]) == (ro["ipm_iters"], ro["n_factor"])
+            assert abs(rg["ipm_iters"] - ro["ipm_iters"]) <= max(2, 0.2 * ro["ipm_iters"]), (b, rq["mode"])
+            if ro["status"] != O.MOI_LOCALLY_SOLVED:
+                continue
+            if rq["mode"] == O.MODE_FR:          # a linear programme: the optimal value is what is unique
+                vo, vg = float(ro["slack"].sum()), float(rg["slack"].sum())
+                assert abs(vg - vo) <= 1e-6 * max(1.0, abs(vo)), (b, vg, vo)
+            else:
+                assert rel(rg["p"], ro["p"]) < TOL, (b, rq["mode"])
+                assert rel(rg["lam"], ro["lam"]) < 1e-7 and rel(rg["mult_x_L"] - rg["mult_x_U"], ro["mult_x_L"] - ro["mult_x_U"]) < 1e-7
+    assert n_sub >= 8 * iters - 8 and {O.MODE_QP, O.MODE_SOC, O.MODE_FR} <= modes
+    # equal interior-point iteration AND factorisation counts on all but a few sub-problems (degenerate LPs, one
+    # infeasible QP in the collection run): two implementations with different elimination orders
+    assert n_equal_counts >= 0.95 * n_sub, (n_equal_counts, n_sub)
+    for c in seats.values():
+        c.close()
+    ctx.close()
+
+
+def test_case118_prefix_before_the_first_restoration_is_exact():
+    """The same workload up to the iteration in front of its first restoration LP (three outer iterations: linear phase,
+    an accepted trust-region step, a rejected one with its second-order correction, the infeasible QP that enters
+    restoration): nothing degenerate has been solved yet, so the whole state must agree -- every decision, the iterate
+    and the objective at 1e-8.  Interior-point iteration counts are held to the allowance of test_gpu_parity.py (two
+    iterations or 20 %): a solve ends when its error measure crosses a threshold; the base case's first QP crosses it at
+    iteration 19, 20 or 21 depending on the elimination order (oracle dense / device / oracle sparse with every
+    direction refined), contingency 7's correction at 14 or 17, and forcing a refinement step on every direction on both
+    sides (SQPHIP_REFINE_TOL = ORA_REFINE_TOL = 0) does not remove that (measured: 20 against 21) -- equal counts are
+    asserted statistically instead, over the 200 sub-problems of the replay test above."""
+    nb, ng, nl, seed = CASES["case118"]
+    base = acopf_synth(nb, ng, nl, seed)
+    nets = [base, contingency(base, 7, seed), contingency(base, 3, seed), contingency(base, 262, seed)]
+    lays = [acopf_layout(nt) for nt in nets]
+    kw = dict(max_iter=3, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=1)
+    ctx = _run_batch(nets, lays, kw)
+    for b in range(len(nets)):
+        ro = O.sqp_solve(O.problem_acopf(nets[b], lays[b]), O.default_options(kkt_mode=2, **kw))
+        rg, tr = ctx.sqp_get(b), ctx.sqp_trace(b)
+        assert (rg["status"], rg["iter"]) == (ro["status"], ro["iter"])
+        assert _same_decisions(ro, tr)
+        assert _ipm_counts_close(ro, tr), b
+        assert rel(rg["x"], ro["x"]) < TOL and abs(rg["obj_val"] - ro["obj_val"]) <= TOL * abs(ro["obj_val"]), b
+    ctx.close()
+
+
+def test_whole_subproblems_on_case9241_match_oracle():
+    """BASELINE.json configs[4] (9241pegase shape, Newton matrix of order 232 443 condensed to 168 247, 6.95 M entries in
+    the fronts): two whole sub-problems at the start point through `sqphip_qp_solve` against the oracle's independent
+    sparse LDL^T -- the linear-phase projection QP (strictly convex: status, iteration count, the step at 1e-8) and the
+    restoration LP (status; its optimal value when solved)."""
+    nb, ng, nl, seed = CASES["case9241"]
+    net = acopf_synth(nb, ng, nl, seed); lay = acopf_layout(net)
+    P = O.problem_acopf(net, lay)
+    ctx = _ctx(lay, pkg.default_options())
+    assert ctx.counters()["sparse"] == 1 and ctx.counters()["kkt_order"] == 168247
+    osolve = _oracle_qp(P, P.structure(), O.default_options(kkt_mode=2, num_threads=16))
+    x = lay.x0
+    df, E, jv, hv = P.eval_grad_f(x), P.eval_g(x), P.eval_jac_g(x), P.eval_h(x, 1.0, np.zeros(lay.m))
+    for mode in (O.MODE_LP, O.MODE_FR):
+        ro, rg = osolve(mode, x, 10.0, 1.0, df, E, jv, hv), ctx.qp_solve(mode, x, 10.0, 1.0, df, E, jv, hv)
+        assert rg["status"] == ro["status"], mode
+        assert abs(rg["ipm_iters"] - ro["ipm_iters"]) <= max(2, 0.2 * ro["ipm_iters"]), mode
+        if ro["status"] == O.MOI_LOCALLY_SOLVED:
+            if mode == O.MODE_LP:
+                assert rel(rg["p"], ro["p"]) < TOL and rel(rg["lam"], ro["lam"]) < 1e-6
+            else:
+                assert abs(rg["slack"].sum() - ro["slack"].sum()) <= 1e-5 * max(1.0, ro["slack"].sum())
+    ctx.close()
+
+
+@pytest.mark.parametrize("form", ["polar", "acr"])
+def test_unpinned_networks_terminate_like_the_oracle(form):
+    """Robustness on networks no other test pins (scripts/gpu_seed_fuzz.py promoted): seven other generator seeds of the
+    IEEE-118 shape, base case and two contingencies each, polar and rectangular voltages, run to termination (textbook
+    Hessian sign).  Every run must end with the oracle's status; converged runs at the same point (1e-6) after the same
+    number of outer iterations -- except that ONE run of the 21 per formulation may differ by one outer iteration: a
+    termination test decided at its threshold (round 2's collection had one such run in 42: the device converged one
+    iteration later to the same point, 5e-9)."""
+    from concurrent.futures import ThreadPoolExecutor
+    nb, ng, nl, seed0 = CASES["case118"]
+    layout = acopf_layout if form == "polar" else acr_layout
+    kw = dict(max_iter=60, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=0)
+    jobs, dev = [], {}
+    for seed in range(seed0 + 1, seed0 + 8):
+        base = acopf_synth(nb, ng, nl, seed)
+        nets = [base, contingency(base, 1, seed), contingency(base, 2, seed)]
+        lays = [layout(nt) for nt in nets]
+        ctx = _ctx(lays[0], pkg.default_options(**kw), batch=3)
+        ctx.acopf_attach(base, lays[0])
+        for b in range(3):
+            ctx.acopf_set_instance(b, nets[b], lays[b])
+            jobs.append((seed, b, nets[b], lays[b]))
+        ctx.sqp_reset(); ctx.sqp_run(0)
+        for b in range(3):
+            dev[(seed, b)] = ctx.sqp_get(b)
+        ctx.close()
+    # the 21 oracle runs side by side (ctypes releases the GIL inside the oracle's solver)
+    with ThreadPoolExecutor(max_workers=host_threads()) as ex:
+        ora = list(ex.map(lambda j: O.sqp_solve(O.problem_acopf(j[2], j[3]), O.default_options(num_threads=1, **kw)), jobs))
+    off_by_one = 0
+    for (seed, b, _, _), ro in zip(jobs, ora):
+        rg = dev[(seed, b)]
+        assert rg["status"] == ro["status"], (seed, b)
+        if rg["iter"] != ro["iter"]:
+            assert abs(rg["iter"] - ro["iter"]) == 1 and ro["status"] == 0, (seed, b, rg["iter"], ro["iter"])
+            off_by_one += 1
+        if ro["status"] == 0:
+            assert rel(rg["x"], ro["x"]) < 1e-6, (seed, b)
+            assert abs(rg["obj_val"] - ro["obj_val"]) <= 1e-7 * abs(ro["obj_val"]), (seed, b)
+    assert off_by_one <= 1
+
+
+def test_case1354_geo_converges_like_the_oracle():
+    """BASELINE.json configs[2] as a CONVERGENT problem (round 3: `acopf_synth_geo`, the lattice-strip network with local
+    generation; the SURVEY.md section 8d recipe stays in restoration at this size): base case and one contingency run to
+    convergence on the device (multifrontal path, order 21 865) and in the oracle (its own sparse LDL^T and ordering) --
+    status, outer iteration count and every accept / reject / restoration decision equal, objective and point at 1e-8.
+    Termination as /root/reference/src/algorithms/sqp_trust_region.jl:187-204; the reference's own example runs its
+    ACOPF cases to convergence (examples/acopf/opf.jl:76-84)."""
+    base = synth_case("case1354")
+    nets = [base, contingency(base, 17, CASES["case1354"][3])]
+    lays = [acopf_layout(nt) for nt in nets]
+    kw = dict(max_iter=40, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=0)
+    ctx = _run_batch(nets, lays, kw)
+    c = ctx.counters()
+    assert c["sparse"] == 1 and c["kkt_order"] == 21865 and c["max_front"] <= 208
+    for b in range(2):
+        ro = O.sqp_solve(O.problem_acopf(nets[b], lays[b]), O.default_options(kkt_mode=2, num_threads=16, **kw))
+        rg, tr = ctx.sqp_get(b), ctx.sqp_trace(b)
+        assert ro["status"] == 0 and (rg["status"], rg["iter"]) == (ro["status"], ro["iter"]), b
+        assert _same_decisions(ro, tr) and _ipm_counts_close(ro, tr), b
+        assert abs(rg["obj_val"] - ro["obj_val"]) <= TOL * abs(ro["obj_val"]) and rel(rg["x"], ro["x"]) < TOL, b
+    ctx.close()
+
+
+def test_queue_shared_between_two_ranks_gives_the_single_rank_results(tmp_path):
+    """SURVEY.md section 8f-4 remainder: a scenario queue shared between ranks.  Two fresh rank processes on the one GPU
+    of the box (--backend gloo --one-device, as the status-gather rehearsal) run 14 IEEE-14-shaped scenarios through 3
+    slots each; rank 0 starts with three quarters of the ids, so rank 1 runs dry and is handed unstarted ids by the
+    host-side exchange of sqpsolver.jl_amd/shard.py (run_shared_queue).  Per scenario the two-rank job must return the
+    bits of the single-rank run: status, iteration count, objective."""
+    import json, subprocess, sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--workload", "case14", "--batch", "3", "--shared-queue", "14", "--literal-quirks", "0", "--quick"]
+    one = tmp_path / "one.json"; two = tmp_path / "two.json"
+    r1 = subprocess.run([_sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dump-status", str(one)] + common,
+                        check=True, cwd=root, capture_output=True, timeout=600)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT="29537")
+        procs.append(subprocess.Popen([_sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                                       "--one-device", "--queue-split", "0.75", "--dump-status", str(two)] + common, cwd=root,
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-800:] for o in outs]
+    line = json.loads(outs[0][0].decode().strip().splitlines()[-1])
+    assert line["mode"] == "shared_queue" and line["n_gpus"] == 2 and sum(line["solved_by_rank"]) == 14
+    assert line["solved_by_rank"][1] > 14 - round(14 * 0.75)          # rank 1 solved more than its initial share
+    a, b = json.load(open(one)), json.load(open(two))
+    assert a == b and all(i > 0 for i in a["iter"])
+    assert json.loads(r1.stdout.decode().strip().splitlines()[-1])["converged"] >= 12
