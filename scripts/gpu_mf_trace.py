@@ -63,3 +63,15 @@ if L.sqphip_mf_trace2_read(buf2.ctypes.data_as(C.POINTER(C.c_longlong)), ns) == 
         if t[0] == 0: continue
         seg = [t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5], (t[9] - t[6]) if t[9] > 0 else -1, t[7] - t[2], t[8] - t[7], t[10] - t[8]]
         print(f"  front {srow:4d}: " + " ".join(f"{int(v):7d}" for v in seg))
+
+# the four-wave solve routines (thread 0): forward: loads issued | barrier | gather | 16-column blocks | rows below ; backward likewise
+buf3 = np.zeros((ns, 16), dtype=np.int64)
+L.sqphip_mf_trace3_read.argtypes = [C.POINTER(C.c_longlong), C.c_int]
+if L.sqphip_mf_trace3_read(buf3.ctypes.data_as(C.POINTER(C.c_longlong)), ns) == 0:
+    print("four-wave solves, cycles: fwd: issue | wait+barrier | gather | blocks | rows-below   bwd: issue | wait+barrier | L21'x | blocks")
+    for srow in range(ns):
+        t = buf3[srow]
+        if t[8] == 0: continue
+        f = [t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4]] if t[0] else [0] * 5
+        b = [t[9] - t[8], t[10] - t[9], t[11] - t[10], t[12] - t[11]]
+        print(f"  front {srow:4d}: fwd " + " ".join(f"{int(v):6d}" for v in f) + "   bwd " + " ".join(f"{int(v):6d}" for v in b))

@@ -11,7 +11,8 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 SO_PATH = os.path.join(_CSRC, "libsqphip.so")
 SOURCES = ["ldlt.hip", "kernel_api.hip", "ipm.hip", "acopf.hip", "sqp.hip", "api.hip", "order.hip", "symbolic.hip",
            "mfplan.hip", "mfront.hip", "comm.hip"]
-HEADERS = ["sqphip_internal.hpp", "ctx.hpp", "sparse.hpp", "dev_util.hpp", "acopf_dev.hpp", os.path.join("..", "..", "include", "sqphip.h")]
+HEADERS = ["sqphip_internal.hpp", "ctx.hpp", "sparse.hpp", "dev_util.hpp", "acopf_dev.hpp", os.path.join("..", "..", "include", "sqphip.h"),
+           os.path.join("..", "..", "include", "sqphip_test_hooks.h")]
 
 _lib = None
 

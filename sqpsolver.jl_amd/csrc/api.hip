@@ -130,7 +130,7 @@ void make_lanes(Ctx &C)
         // queues by default, and a fifth stream would share one -- measured: 3131 QP/s with five streams against 5216
         // with four (or with GPU_MAX_HW_QUEUES=8)
         if (g == 0) { L->stream = C.stream; L->owns_stream = false; }
-        else SQPHIP_HIP_OK(hipStreamCreate(&L->stream));
+        else SQPHIP_HIP_OK(hipStreamCreateWithFlags(&L->stream, getenv("SQPHIP_STREAM_BLOCKING") ? hipStreamDefault : hipStreamNonBlocking));
         SQPHIP_HIP_OK(hipHostMalloc((void **)&L->h_counters, 8 * sizeof(int)));
         L->tm.enabled = C.tm.enabled;
         C.lanes.push_back(std::move(L));

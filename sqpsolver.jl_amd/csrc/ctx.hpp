@@ -5,6 +5,7 @@
 #include <memory>
 #include <vector>
 #include "../../include/sqphip.h"
+#include "../../include/sqphip_test_hooks.h"
 #include "sqphip_internal.hpp"
 #include "sparse.hpp"
 

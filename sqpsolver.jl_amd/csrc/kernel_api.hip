@@ -1,5 +1,6 @@
 // kernel_api.hip -- kernel-level C entry points (parity tests and micro-benchmarks of the LDL^T).
 #include "../../include/sqphip.h"
+#include "../../include/sqphip_test_hooks.h"
 #include "sqphip_internal.hpp"
 #include <cmath>
 #include <cstring>

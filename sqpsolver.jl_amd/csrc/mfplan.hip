@@ -8,6 +8,7 @@
 //     [ J_K                       -(D_K + reg) ]
 #include "sparse.hpp"
 #include "../../include/sqphip.h"
+#include "../../include/sqphip_test_hooks.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -150,11 +151,17 @@ MfPlan mf_build_plan(int n, int m, const std::vector<int> &kpos, int mk, const s
     auto tiles = [&](int s) { return (S.sn_nc[s] + S.sn_nr[s] + 1 + 15) / 16; };
     auto cls = [&](int s) { const int T = tiles(s); return T <= 8 ? T - 1 : (T <= 13 ? 8 : 9); };
     for (int l = 0; l < S.nlevels; ++l) {
+        // a level with a handful of fronts (the upper part of the tree) is ONE launch of the kernel of its tallest
+        // front: a front of fewer tiles runs in it with empty tiles, off the critical path of the level, and every
+        // launch saved is a dependent kernel boundary less in a chain of ~45 per sweep
+        int cnt = 0, tmax = 0;
+        for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; ++q) { ++cnt; tmax = std::max(tmax, tiles(S.level_sn[q])); }
+        const bool merge = cnt <= 8 && tmax <= 8 && !getenv("SQPHIP_MF_NO_LEVEL_MERGE");
         for (int c = 0; c < 10; ++c) {
             MfLaunch L{(int)P.sched.size(), 0, 0, 0, c, 0};
             for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; ++q) {
                 const int s = S.level_sn[q];
-                if (cls(s) != c) continue;
+                if (merge ? c != tmax - 1 : cls(s) != c) continue;
                 P.sched.push_back(s);
                 L.count++;
                 L.tiles = std::max(L.tiles, tiles(s));

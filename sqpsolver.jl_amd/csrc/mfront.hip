@@ -66,9 +66,13 @@ __device__ long long g_mf_trace[1 << 16][8];
 // shader-clock stamps inside the static front kernel (wave 0 of instance 0): [front][16]
 __device__ long long g_mf_trace2[1 << 12][16];
 #define MF_TRW(i) if (W == 0 && trs >= 0 && trs < (1 << 12) && lane == 0) g_mf_trace2[trs][i] = (long long)clock64();
+// ... and inside the four-wave solve routines (thread 0 of instance 0): [front][forward 0..7 | backward 8..15]
+__device__ long long g_mf_trace3[1 << 12][16];
+#define MF_TRS(i) if (inst == 0 && tid == 0 && s < (1 << 12)) g_mf_trace3[s][i] = (long long)clock64();
 #else
 #define MF_TR(i)
 #define MF_TRW(i)
+#define MF_TRS(i)
 #endif
 
 // Thread layout inside a front: RL row lanes x (NT / RL) column groups; RL = 16 / 32 / 64 by front height so that a
@@ -160,6 +164,10 @@ __global__ __launch_bounds__(NT) void k_mf_factor(DV d, int sbegin, int want, in
 extern "C" int sqphip_mf_trace_read(long long *out, int nfronts)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mf_trace), sizeof(long long) * 8 * (size_t)nfronts);
+}
+extern "C" int sqphip_mf_trace3_read(long long *out, int nfronts)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mf_trace3), sizeof(long long) * 16 * (size_t)nfronts);
 }
 extern "C" int sqphip_mf_trace2_read(long long *out, int nfronts)
 {
@@ -820,6 +828,29 @@ __device__ __forceinline__ void mf_front_bwd(const DV &d, int inst, int s, doubl
     }
 }
 
+// L11 corner of a front into LDS, by the four waves of a workgroup.  Written as "load sixteen columns' worth into
+// registers, then store": with the load and the LDS store of an entry in one loop body the compiler waits for every
+// load before the next is issued (measured on the 80-column front of IEEE-118: 15 900 cycles for the staging against
+// 2 300 for everything else that precedes the triangular solve).
+__device__ __forceinline__ void mf_stage_l11(double *Ls, const double *G, int nc, int ld, int lane, int wave)
+{
+    for (int c0 = wave; c0 < nc; c0 += 64) {           // sixteen columns of this wave per batch, two rows per lane and column
+        double t0[16], t1[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int c = c0 + 4 * q, r0 = c + 1 + lane, r1 = r0 + 64;
+            t0[q] = (c < nc && r0 < nc) ? G[(long)c * ld + r0] : 0.0;
+            t1[q] = (c < nc && r1 < nc) ? G[(long)c * ld + r1] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int c = c0 + 4 * q, r0 = c + 1 + lane, r1 = r0 + 64;
+            if (c < nc && r0 < nc) Ls[c * nc + r0] = t0[q];
+            if (c < nc && r1 < nc) Ls[c * nc + r1] = t1[q];
+        }
+    }
+}
+
 // A front of more than 64 rows, by the four waves of a workgroup.  The triangular part L11 (its nc x nc corner) is
 // staged in LDS with all loads in flight at once; the dependent chain -- 16 columns at a time, the 16 x 16 diagonal block
 // by a shuffle chain in wave 0, the rest of the triangle by all threads -- then runs at LDS latency.  The rectangular
@@ -836,11 +867,39 @@ __device__ __forceinline__ void mf_front_fwd_big(const DV &d, int inst, int s, d
     const double *b = d.xv + (long)inst * d.Fpad + f0, *dinv = mf_dinv(d, inst, cand) + f0;
     double *vv = mf_vv(d, inst, cand) + f0;
     const int lane = tid & 63, wave = tid >> 6;
-    if (Ls)
-        for (int c = wave; c < nc; c += 4)
-            for (int r = c + 1 + lane; r < nc; r += 64) Ls[c * nc + r] = G[(long)c * ld + r];
+    // Every global load of this front that does not depend on the solve is issued HERE, in one batch: the L11 corner (to
+    // LDS), the L21 entries this thread needs for the rows below the supernode (to registers: two row blocks of 32 rows x
+    // up to 16 of the thread's columns), the right-hand side.  A front's solve is a chain of dependent memory round trips
+    // of 1 - 2 us each with little arithmetic in between; loading L21 where it is used cost two or three more of them.
+    MF_TRS(0)
+    constexpr int PB = 2, PK = 16;
+    const bool pre = Ls && nc >= 16 && nr <= 32 * PB && nc <= 8 * PK;
+    double l21[PB][PK];
+    if (pre) {
+        const int r = tid & 31, kc = tid >> 5;
+#pragma unroll
+        for (int rb = 0; rb < PB; ++rb) {
+            const int i = nc + 32 * rb + r;
+#pragma unroll
+            for (int q = 0; q < PK; ++q) {
+                const int k = kc + 8 * q;
+                l21[rb][q] = (i < fs && k < nc) ? G[(long)k * ld + i] : 0.0;
+            }
+        }
+    }
+    if (Ls) {
+        if (nc <= 128) mf_stage_l11(Ls, G, nc, ld, lane, wave);
+        else
+            for (int c = wave; c < nc; c += 4)
+                for (int r = c + 1 + lane; r < nc; r += 64) Ls[c * nc + r] = G[(long)c * ld + r];
+    }
+    double dv[8];                                        // 1 / D of the columns wave 0 finishes: block kb / 16, column lane
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dv[q] = (wave == 0 && lane < 16 && 16 * q + lane < nc) ? dinv[16 * q + lane] : 0.0;
     for (int i = tid; i < fs; i += 256) y[i] = i < nc ? b[i] : 0.0;
+    MF_TRS(1)
     __syncthreads();
+    MF_TRS(2)
     for (int t = Fd.ev_begin + tid; t < Fd.ev_end; t += 256) {
         const MfGather g = M.ev_ent[t];
         double a = arena[g.src0];
@@ -848,6 +907,7 @@ __device__ __forceinline__ void mf_front_fwd_big(const DV &d, int inst, int s, d
         y[g.where] += a;
     }
     __syncthreads();
+    MF_TRS(3)
     const double *L = Ls ? Ls : G;
     const int ll = Ls ? nc : ld;
     for (int kb = 0; kb < nc; kb += 16) {
@@ -859,8 +919,8 @@ __device__ __forceinline__ void mf_front_fwd_big(const DV &d, int inst, int s, d
             double yi = lane < nb ? y[kb + lane] : 0.0;
 #pragma unroll
             for (int c = 0; c < 15; ++c) yi -= l[c] * mf_readlane(yi, c);      // v_readlane: ~20 cycles; __shfl (ds_bpermute): 85
-            if (lane < nb) { y[kb + lane] = yi; vv[kb + lane] = yi * dinv[kb + lane]; }
-        }
+            if (lane < nb) y[kb + lane] = yi;      // (D^-1 y goes to global memory behind the loop: a barrier behind a
+        }                                          //  global store waits for the store -- __syncthreads() is vmcnt(0) + s_barrier)
         __syncthreads();
         for (int i = kb + nb + tid; i < nc; i += 256) {          // the rest of the triangle
             double acc = 0.0;
@@ -874,13 +934,28 @@ __device__ __forceinline__ void mf_front_fwd_big(const DV &d, int inst, int s, d
     // many columns: one thread per row would walk nc dependent-latency loads while most of the workgroup idles, so eight
     // column groups share a row (32 rows x 8 groups per pass) and their partial sums meet, in fixed order, in the LDS
     // area the L11 image no longer needs.
+    MF_TRS(4)
+    if (wave == 0) {                                 // D^-1 L^-1 b of the front's columns, one batch of stores
+        if (nc <= 128) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (lane < 16 && 16 * q + lane < nc) vv[16 * q + lane] = y[16 * q + lane] * dv[q];
+        } else for (int k = lane; k < nc; k += 64) vv[k] = y[k] * dinv[k];
+    }
     if (Ls && nc >= 16) {
         double *part = Ls;
         const int r = tid & 31, kc = tid >> 5;
         for (int rb = nc; rb < fs; rb += 32) {
             const int i = rb + r;
             double a = 0.0;
-            if (i < fs) {
+            if (pre) {          // same products in the same order, the L21 entries from the registers
+                const int b2 = (rb - nc) >> 5;
+#pragma unroll
+                for (int q = 0; q < PK; ++q) {
+                    const int k = kc + 8 * q;
+                    const double lv = b2 == 0 ? l21[0][q] : l21[1][q];
+                    if (i < fs && k < nc) a += lv * y[k];
+                }
+            } else if (i < fs) {
 #pragma unroll 4
                 for (int k = kc; k < nc; k += 8) a += G[(long)k * ld + i] * y[k];
             }
@@ -894,6 +969,7 @@ __device__ __forceinline__ void mf_front_fwd_big(const DV &d, int inst, int s, d
             }
             __syncthreads();
         }
+        MF_TRS(5)
         return;
     }
     for (int i = nc + tid; i < fs; i += 256) {
@@ -916,14 +992,52 @@ __device__ __forceinline__ void mf_front_bwd_big(const DV &d, int inst, int s, d
     const int *rows = M.rows + Fd.rowptr;
     const int lane = tid & 63, wave = tid >> 6;
     double *part = x + fs;                       // 16 block sums behind the vector
-    if (Ls)
-        for (int c = wave; c < nc; c += 4)
-            for (int r = c + 1 + lane; r < nc; r += 64) Ls[c * nc + r] = G[(long)c * ld + r];
+    // as in the forward routine: the L21 entries of this thread (four passes of 32 columns x up to 8 of its rows) are
+    // requested together with the L11 corner and the gather of x_rows -- one round trip instead of three or four
+    MF_TRS(8)
+    constexpr int PP = 4, PR = 8;
+    const bool pre = Ls && nc <= 32 * PP && nr <= 8 * PR;
+    double l21[PP][PR];
+    if (pre) {
+        const int c = tid >> 3, r = tid & 7;
+#pragma unroll
+        for (int p = 0; p < PP; ++p) {
+            const int k = 32 * p + c;
+#pragma unroll
+            for (int q = 0; q < PR; ++q) {
+                const int i = nc + r + 8 * q;
+                l21[p][q] = (k < nc && i < fs) ? G[(long)k * ld + i] : 0.0;
+            }
+        }
+    }
+    if (Ls) {
+        if (nc <= 128) mf_stage_l11(Ls, G, nc, ld, lane, wave);
+        else
+            for (int c = wave; c < nc; c += 4)
+                for (int r = c + 1 + lane; r < nc; r += 64) Ls[c * nc + r] = G[(long)c * ld + r];
+    }
     for (int i = tid; i < fs; i += 256) x[i] = i < nc ? vv[i] : xg[rows[i - nc]];
+    MF_TRS(9)
     __syncthreads();
+    MF_TRS(10)
     {   // x_cols -= L21' x_rows: column k by 8 threads, 32 columns per pass (a front has tens of rows below its columns:
         // more columns in flight per pass matter more than longer coalesced runs), every column independent of the others
         const int c = tid >> 3, r = tid & 7;
+        if (pre) {
+#pragma unroll
+            for (int p = 0; p < PP; ++p) {
+                const int k = 32 * p + c;
+                if (32 * p >= nc) break;
+                double a = 0.0;
+#pragma unroll
+                for (int q = 0; q < PR; ++q) {
+                    const int i = nc + r + 8 * q;
+                    if (k < nc && i < fs) a += l21[p][q] * x[i];
+                }
+                a += __shfl_xor(a, 4); a += __shfl_xor(a, 2); a += __shfl_xor(a, 1);
+                if (r == 0 && k < nc) x[k] -= a;
+            }
+        } else
         for (int kb = 0; kb < nc; kb += 32) {
             double a = 0.0;
             if (kb + c < nc) {
@@ -936,6 +1050,7 @@ __device__ __forceinline__ void mf_front_bwd_big(const DV &d, int inst, int s, d
         }
     }
     __syncthreads();
+    MF_TRS(11)
     const double *L = Ls ? Ls : G;
     const int ll = Ls ? nc : ld;
     for (int kb = ((nc - 1) >> 4) << 4; kb >= 0; kb -= 16) {
@@ -958,10 +1073,12 @@ __device__ __forceinline__ void mf_front_bwd_big(const DV &d, int inst, int s, d
             double t = lane < nb ? x[kb + lane] - part[lane] : 0.0;
 #pragma unroll
             for (int c = 15; c > 0; --c) t -= l[c - 1] * mf_readlane(t, c);
-            if (lane < nb) { x[kb + lane] = t; xg[f0 + kb + lane] = t; }
+            if (lane < nb) x[kb + lane] = t;
         }
         __syncthreads();
     }
+    for (int k = tid; k < nc; k += 256) xg[f0 + k] = x[k];        // (one batch of stores behind the loop, see the forward routine)
+    MF_TRS(12)
 }
 
 // level-by-level launches: a workgroup of four waves per work item = one front of more than 64 rows (all four waves)

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "../include/sqphip.h"
+#include "../include/sqphip_test_hooks.h"
 
 #define SYM(name) __typeof__(&name) p_##name = (__typeof__(&name))dlsym(h, #name); \
     if (!p_##name) { fprintf(stderr, "missing symbol %s\n", #name); return 2; }

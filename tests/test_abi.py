@@ -15,8 +15,8 @@ from sqpsolver_jl_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    src = open(os.path.join(ROOT, "include", "sqphip.h")).read()
+def _declared(header="sqphip.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(sqphip_[a-z0-9_]+)\s*\(", src)))
 
@@ -24,11 +24,14 @@ def _declared():
 def test_library_loads_and_exports_every_declared_symbol():
     _lib.build()
     L = _lib.lib()
-    declared = _declared()
-    assert len(declared) >= 25
-    missing = [s for s in declared if not hasattr(L, s)]
+    declared, hooks = _declared(), _declared("sqphip_test_hooks.h")
+    assert len(declared) >= 25 and not set(declared) & set(hooks)
+    missing = [s for s in declared + hooks if not hasattr(L, s)]
     assert not missing, missing
-    assert sorted(_lib.EXPORTS) == declared
+    assert sorted(_lib.EXPORTS) == sorted(declared + hooks)
+    # the test hooks stay out of the boundary: the Julia shim binds none of them
+    jl = open(os.path.join(ROOT, "julia", "SqpHip.jl")).read()
+    assert not [h for h in hooks if h in jl]
 
 
 def test_options_defaults_mirror_parameters_jl():
