@@ -232,7 +232,7 @@ def acopf_synth(nb: int, ng: int, nl: int, seed: int, load_scale: float | None =
 
 
 def acopf_synth_geo(nb: int, ng: int, nl: int, seed: int, width: int | None = None, load_scale: float = 0.5,
-                    qd_frac: float = 0.1, x_scale: float = 0.25, compensate: float = 0.0) -> Network:
+                    qd_frac: float = 0.1, x_scale: float = 0.25, compensate: float = 0.0, regions: int = 1) -> Network:
     """Synthetic transmission network with a geography (round 3; VERDICT r2 "missing" #2): the large shapes of
     `acopf_synth` are chains hundreds of branches long that SQP-TR cannot bring to feasibility from a flat start inside
     any reasonable iteration budget.  Here the buses sit on a strip of a square lattice, `width`
@@ -255,7 +255,15 @@ def acopf_synth_geo(nb: int, ng: int, nl: int, seed: int, width: int | None = No
     def bus(r, c):
         return c * W + r
 
-    cand = []                                       # lattice edges among the nb buses (the last column may be short)
+    # regions > 1: the strip is cut into that many regional strips (contiguous bus ranges), joined by two tie lines each
+    # to the region (k - 1) // 2 -- a binary tree of regions, so the regions are parallel subtrees of the assembly tree
+    # instead of one strip thousands of columns long
+    R = max(1, int(regions))
+    colcut = np.linspace(0, L, R + 1).astype(int)
+    region_of_col = np.zeros(L, dtype=int)
+    for k in range(R):
+        region_of_col[colcut[k]:colcut[k + 1]] = k
+    cand, ties = [], []                             # lattice edges among the nb buses (the last column may be short)
     for c in range(L):
         for r in range(W):
             a = bus(r, c)
@@ -263,10 +271,17 @@ def acopf_synth_geo(nb: int, ng: int, nl: int, seed: int, width: int | None = No
                 continue
             if r + 1 < W and bus(r + 1, c) < nb:
                 cand.append((a, bus(r + 1, c)))
-            if c + 1 < L and bus(r, c + 1) < nb:
+            if c + 1 < L and bus(r, c + 1) < nb and region_of_col[c] == region_of_col[c + 1]:
                 cand.append((a, bus(r, c + 1)))
+    for k in range(1, R):
+        par = (k - 1) // 2
+        ca, cb = colcut[k], (colcut[par] + colcut[par + 1]) // 2          # first column of the region, middle of its parent
+        for r in (0, W - 1):
+            if bus(r, ca) < nb and bus(r, cb) < nb:
+                ties.append((min(bus(r, ca), bus(r, cb)), max(bus(r, ca), bus(r, cb))))
+    cand = ties + cand
     assert len(cand) >= nl, "the lattice has fewer edges than nl: choose a wider strip"
-    order = rng.permutation(len(cand))
+    order = np.concatenate([np.arange(len(ties)), len(ties) + rng.permutation(len(cand) - len(ties))]).astype(int)
     parent = list(range(nb))
 
     def find(a):
@@ -285,6 +300,8 @@ def acopf_synth_geo(nb: int, ng: int, nl: int, seed: int, width: int | None = No
         else:
             rest.append((a, b))
     assert len(tree) == nb - 1
+    tie_set = set(ties)
+    rest = [e for e in rest if e in tie_set] + [e for e in rest if e not in tie_set]      # every tie line is built
     edges = tree + rest[:nl - (nb - 1)]
     f_bus = np.asarray([min(a, b) for a, b in edges], dtype=np.int32)
     t_bus = np.asarray([max(a, b) for a, b in edges], dtype=np.int32)
@@ -338,7 +355,11 @@ def synth_case(case: str, topology: str | None = None) -> Network:
         topology = "chain" if nb <= 118 else "geo"
     if topology not in ("chain", "geo"):
         raise ValueError(f"unknown topology {topology!r}")
-    return acopf_synth(nb, ng, nl, seed) if topology == "chain" else acopf_synth_geo(nb, ng, nl, seed)
+    if topology == "chain":
+        return acopf_synth(nb, ng, nl, seed)
+    # 9241 buses carry 1.74 branches per bus (1354: 1.47): 4 buses across and 16 regional strips keep the largest front
+    # at 198 rows and the assembly tree at 69 levels (5 across, one strip: 382 rows; 4 across, one strip: 359 levels)
+    return acopf_synth_geo(nb, ng, nl, seed, width=4, regions=16) if nb > 5000 else acopf_synth_geo(nb, ng, nl, seed)
 
 
 def contingency(net: Network, s: int, base_seed: int) -> Network:

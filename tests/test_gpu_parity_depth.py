@@ -145,18 +145,18 @@ def test_whole_subproblems_on_case9241_match_oracle():
 
 @pytest.mark.parametrize("form", ["polar", "acr"])
 def test_unpinned_networks_terminate_like_the_oracle(form):
-    """Robustness on networks no other test pins (scripts/gpu_seed_fuzz.py promoted; the script runs seven seeds, the
-    test four to stay within a minute per formulation): other generator seeds of the IEEE-118 shape, base case and two
+    """Robustness on networks no other test pins (scripts/gpu_seed_fuzz.py promoted; the script runs seven seeds to 60
+    iterations, the test three to 40 to stay near a minute per formulation): other generator seeds of the IEEE-118 shape, base case and two
     contingencies each, polar and rectangular voltages, run to termination (textbook Hessian sign).  Every run must end
     with the oracle's status; converged runs at the same point (1e-6) after the same number of outer iterations --
-    except that ONE run of the 12 per formulation may differ by one outer iteration: a termination test decided at its
+    except that ONE run of the 9 per formulation may differ by one outer iteration: a termination test decided at its
     threshold (round 2's collection of 42 runs had one: the device converged one iteration later to the same point, 5e-9)."""
     from concurrent.futures import ThreadPoolExecutor
     nb, ng, nl, seed0 = CASES["case118"]
     layout = acopf_layout if form == "polar" else acr_layout
-    kw = dict(max_iter=60, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=0)
+    kw = dict(max_iter=40, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=0)
     jobs, dev = [], {}
-    for seed in range(seed0 + 1, seed0 + 5):
+    for seed in range(seed0 + 1, seed0 + 4):
         base = acopf_synth(nb, ng, nl, seed)
         nets = [base, contingency(base, 1, seed), contingency(base, 2, seed)]
         lays = [layout(nt) for nt in nets]
