@@ -178,8 +178,18 @@ MfPlan mf_build_plan(int n, int m, const std::vector<int> &kpos, int mk, const s
     // pass up, backward pass down, a workgroup barrier between fronts) -- same arithmetic, 2 x levels fewer launches.
     P.top_level = S.nlevels;
     if (big_solve && !(getenv("SQPHIP_MF_TOP") && atoi(getenv("SQPHIP_MF_TOP")) == 0)) {
+        // ... a level of up to four fronts joins the top as well when all of them are wave-sized (<= 64 rows): the four
+        // waves of the instance's workgroup take one each, exactly what a level launch would do, one launch less per pass
+        auto joins = [&](int lev) {
+            const int cnt = S.level_ptr[lev + 1] - S.level_ptr[lev];
+            if (cnt <= 2) return true;
+            if (cnt > 4 || getenv("SQPHIP_MF_TOP_NARROW")) return false;
+            for (int q = S.level_ptr[lev]; q < S.level_ptr[lev + 1]; ++q)
+                if (S.sn_nc[S.level_sn[q]] + S.sn_nr[S.level_sn[q]] > 64) return false;
+            return true;
+        };
         int l = S.nlevels;
-        while (l > 0 && S.level_ptr[l] - S.level_ptr[l - 1] <= 2) --l;
+        while (l > 0 && joins(l - 1)) --l;
         if (S.nlevels - l >= 2) P.top_level = l;
     }
     int top_maxfs = 64, top_lcap = 0;

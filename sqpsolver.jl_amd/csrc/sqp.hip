@@ -468,9 +468,10 @@ __global__ void k_sqp_budget(DV d, int budget)
     for (int i = threadIdx.x; i < d.B; i += blockDim.x) d.sst[i].budget = budget;
 }
 
-__global__ void k_sqp_count(DV d)
+__global__ void k_sqp_count(DV d, int *host_slot)
 {
-    // counters[2] = instances that still have work in this run, [3] = pending sub-problem starts
+    // counters[2] = instances that still have work in this run, [3] = pending sub-problem starts; host_slot: the same
+    // two words in pinned host memory (written from here: one launch per sweep less than a device-to-host copy behind it)
     int nb = 0, ns = 0;
     for (int i = threadIdx.x; i < d.B; i += blockDim.x) {
         const SqpState &S = d.sst[i];
@@ -484,6 +485,7 @@ __global__ void k_sqp_count(DV d)
         int s0 = 0, s1 = 0;
         for (int k = 0; k < (int)blockDim.x; ++k) { s0 += a[k]; s1 += b[k]; }
         d.counters[2] = s0; d.counters[3] = s1;
+        if (host_slot) { host_slot[0] = s0; host_slot[1] = s1; __threadfence_system(); }
     }
 }
 
@@ -578,9 +580,9 @@ static void sqp_run_lane(Ctx &C, int max_outer)
     try {
         for (long sweep = 0; sweep < 100000000L; ++sweep) {
             ipm_sweep(C, /*sqp_level=*/true);
-            hipLaunchKernelGGL(k_sqp_count, dim3(1), dim3(64), 0, s, d);
-            SQPHIP_HIP_OK(hipMemcpyAsync(C.h_counters + 2 + 2 * (sweep & 1), d.counters + 2, 2 * sizeof(int),
-                                         hipMemcpyDeviceToHost, s));
+            int *slot = nullptr;                 // device view of the pinned words this sweep reports into
+            SQPHIP_HIP_OK(hipHostGetDevicePointer((void **)&slot, C.h_counters + 2 + 2 * (sweep & 1), 0));
+            hipLaunchKernelGGL(k_sqp_count, dim3(1), dim3(64), 0, s, d, slot);
             SQPHIP_HIP_OK(hipEventRecord(ev[sweep & 1], s));
             if (C.tm.pending_trailing.size() > 4096) C.tm.flush();
             if (lockstep) { if (left_after(sweep) == 0) break; continue; }
