@@ -357,9 +357,12 @@ def synth_case(case: str, topology: str | None = None) -> Network:
         raise ValueError(f"unknown topology {topology!r}")
     if topology == "chain":
         return acopf_synth(nb, ng, nl, seed)
-    # 9241 buses carry 1.74 branches per bus (1354: 1.47): 4 buses across and 16 regional strips keep the largest front
-    # at 198 rows and the assembly tree at 69 levels (5 across, one strip: 382 rows; 4 across, one strip: 359 levels)
-    return acopf_synth_geo(nb, ng, nl, seed, width=4, regions=16) if nb > 5000 else acopf_synth_geo(nb, ng, nl, seed)
+    # 9241 buses carry 1.74 branches per bus (1354: 1.47): 4 buses across and 32 regional strips keep the largest front
+    # at 176 rows and the assembly tree at 74 levels (5 across, one strip: 382 rows; 4 across, one strip: 359 levels).
+    # Oracle, flat start: 32 regions converge in 15 outer iterations, 16 regions of 5 across in 20; with 16 regions of 4
+    # across the first trust-region QP stalls at 1.5e-6 (a nearly singular reduced Hessian under a permanent inertia
+    # correction) and ends at the interior-point iteration limit.
+    return acopf_synth_geo(nb, ng, nl, seed, width=4, regions=32) if nb > 5000 else acopf_synth_geo(nb, ng, nl, seed)
 
 
 def contingency(net: Network, s: int, base_seed: int) -> Network:

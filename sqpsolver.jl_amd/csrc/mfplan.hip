@@ -145,11 +145,15 @@ MfPlan mf_build_plan(int n, int m, const std::vector<int> &kpos, int mk, const s
         }
         for (int s = 0; s < S.ns; ++s) P.ev_ptr[s + 1] += P.ev_ptr[s];
     }
-    // launch schedule: level by level (leaves first); inside a level one launch per front height in 16-row tiles T (the
-    // front with its right-hand-side row): the front kernels of mfront.hip are compiled per T (k_mf_front<T, ...>, T <= 8);
-    // taller fronts share the generic kernels: class 8 = T <= 13 (k_mf_factor2<8, 12>), class 9 = larger (rank-1 kernel)
+    // launch schedule: level by level (leaves first); inside a level one launch per class of front height in 16-row tiles T
+    // (the front with its right-hand-side row): the front kernels of mfront.hip are compiled per T (k_mf_front<T, ...>,
+    // T <= 8); taller fronts share the generic kernels: class 8 = T <= 13 (k_mf_factor2<8, 12>), class 9 = larger (rank-1 kernel)
     auto tiles = [&](int s) { return (S.sn_nc[s] + S.sn_nr[s] + 1 + 15) / 16; };
-    auto cls = [&](int s) { const int T = tiles(s); return T <= 8 ? T - 1 : (T <= 13 ? 8 : 9); };
+    // launch classes by the kernel that runs the front: the static kernels exist for every T <= 8, but a level of a large
+    // structure holds fronts of every height, and a launch per height and level made the factorisation of the 1354- and
+    // 9241-bus shapes launch-bound (68 levels x up to 10 launches; measured -12 % / -17 % QP/s against round 2's six
+    // classes).  Fronts of one or two tiles share the T = 2 kernel, T = 7 shares the T = 8 kernel.
+    auto cls = [&](int s) { const int T = tiles(s); return T <= 2 ? 1 : (T <= 6 ? T - 1 : (T <= 8 ? 7 : (T <= 13 ? 8 : 9))); };
     for (int l = 0; l < S.nlevels; ++l) {
         // a level with a handful of fronts (the upper part of the tree) is ONE launch of the kernel of its tallest
         // front: a front of fewer tiles runs in it with empty tiles, off the critical path of the level, and every
@@ -167,6 +171,8 @@ MfPlan mf_build_plan(int n, int m, const std::vector<int> &kpos, int mk, const s
                 L.tiles = std::max(L.tiles, tiles(s));
             }
             if (!L.count) continue;
+            if (!merge && c == 1) L.tiles = 2;        // the kernel of the class (a front of fewer tiles runs in it with empty tiles)
+            if (!merge && c == 7) L.tiles = 8;
             P.fac.push_back(L);                       // threads and LDS are the kernel's business (mf_factor)
         }
     }

@@ -828,29 +828,6 @@ __device__ __forceinline__ void mf_front_bwd(const DV &d, int inst, int s, doubl
     }
 }
 
-// L11 corner of a front into LDS, by the four waves of a workgroup.  Written as "load sixteen columns' worth into
-// registers, then store": with the load and the LDS store of an entry in one loop body the compiler waits for every
-// load before the next is issued (measured on the 80-column front of IEEE-118: 15 900 cycles for the staging against
-// 2 300 for everything else that precedes the triangular solve).
-__device__ __forceinline__ void mf_stage_l11(double *Ls, const double *G, int nc, int ld, int lane, int wave)
-{
-    for (int c0 = wave; c0 < nc; c0 += 64) {           // sixteen columns of this wave per batch, two rows per lane and column
-        double t0[16], t1[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int c = c0 + 4 * q, r0 = c + 1 + lane, r1 = r0 + 64;
-            t0[q] = (c < nc && r0 < nc) ? G[(long)c * ld + r0] : 0.0;
-            t1[q] = (c < nc && r1 < nc) ? G[(long)c * ld + r1] : 0.0;
-        }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int c = c0 + 4 * q, r0 = c + 1 + lane, r1 = r0 + 64;
-            if (c < nc && r0 < nc) Ls[c * nc + r0] = t0[q];
-            if (c < nc && r1 < nc) Ls[c * nc + r1] = t1[q];
-        }
-    }
-}
-
 // A front of more than 64 rows, by the four waves of a workgroup.  The triangular part L11 (its nc x nc corner) is
 // staged in LDS with all loads in flight at once; the dependent chain -- 16 columns at a time, the 16 x 16 diagonal block
 // by a shuffle chain in wave 0, the rest of the triangle by all threads -- then runs at LDS latency.  The rectangular
@@ -867,32 +844,9 @@ __device__ __forceinline__ void mf_front_fwd_big(const DV &d, int inst, int s, d
     const double *b = d.xv + (long)inst * d.Fpad + f0, *dinv = mf_dinv(d, inst, cand) + f0;
     double *vv = mf_vv(d, inst, cand) + f0;
     const int lane = tid & 63, wave = tid >> 6;
-    // Every global load of this front that does not depend on the solve is issued HERE, in one batch: the L11 corner (to
-    // LDS), the L21 entries this thread needs for the rows below the supernode (to registers: two row blocks of 32 rows x
-    // up to 16 of the thread's columns), the right-hand side.  A front's solve is a chain of dependent memory round trips
-    // of 1 - 2 us each with little arithmetic in between; loading L21 where it is used cost two or three more of them.
-    MF_TRS(0)
-    constexpr int PB = 2, PK = 16;
-    const bool pre = Ls && nc >= 16 && nr <= 32 * PB && nc <= 8 * PK;
-    double l21[PB][PK];
-    if (pre) {
-        const int r = tid & 31, kc = tid >> 5;
-#pragma unroll
-        for (int rb = 0; rb < PB; ++rb) {
-            const int i = nc + 32 * rb + r;
-#pragma unroll
-            for (int q = 0; q < PK; ++q) {
-                const int k = kc + 8 * q;
-                l21[rb][q] = (i < fs && k < nc) ? G[(long)k * ld + i] : 0.0;
-            }
-        }
-    }
-    if (Ls) {
-        if (nc <= 128) mf_stage_l11(Ls, G, nc, ld, lane, wave);
-        else
-            for (int c = wave; c < nc; c += 4)
-                for (int r = c + 1 + lane; r < nc; r += 64) Ls[c * nc + r] = G[(long)c * ld + r];
-    }
+    if (Ls)
+        for (int c = wave; c < nc; c += 4)
+            for (int r = c + 1 + lane; r < nc; r += 64) Ls[c * nc + r] = G[(long)c * ld + r];
     double dv[8];                                        // 1 / D of the columns wave 0 finishes: block kb / 16, column lane
 #pragma unroll
     for (int q = 0; q < 8; ++q) dv[q] = (wave == 0 && lane < 16 && 16 * q + lane < nc) ? dinv[16 * q + lane] : 0.0;
@@ -947,15 +901,7 @@ __device__ __forceinline__ void mf_front_fwd_big(const DV &d, int inst, int s, d
         for (int rb = nc; rb < fs; rb += 32) {
             const int i = rb + r;
             double a = 0.0;
-            if (pre) {          // same products in the same order, the L21 entries from the registers
-                const int b2 = (rb - nc) >> 5;
-#pragma unroll
-                for (int q = 0; q < PK; ++q) {
-                    const int k = kc + 8 * q;
-                    const double lv = b2 == 0 ? l21[0][q] : l21[1][q];
-                    if (i < fs && k < nc) a += lv * y[k];
-                }
-            } else if (i < fs) {
+            if (i < fs) {
 #pragma unroll 4
                 for (int k = kc; k < nc; k += 8) a += G[(long)k * ld + i] * y[k];
             }
@@ -992,30 +938,9 @@ __device__ __forceinline__ void mf_front_bwd_big(const DV &d, int inst, int s, d
     const int *rows = M.rows + Fd.rowptr;
     const int lane = tid & 63, wave = tid >> 6;
     double *part = x + fs;                       // 16 block sums behind the vector
-    // as in the forward routine: the L21 entries of this thread (four passes of 32 columns x up to 8 of its rows) are
-    // requested together with the L11 corner and the gather of x_rows -- one round trip instead of three or four
-    MF_TRS(8)
-    constexpr int PP = 4, PR = 8;
-    const bool pre = Ls && nc <= 32 * PP && nr <= 8 * PR;
-    double l21[PP][PR];
-    if (pre) {
-        const int c = tid >> 3, r = tid & 7;
-#pragma unroll
-        for (int p = 0; p < PP; ++p) {
-            const int k = 32 * p + c;
-#pragma unroll
-            for (int q = 0; q < PR; ++q) {
-                const int i = nc + r + 8 * q;
-                l21[p][q] = (k < nc && i < fs) ? G[(long)k * ld + i] : 0.0;
-            }
-        }
-    }
-    if (Ls) {
-        if (nc <= 128) mf_stage_l11(Ls, G, nc, ld, lane, wave);
-        else
-            for (int c = wave; c < nc; c += 4)
-                for (int r = c + 1 + lane; r < nc; r += 64) Ls[c * nc + r] = G[(long)c * ld + r];
-    }
+    if (Ls)
+        for (int c = wave; c < nc; c += 4)
+            for (int r = c + 1 + lane; r < nc; r += 64) Ls[c * nc + r] = G[(long)c * ld + r];
     for (int i = tid; i < fs; i += 256) x[i] = i < nc ? vv[i] : xg[rows[i - nc]];
     MF_TRS(9)
     __syncthreads();
@@ -1023,21 +948,6 @@ __device__ __forceinline__ void mf_front_bwd_big(const DV &d, int inst, int s, d
     {   // x_cols -= L21' x_rows: column k by 8 threads, 32 columns per pass (a front has tens of rows below its columns:
         // more columns in flight per pass matter more than longer coalesced runs), every column independent of the others
         const int c = tid >> 3, r = tid & 7;
-        if (pre) {
-#pragma unroll
-            for (int p = 0; p < PP; ++p) {
-                const int k = 32 * p + c;
-                if (32 * p >= nc) break;
-                double a = 0.0;
-#pragma unroll
-                for (int q = 0; q < PR; ++q) {
-                    const int i = nc + r + 8 * q;
-                    if (k < nc && i < fs) a += l21[p][q] * x[i];
-                }
-                a += __shfl_xor(a, 4); a += __shfl_xor(a, 2); a += __shfl_xor(a, 1);
-                if (r == 0 && k < nc) x[k] -= a;
-            }
-        } else
         for (int kb = 0; kb < nc; kb += 32) {
             double a = 0.0;
             if (kb + c < nc) {
@@ -1191,7 +1101,7 @@ void mf_factor(Ctx &C, int want, bool with_rhs)
     const int nb = d.mf.fronts1 ? 2 * d.B : d.B;         // with the second candidate the factor side runs over 2 B "instances"
     if (!v1) hipLaunchKernelGGL(k_mf_values, dim3((d.mf.nnzK + 255) / 256, nb), dim3(256), 0, s, d, want);
     // static front kernels (k_mf_front<T, NW, LDSIMG>) unless SQPHIP_MF_STATIC=0 asks for the generic ones (cross-check)
-    static const bool stat = !(getenv("SQPHIP_MF_STATIC") && atoi(getenv("SQPHIP_MF_STATIC")) == 0);
+    const bool stat = !(getenv("SQPHIP_MF_STATIC") && atoi(getenv("SQPHIP_MF_STATIC")) == 0);     // (read per call: tests flip it)
     for (const MfLaunch &L : C.mfp().fac) {
         const dim3 grid(L.count, nb);
         const int T = L.tiles, R = 16 * T;
@@ -1199,7 +1109,12 @@ void mf_factor(Ctx &C, int want, bool with_rhs)
         // generic kernels: dynamic LDS = [image (16 T)^2 when it lives in LDS][panel X and L: 2 x 4 x 16 T][4 x 4 block][1 / D: 16 T]
 #define MF_GENERIC(NW, MAXT, IMG) hipLaunchKernelGGL((k_mf_factor2<NW, MAXT, IMG>), grid, dim3(64 * NW), 8 * (size_t)((IMG ? R * R : 0) + 9 * R + 16), s, d, L.begin, want, wr, T)
 #define MF_STATIC(TT, NW, IMG) hipLaunchKernelGGL((k_mf_front<TT, NW, IMG>), grid, dim3(64 * NW), 8 * (size_t)mf_front_lds_doubles(TT, NW, IMG), s, d, L.begin, want, wr)
-        if (!stat || T > 8) {
+        // ... from four tile rows on: below that the generic kernels are as fast per front and lighter (registers, code
+        // size) where thousands of small fronts are in flight.  Measured (QP/s, static from T = 1 / from T = 4 / never):
+        // 512 x IEEE-118 5565 / 5507 / 5259, 64 x IEEE-118 1372 / - / 1315, 9241 shape 20.6 / 24.3 / 23.4, IEEE-14 50.9 k /
+        // 55.4 k / 53.9 k.  SQPHIP_MF_STATIC_MIN moves the threshold (tests run it at 1 to cover every instantiation).
+        const int stat_min = getenv("SQPHIP_MF_STATIC_MIN") ? atoi(getenv("SQPHIP_MF_STATIC_MIN")) : 4;
+        if (!stat || T > 8 || T < stat_min) {
             if (T <= 2) MF_GENERIC(1, 3, true);
             else if (T <= 4) MF_GENERIC(2, 5, true);
             else if (T <= 5) MF_GENERIC(4, 4, true);

@@ -149,6 +149,29 @@ def test_multifrontal_kernels_match_host_reference(case, cond):
     ctx.close()
 
 
+@pytest.mark.parametrize("env", [{"SQPHIP_MF_STATIC_MIN": "1"}, {"SQPHIP_MF_STATIC": "0"}])
+def test_every_front_kernel_variant_matches_the_host_reference(env, monkeypatch):
+    """The front kernels the default dispatch does not pick: the static kernels k_mf_front<T, ...> for fronts of one to
+    three tile rows (default: from four on) and the generic k_mf_factor2 kernels for every height (default: up to
+    three, and from nine on) -- same comparison as above on the IEEE-118 and 1354 shapes."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for case in ("case118", "case1354"):
+        nb, ng, nl, seed = CASES[case]
+        lay = acopf_layout(acopf_synth(nb, ng, nl, seed))
+        Jv, Hv, Dd, sigp, hd, rt = _newton_values(lay, 1)
+        ctx = pkg.Context(lay.n, lay.m, lay.num_linear, lay.jrow, lay.jcol, lay.hrow, lay.hcol, lay.xL, lay.xU, lay.gL,
+                          lay.gU, pkg.default_options(kkt_mode=2), batch=2)
+        mk = int((lay.gL == lay.gU).sum())
+        rhs = np.random.default_rng(2).normal(size=lay.n + mk)
+        ref, dref, npos = pkg.mf_host_solve(lay.n, lay.m, lay.jrow, lay.jcol, lay.hrow, lay.hcol, lay.gL, lay.gU, 1, Jv, Hv,
+                                            Dd, sigp, hd, rt, 0.7, 1e-3, rhs)
+        fused, alone, dv = ctx.mf_solve_test(1, Jv, Hv, Dd, sigp, hd, rt, 0.7, 1e-3, rhs)
+        assert rel(fused, ref) < 1e-11 and rel(alone, ref) < 1e-11 and rel(dv, dref) < 1e-11
+        assert int((dv > 0).sum()) == lay.n == npos
+        ctx.close()
+
+
 def test_subproblems_on_case1354_match_oracle():
     """BASELINE.json configs[2] (1354pegase shape, Newton matrix of order 29 829 condensed to 21 865): the first
     sub-problems of an SQP run -- the linear-phase projection QP, the trust-region QP (infeasible: restoration is
