@@ -75,3 +75,13 @@ if L.sqphip_mf_trace3_read(buf3.ctypes.data_as(C.POINTER(C.c_longlong)), ns) == 
         f = [t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4]] if t[0] else [0] * 5
         b = [t[9] - t[8], t[10] - t[9], t[11] - t[10], t[12] - t[11]]
         print(f"  front {srow:4d}: fwd " + " ".join(f"{int(v):6d}" for v in f) + "   bwd " + " ".join(f"{int(v):6d}" for v in b))
+
+# vector stages of the last sweeps (instance 0, thread 0), shader cycles
+vt = np.zeros(64, dtype=np.int64)
+L.sqphip_vec_trace_read.argtypes = [C.POINTER(C.c_longlong)]
+if L.sqphip_vec_trace_read(vt.ctypes.data_as(C.POINTER(C.c_longlong))) == 0:
+    def seg(a, b): return int(vt[b] - vt[a]) if vt[a] and vt[b] else -1
+    print("k_ipm_tail: refine accumulate", seg(0, 1), "| H sol, J sol", seg(1, 2), "| residual + reduce", seg(2, 3), "| next rhs", seg(3, 4))
+    print("            step: (gap)", seg(4, 8), "expand", seg(8, 9), "| 2 reductions", seg(9, 10), "| update", seg(10, 11))
+    print("            prepare: (gap)", seg(11, 16), "stage", seg(16, 17), "| H p", seg(17, 18), "| J p + barrier", seg(18, 19), "| residual loops", seg(19, 20), "| 6 reductions", seg(20, 21), "| rest", seg(21, 22))
+    print("k_ipm_mid:  refine accumulate", seg(32, 33), "| H sol, J sol", seg(33, 34), "| residual + reduce", seg(34, 35), "| next rhs", seg(35, 36))

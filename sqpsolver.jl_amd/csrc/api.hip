@@ -344,6 +344,7 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
         d.trace = C.dalloc<double>((size_t)B * SQPHIP_TRACE_CAP * SQPHIP_TRACE_COLS);
         d.ipm_tol = opt->ipm_tol; d.ipm_max_iter = opt->ipm_max_iter; d.ipm_phase1 = opt->ipm_phase1; d.ipm_corrector = opt->ipm_corrector; d.ipm_warm = opt->ipm_warm_start;
         d.refine_tol = getenv("SQPHIP_REFINE_TOL") ? atof(getenv("SQPHIP_REFINE_TOL")) : 1e-11;
+        d.vstage = (d.n + d.N <= 7000 && !getenv("SQPHIP_NO_VSTAGE")) ? d.n + d.N : 0;      // up to 56 KB of LDS per workgroup
         d.tol_direction = opt->tol_direction; d.tol_residual = opt->tol_residual;
         d.tol_infeas = opt->tol_infeas; d.init_mu = opt->init_mu; d.tr_size = opt->tr_size;
         d.max_iter = opt->max_iter; d.use_soc = opt->use_soc; d.literal_quirks = opt->literal_quirks;

@@ -131,6 +131,7 @@ struct DV {
     double ipm_tol;
     int ipm_max_iter, ipm_phase1, ipm_corrector, ipm_warm;
     double refine_tol;                    // refinement step when the relative residual is above this (condensed form)
+    int vstage;                           // doubles of dynamic LDS of the vector stages (n + N; 0: the vectors do not fit, ipm.hip)
     // ---- SQP level
     double *x, *lambda, *mxL, *mxU, *df, *E, *pstep, *psoc, *plam, *pmxL, *pmxU, *Esoc, *tmpx, *tmpE,
         *hlam;

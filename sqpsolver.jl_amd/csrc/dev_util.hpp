@@ -37,6 +37,45 @@ template <class Op> static __device__ __forceinline__ double block_reduce(double
     return r;
 }
 
+// several reductions behind ONE pair of barriers (a block_reduce costs two workgroup barriers, ~2 300 cycles each way
+// with sixteen waves behind global stores: six in a row were 14 000 cycles of the prepare stage).  Same operations on
+// the same operands in the same order as the single reductions: the results are bit-identical.
+template <class O0, class O1, class O2, class O3, class O4, class O5>
+static __device__ __forceinline__ void block_reduce6(double &v0, double &v1, double &v2, double &v3, double &v4, double &v5)
+{
+    __shared__ double sh6[6][TPB / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        v0 = O0::f(v0, __shfl_xor(v0, o)); v1 = O1::f(v1, __shfl_xor(v1, o)); v2 = O2::f(v2, __shfl_xor(v2, o));
+        v3 = O3::f(v3, __shfl_xor(v3, o)); v4 = O4::f(v4, __shfl_xor(v4, o)); v5 = O5::f(v5, __shfl_xor(v5, o));
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        sh6[0][w] = v0; sh6[1][w] = v1; sh6[2][w] = v2; sh6[3][w] = v3; sh6[4][w] = v4; sh6[5][w] = v5;
+    }
+    __syncthreads();
+    v0 = sh6[0][0]; v1 = sh6[1][0]; v2 = sh6[2][0]; v3 = sh6[3][0]; v4 = sh6[4][0]; v5 = sh6[5][0];
+#pragma unroll
+    for (int w = 1; w < TPB / 64; ++w) {
+        v0 = O0::f(v0, sh6[0][w]); v1 = O1::f(v1, sh6[1][w]); v2 = O2::f(v2, sh6[2][w]);
+        v3 = O3::f(v3, sh6[3][w]); v4 = O4::f(v4, sh6[4][w]); v5 = O5::f(v5, sh6[5][w]);
+    }
+}
+template <class O0, class O1>
+static __device__ __forceinline__ void block_reduce2(double &v0, double &v1)
+{
+    __shared__ double sh2[2][TPB / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { v0 = O0::f(v0, __shfl_xor(v0, o)); v1 = O1::f(v1, __shfl_xor(v1, o)); }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sh2[0][threadIdx.x >> 6] = v0; sh2[1][threadIdx.x >> 6] = v1; }
+    __syncthreads();
+    v0 = sh2[0][0]; v1 = sh2[1][0];
+#pragma unroll
+    for (int w = 1; w < TPB / 64; ++w) { v0 = O0::f(v0, sh2[0][w]); v1 = O1::f(v1, sh2[1][w]); }
+}
+
 static __device__ __forceinline__ bool fin(double v) { return isfinite(v); }
 
 // Inertia correction: the shift tried after `dw` has given the wrong inertia (Ipopt's schedule; dw_last = last shift

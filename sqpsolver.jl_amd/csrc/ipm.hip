@@ -21,6 +21,22 @@
 
 namespace sqphip {
 
+// Gathered vectors in LDS (round 3).  The sparse products of the vector stages -- H v, J v, J' w, the expansion of the
+// eliminated rows -- walk index -> value chains through global memory: two or three dependent round trips per entry of
+// the longest row or column (a bus with ten branches), with one workgroup per instance and one per CU nothing hides
+// them.  Where the vectors of an instance fit (DV::vstage doubles of dynamic LDS: n + N), the vector being gathered FROM
+// is staged in LDS first -- one coalesced round trip -- and the chain ends in an LDS read.  Same arithmetic, same order.
+extern __shared__ double ipm_lds[];
+
+// shader-clock stamps inside the vector stages (instance 0, thread 0; scripts/gpu_mf_trace.py builds with -DSQPHIP_MF_TRACE)
+#ifdef SQPHIP_MF_TRACE
+__device__ long long g_vec_trace[64];
+#define VTR(i) if (blockIdx.x == 0 && threadIdx.x == 0) g_vec_trace[i] = (long long)clock64();
+extern "C" int sqphip_vec_trace_read(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vec_trace), sizeof(long long) * 64); }
+#else
+#define VTR(i)
+#endif
+
 #define RHO_BIG0 1e4
 #define RHO_BIG_MAX 1e10
 #define ELASTIC_TOL 1e-8
@@ -35,8 +51,11 @@ __device__ void hess_mul(const DV &d, int inst, double hsc, const double *v, dou
     const double *hv = d.hv + (long)inst * d.nnzhc, *hd = d.hd + (long)inst * d.n;
     for (int j = threadIdx.x; j < d.n; j += TPB) {
         double acc = 0.0;
-        for (int k = d.hcolptr[j]; k < d.hcolptr[j + 1]; ++k) acc += hv[k] * v[d.hrowval[k]];
-        out[j] = hsc * acc + hd[j] * v[j];
+        const int k0 = d.hcolptr[j], k1 = d.hcolptr[j + 1];
+        const double hdj = hd[j], vj = v[j];
+#pragma unroll 4
+        for (int k = k0; k < k1; ++k) acc += hv[k] * v[d.hrowval[k]];
+        out[j] = hsc * acc + hdj * vj;
     }
 }
 // out_i = J_i v over active rows (CSR view)
@@ -46,10 +65,23 @@ __device__ void jac_mul(const DV &d, int inst, const double *v, double *out)
     const int *rt = d.rtype + (long)inst * d.m;
     for (int i = threadIdx.x; i < d.m; i += TPB) {
         double acc = 0.0;
-        if (rt[i] != ROW_FREE)
-            for (int k = d.jrowptr[i]; k < d.jrowptr[i + 1]; ++k) acc += jv[d.jrslot[k]] * v[d.jrcol[k]];
+        const int k0 = d.jrowptr[i], k1 = d.jrowptr[i + 1];
+        if (rt[i] != ROW_FREE) {
+#pragma unroll 4
+            for (int k = k0; k < k1; ++k) acc += jv[d.jrslot[k]] * v[d.jrcol[k]];
+        }
         out[i] = acc;
     }
+}
+// (J' w)_j, w from an LDS copy in which the entries of free rows are zero: no row-type gather (the product of a free row
+// is then + 0.0 instead of being skipped -- the same sum)
+__device__ __forceinline__ double jact_col_masked(const DV &d, const double *jv, const double *w, int j)
+{
+    double acc = 0.0;
+    const int k0 = d.jcolptr[j], k1 = d.jcolptr[j + 1];
+#pragma unroll 4
+    for (int k = k0; k < k1; ++k) acc += jv[k] * w[d.jrowval[k]];
+    return acc;
 }
 // (J' w)_j over active rows
 __device__ __forceinline__ double jact_col(const DV &d, const double *jv, const int *rt, const double *w, int j)
@@ -260,39 +292,56 @@ static __device__ void b_ipm_prepare(const DV &d)
     }
     const double hsc = st.hsc;
     const int n_acc_prev = st.n_acc, n_acc2_prev = st.n_acc2;   // read here: thread 0 updates them below, after the reductions' barriers
-    hess_mul(d, inst, hsc, p, rd);
-    jac_mul(d, inst, p, rp);
+    VTR(16)
+    const double *pv = p, *yv = y;
+    if (d.vstage) {                                  // p and y are gathered from below: LDS copies
+        double *sp = ipm_lds, *sy = ipm_lds + d.n;
+        for (int j = threadIdx.x; j < d.n; j += TPB) sp[j] = p[j];
+        for (int i = threadIdx.x; i < d.m; i += TPB) sy[i] = rt[i] != ROW_FREE ? y[i] : 0.0;      // (masked: jact_col_masked)
+        __syncthreads();
+        pv = sp; yv = sy;
+    }
+    VTR(17)
+    hess_mul(d, inst, hsc, pv, rd);
+    VTR(18)
+    jac_mul(d, inst, pv, rp);
     __syncthreads();
+    VTR(19)
     double csum = 0, cmax = 0, rdn = 0, rpn = 0, dl1 = 0, nc = 0;
+    // (loop bodies: every operand is loaded before the first test on one of them -- a load behind a branch on another
+    //  load is a second memory round trip, and these loops are round trips and little else)
     for (int j = threadIdx.x; j < d.n; j += TPB) {
-        double r = rd[j] + c[j] - jact_col(d, jv, rt, y, j);
-        const double g_l = p[j] - lb[j], g_u = ub[j] - p[j];
+        const double rdj = rd[j], cj = c[j], pj = p[j], lbj = lb[j], ubj = ub[j], zlj = zl[j], zuj = zu[j];
+        double r = rdj + cj - (d.vstage ? jact_col_masked(d, jv, yv, j) : jact_col(d, jv, rt, yv, j));
+        const double g_l = pj - lbj, g_u = ubj - pj;
         double sg = 0.0;
-        if (fin(lb[j])) { r -= zl[j]; const double cc = zl[j] * g_l; csum += cc; cmax = fmax(cmax, cc); nc += 1; dl1 += zl[j]; sg += zl[j] / g_l; }
-        if (fin(ub[j])) { r += zu[j]; const double cc = zu[j] * g_u; csum += cc; cmax = fmax(cmax, cc); nc += 1; dl1 += zu[j]; sg += zu[j] / g_u; }
+        if (fin(lbj)) { r -= zlj; const double cc = zlj * g_l; csum += cc; cmax = fmax(cmax, cc); nc += 1; dl1 += zlj; sg += zlj / g_l; }
+        if (fin(ubj)) { r += zuj; const double cc = zuj * g_u; csum += cc; cmax = fmax(cmax, cc); nc += 1; dl1 += zuj; sg += zuj / g_u; }
         rd[j] = r; sigp[j] = sg;
         rdn = fmax(rdn, fabs(r));
     }
     for (int i = threadIdx.x; i < d.m; i += TPB) {
-        if (rt[i] == ROW_FREE) { rp[i] = 0.0; Dd[i] = 1.0; continue; }
-        const double r = rp[i] + tp[i] - tm[i] - s[i];
+        const int rti = rt[i];
+        const double rpi = rp[i], tpi = tp[i], tmi = tm[i], si = s[i], zp = zpv[i], zm = zmv[i], yi = y[i], loi = lo[i], hii = hi[i],
+                     vli = vl[i], vui = vu[i];
+        if (rti == ROW_FREE) { rp[i] = 0.0; Dd[i] = 1.0; continue; }
+        const double r = rpi + tpi - tmi - si;
         rp[i] = r; rpn = fmax(rpn, fabs(r));
-        const double zp = zpv[i], zm = zmv[i];
-        double cc = zp * tp[i]; csum += cc; cmax = fmax(cmax, cc);
-        cc = zm * tm[i]; csum += cc; cmax = fmax(cmax, cc); nc += 2;
-        dl1 += fabs(y[i]);
-        double dd = tp[i] / zp + tm[i] / zm;
-        if (rt[i] == ROW_INEQ) {
+        double cc = zp * tpi; csum += cc; cmax = fmax(cmax, cc);
+        cc = zm * tmi; csum += cc; cmax = fmax(cmax, cc); nc += 2;
+        dl1 += fabs(yi);
+        double dd = tpi / zp + tmi / zm;
+        if (rti == ROW_INEQ) {
             double sig = 0.0;
-            if (fin(lo[i])) { const double al = s[i] - lo[i]; cc = vl[i] * al; csum += cc; cmax = fmax(cmax, cc); nc += 1; sig += vl[i] / al; }
-            if (fin(hi[i])) { const double au = hi[i] - s[i]; cc = vu[i] * au; csum += cc; cmax = fmax(cmax, cc); nc += 1; sig += vu[i] / au; }
+            if (fin(loi)) { const double al = si - loi; cc = vli * al; csum += cc; cmax = fmax(cmax, cc); nc += 1; sig += vli / al; }
+            if (fin(hii)) { const double au = hii - si; cc = vui * au; csum += cc; cmax = fmax(cmax, cc); nc += 1; sig += vui / au; }
             dd += 1.0 / sig;
         }
         Dd[i] = dd;
     }
-    csum = block_reduce<OpSum>(csum); cmax = block_reduce<OpMax>(cmax);
-    rdn = block_reduce<OpMax>(rdn); rpn = block_reduce<OpMax>(rpn);
-    dl1 = block_reduce<OpSum>(dl1); nc = block_reduce<OpSum>(nc);
+    VTR(20)
+    block_reduce6<OpSum, OpMax, OpMax, OpMax, OpSum, OpSum>(csum, cmax, rdn, rpn, dl1, nc);
+    VTR(21)
     const double cavg = nc > 0 ? csum / nc : 0.0;
     if (!fin(rdn) || !fin(cavg) || !fin(rpn)) {
         if (threadIdx.x == 0) { st.rc = 2; d.phase[inst] = PH_DONE; }
@@ -341,6 +390,7 @@ static __device__ void b_ipm_prepare(const DV &d)
         st.dw = keep; st.dw_floor = keep; st.fac_attempt = 0; st.dir_attempt = 0;
         d.phase[inst] = PH_FACTOR;
     }
+    VTR(22)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -458,21 +508,26 @@ __device__ double build_rhs(const DV &d, int inst, double tgt, bool soc)
     SOC_PTRS
     double rn = 0.0;
     for (int j = threadIdx.x; j < d.n; j += TPB) {
-        double g = -rd[j];
-        if (fin(lb[j])) { const double gl = p[j] - lb[j]; g += (tgt - SOCV(sZL, j) - zl[j] * gl) / gl; }
-        if (fin(ub[j])) { const double gu = ub[j] - p[j]; g -= (tgt - SOCV(sZU, j) - zu[j] * gu) / gu; }
+        const double rdj = rd[j], lbj = lb[j], ubj = ub[j], pj = p[j], zlj = zl[j], zuj = zu[j];
+        const double sl = SOCV(sZL, j), su = SOCV(sZU, j);
+        double g = -rdj;
+        if (fin(lbj)) { const double gl = pj - lbj; g += (tgt - sl - zlj * gl) / gl; }
+        if (fin(ubj)) { const double gu = ubj - pj; g -= (tgt - su - zuj * gu) / gu; }
         rhs[j] = g; rn = fmax(rn, fabs(g));
     }
     for (int i = threadIdx.x; i < d.m; i += TPB) {
+        const int rti = rt[i];
+        const double zp = zpv[i], zm = zmv[i], tpi = tp[i], tmi = tm[i], rpi = rp[i], si = s[i], loi = lo[i], hii = hi[i],
+                     vli = vl[i], vui = vu[i];
+        const double sp_ = SOCV(sZP, i), sm_ = SOCV(sZM, i), svl = SOCV(sVL, i), svu = SOCV(sVU, i);
         double b = 0.0;
-        if (rt[i] != ROW_FREE) {
-            const double zp = zpv[i], zm = zmv[i];
-            const double cp = tgt - SOCV(sZP, i) - zp * tp[i], cm = tgt - SOCV(sZM, i) - zm * tm[i];
-            b = -rp[i] - cp / zp + cm / zm;
-            if (rt[i] == ROW_INEQ) {
+        if (rti != ROW_FREE) {
+            const double cp = tgt - sp_ - zp * tpi, cm = tgt - sm_ - zm * tmi;
+            b = -rpi - cp / zp + cm / zm;
+            if (rti == ROW_INEQ) {
                 double sig = 0.0, t = 0.0;
-                if (fin(lo[i])) { const double al = s[i] - lo[i]; sig += vl[i] / al; t += (tgt - SOCV(sVL, i) - vl[i] * al) / al; }
-                if (fin(hi[i])) { const double au = hi[i] - s[i]; sig += vu[i] / au; t -= (tgt - SOCV(sVU, i) - vu[i] * au) / au; }
+                if (fin(loi)) { const double al = si - loi; sig += vli / al; t += (tgt - svl - vli * al) / al; }
+                if (fin(hii)) { const double au = hii - si; sig += vui / au; t -= (tgt - svu - vui * au) / au; }
                 b += t / sig;
             }
         }
@@ -548,47 +603,72 @@ static __device__ void b_refine(const DV &d, int last, int want)
     INST_PTRS
     double *xv = d.xv + (long)inst * d.Fpad;
     const int refine_it = st.refine_it;      // read before the first barrier, written by thread 0 at the end
+    VTR(want == PH_RESOLVE ? 0 : 32)
+    // LDS copies (d.vstage): xs = the solve's result in variable order, ss = the accumulated solution (both gathered from below)
+    double *xs = d.vstage ? ipm_lds : nullptr, *ss = d.vstage ? ipm_lds + d.n : nullptr;
     if (!d.condense) {
-        for (int i = threadIdx.x; i < d.N; i += TPB) sol[i] += xv[d.upos[i]];
+        for (int i = threadIdx.x; i < d.N; i += TPB) {
+            const double v = sol[i] + xv[d.upos[i]];
+            sol[i] = v;
+            if (ss) ss[i] = (i >= d.n && rt[i - d.n] == ROW_FREE) ? 0.0 : v;        // (rows masked: jact_col_masked)
+        }
     } else {
         // the right-hand side this solve answered: the Newton rhs, or the residual of the first pass
         const double *cur = refine_it == 0 ? rhs : wN;
-        for (int j = threadIdx.x; j < d.n; j += TPB) sol[j] += xv[d.upos[j]];
+        for (int j = threadIdx.x; j < d.n; j += TPB) {
+            const double xj = xv[d.upos[j]], v = sol[j] + xj;
+            sol[j] = v;
+            if (ss) { xs[j] = xj; ss[j] = v; }
+        }
+        if (xs) __syncthreads();
         for (int i = threadIdx.x; i < d.m; i += TPB) {
             double v;
             if (d.kpos[i] >= 0) v = xv[d.upos[d.n + d.kpos[i]]];
             else if (rt[i] == ROW_FREE) v = -cur[d.n + i];
             else {      // eliminated row: q_i = (J_i dp - b_i) / (D_i + reg)
                 double acc = 0.0;
-                for (int t = d.jrowptr[i]; t < d.jrowptr[i + 1]; ++t) acc += jv[d.jrslot[t]] * xv[d.upos[d.jrcol[t]]];
+                if (xs) for (int t = d.jrowptr[i]; t < d.jrowptr[i + 1]; ++t) acc += jv[d.jrslot[t]] * xs[d.jrcol[t]];
+                else for (int t = d.jrowptr[i]; t < d.jrowptr[i + 1]; ++t) acc += jv[d.jrslot[t]] * xv[d.upos[d.jrcol[t]]];
                 v = (acc - cur[d.n + i]) / (Dd[i] + IPM_REG_D);
             }
-            sol[d.n + i] += v;
+            const double w = sol[d.n + i] + v;
+            sol[d.n + i] = w;
+            if (ss) ss[d.n + i] = rt[i] != ROW_FREE ? w : 0.0;                       // (masked: jact_col_masked)
         }
     }
     __syncthreads();
+    VTR(want == PH_RESOLVE ? 1 : 33)
     const double hsc = st.hsc;
+    const double *sv = ss ? ss : sol;
     // res = rhs - K sol : top block (H + hd + sigp + dw) dp + J' q ; bottom J dp - D q
-    hess_mul(d, inst, hsc, sol, wn);
-    jac_mul(d, inst, sol, wN + d.n);
+    hess_mul(d, inst, hsc, sv, wn);
+    jac_mul(d, inst, sv, wN + d.n);
     __syncthreads();
+    VTR(want == PH_RESOLVE ? 2 : 34)
     double en = 0.0;
+    const double dwv = st.dw;
     for (int j = threadIdx.x; j < d.n; j += TPB) {
-        const double kx = wn[j] + (sigp[j] + st.dw + IPM_REG_P) * sol[j] + jact_col(d, jv, rt, sol + d.n, j);
-        const double r = rhs[j] - kx;
+        const double wnj = wn[j], sgj = sigp[j], rhj = rhs[j], svj = sv[j];
+        const double kx = wnj + (sgj + dwv + IPM_REG_P) * svj +
+                          (ss ? jact_col_masked(d, jv, sv + d.n, j) : jact_col(d, jv, rt, sv + d.n, j));
+        const double r = rhj - kx;
         wN[j] = r; en = fmax(en, fabs(r));
     }
     for (int i = threadIdx.x; i < d.m; i += TPB) {
-        const double dd = rt[i] == ROW_FREE ? 1.0 : Dd[i] + IPM_REG_D;
-        const double r = rhs[d.n + i] - (wN[d.n + i] - dd * sol[d.n + i]);
+        const int rti = rt[i];
+        const double Ddi = Dd[i], rhi = rhs[d.n + i], wi = wN[d.n + i], soli = sol[d.n + i];
+        const double dd = rti == ROW_FREE ? 1.0 : Ddi + IPM_REG_D;
+        const double r = rhi - (wi - dd * soli);
         wN[d.n + i] = r; en = fmax(en, fabs(r));
     }
     en = block_reduce<OpMax>(en);            // (its barriers publish wN)
+    VTR(want == PH_RESOLVE ? 3 : 35)
     // no refinement for a predictor (affine-scaling) direction: it only feeds Mehrotra's centring parameter and the
     // second-order terms, the direction that is actually taken -- the corrector -- is refined (oracle: ipm_direction)
     const bool predictor = want == PH_SOLVE && st.mpc;
     const bool stop = last || predictor || refine_it >= 1 || !(en > d.refine_tol * st.rn);
     if (!stop) load_solve_vector(d, inst, wN, xv);
+    VTR(want == PH_RESOLVE ? 4 : 36)
     if (threadIdx.x == 0) {
         st.n_solve++;
         st.relres = en / st.rn;
@@ -612,30 +692,34 @@ __device__ void expand_directions(const DV &d, int inst, double tgt, bool soc, d
     INST_PTRS
     SOC_PTRS
     for (int j = threadIdx.x; j < d.n; j += TPB) {
-        const double dpj = sol[j];
+        const double dpj = sol[j], lbj = lb[j], ubj = ub[j], pj = p[j], zlj = zl[j], zuj = zu[j];
+        const double sl = SOCV(sZL, j), su = SOCV(sZU, j);
         dp[j] = dpj;
         double a = 0.0, b = 0.0;
-        if (fin(lb[j])) { const double gl = p[j] - lb[j]; a = (tgt - SOCV(sZL, j) - zl[j] * gl - zl[j] * dpj) / gl; ap = ratio(gl, dpj, ap); ad = ratio(zl[j], a, ad); }
-        if (fin(ub[j])) { const double gu = ub[j] - p[j]; b = (tgt - SOCV(sZU, j) - zu[j] * gu + zu[j] * dpj) / gu; ap = ratio(gu, -dpj, ap); ad = ratio(zu[j], b, ad); }
+        if (fin(lbj)) { const double gl = pj - lbj; a = (tgt - sl - zlj * gl - zlj * dpj) / gl; ap = ratio(gl, dpj, ap); ad = ratio(zlj, a, ad); }
+        if (fin(ubj)) { const double gu = ubj - pj; b = (tgt - su - zuj * gu + zuj * dpj) / gu; ap = ratio(gu, -dpj, ap); ad = ratio(zuj, b, ad); }
         dzl[j] = a; dzu[j] = b;
     }
     for (int i = threadIdx.x; i < d.m; i += TPB) {
         double dyi = 0, dsi = 0, dtpi = 0, dtmi = 0, dvli = 0, dvui = 0;
-        if (rt[i] != ROW_FREE) {
-            dyi = -sol[d.n + i];
-            const double zp = zpv[i], zm = zmv[i];
-            dtpi = (tgt - SOCV(sZP, i) - zp * tp[i] + tp[i] * dyi) / zp;
-            dtmi = (tgt - SOCV(sZM, i) - zm * tm[i] - tm[i] * dyi) / zm;
-            ap = ratio(tp[i], dtpi, ap); ap = ratio(tm[i], dtmi, ap);
+        const int rti = rt[i];
+        const double soli = sol[d.n + i], zp = zpv[i], zm = zmv[i], tpi = tp[i], tmi = tm[i], si = s[i], loi = lo[i], hii = hi[i],
+                     vli = vl[i], vui = vu[i];
+        const double sp_ = SOCV(sZP, i), sm_ = SOCV(sZM, i), svl = SOCV(sVL, i), svu = SOCV(sVU, i);
+        if (rti != ROW_FREE) {
+            dyi = -soli;
+            dtpi = (tgt - sp_ - zp * tpi + tpi * dyi) / zp;
+            dtmi = (tgt - sm_ - zm * tmi - tmi * dyi) / zm;
+            ap = ratio(tpi, dtpi, ap); ap = ratio(tmi, dtmi, ap);
             ad = ratio(zp, -dyi, ad); ad = ratio(zm, dyi, ad);
-            if (rt[i] == ROW_INEQ) {
+            if (rti == ROW_INEQ) {
                 double sig = 0, t = 0, al = 0, au = 0, cl = 0, cu = 0;
-                const bool hl = fin(lo[i]), hu = fin(hi[i]);
-                if (hl) { al = s[i] - lo[i]; cl = tgt - SOCV(sVL, i) - vl[i] * al; sig += vl[i] / al; t += cl / al; }
-                if (hu) { au = hi[i] - s[i]; cu = tgt - SOCV(sVU, i) - vu[i] * au; sig += vu[i] / au; t -= cu / au; }
+                const bool hl = fin(loi), hu = fin(hii);
+                if (hl) { al = si - loi; cl = tgt - svl - vli * al; sig += vli / al; t += cl / al; }
+                if (hu) { au = hii - si; cu = tgt - svu - vui * au; sig += vui / au; t -= cu / au; }
                 dsi = (t - dyi) / sig;
-                if (hl) { dvli = (cl - vl[i] * dsi) / al; ap = ratio(al, dsi, ap); ad = ratio(vl[i], dvli, ad); }
-                if (hu) { dvui = (cu + vu[i] * dsi) / au; ap = ratio(au, -dsi, ap); ad = ratio(vu[i], dvui, ad); }
+                if (hl) { dvli = (cl - vli * dsi) / al; ap = ratio(al, dsi, ap); ad = ratio(vli, dvli, ad); }
+                if (hu) { dvui = (cu + vui * dsi) / au; ap = ratio(au, -dsi, ap); ad = ratio(vui, dvui, ad); }
             }
         }
         dy[i] = dyi; ds[i] = dsi; dtp[i] = dtpi; dtm[i] = dtmi; dvl[i] = dvli; dvu[i] = dvui;
@@ -660,7 +744,7 @@ static __device__ void b_mpc(const DV &d)
     if (corr) {
         double ap = 1e300, ad = 1e300;
         expand_directions(d, inst, 0.0, false, ap, ad);
-        ap = block_reduce<OpMin>(ap); ad = block_reduce<OpMin>(ad);
+        block_reduce2<OpMin, OpMin>(ap, ad);
         const double ap1 = fmin(1.0, ap), ad1 = fmin(1.0, ad);
         double *sZL = d.socZL + on, *sZU = d.socZU + on, *sZP = d.socZP + om, *sZM = d.socZM + om,
                *sVL = d.socVL + om, *sVU = d.socVU + om;
@@ -685,7 +769,7 @@ static __device__ void b_mpc(const DV &d)
             sZP[i] = a; sZM[i] = b; sVL[i] = e; sVU[i] = f;
         }
 #undef PR
-        csum = block_reduce<OpSum>(csum); nc = block_reduce<OpSum>(nc);
+        block_reduce2<OpSum, OpSum>(csum, nc);
         const double mu_aff = nc > 0 ? csum / nc : 0.0;
         double sigma = cavg > 0.0 ? pow(fmax(0.0, mu_aff) / cavg, 3.0) : 1.0;
         sigma = fmin(1.0, fmax(sigma, 1e-4));
@@ -711,8 +795,11 @@ static __device__ void b_ipm_step(const DV &d)
     IpmState &st = d.ist[inst];
     INST_PTRS
     double ap = 1e300, ad = 1e300;
+    VTR(8)
     expand_directions(d, inst, st.mu, st.use_soc != 0, ap, ad);
-    ap = block_reduce<OpMin>(ap); ad = block_reduce<OpMin>(ad);
+    VTR(9)
+    block_reduce2<OpMin, OpMin>(ap, ad);
+    VTR(10)
     // plain fraction-to-boundary step lengths, primal and dual separately
     const double a = fmin(1.0, st.tau * ap), a_d = fmin(1.0, st.tau * ad);
     const bool ok = fin(st.relres) && st.relres < 1e-6 && fin(a) && fin(a_d);
@@ -727,16 +814,24 @@ static __device__ void b_ipm_step(const DV &d)
         return;
     }
     for (int j = threadIdx.x; j < d.n; j += TPB) {
-        p[j] = nudge_inside(p[j] + a * dp[j], lb[j], ub[j]); zl[j] += a_d * dzl[j]; zu[j] += a_d * dzu[j];
+        const double pj = p[j], dpj = dp[j], lbj = lb[j], ubj = ub[j], zlj = zl[j], zuj = zu[j], dzlj = dzl[j], dzuj = dzu[j];
+        p[j] = nudge_inside(pj + a * dpj, lbj, ubj); zl[j] = zlj + a_d * dzlj; zu[j] = zuj + a_d * dzuj;
     }
     for (int i = threadIdx.x; i < d.m; i += TPB) {
-        if (rt[i] == ROW_FREE) continue;
-        tp[i] += a * dtp[i]; tm[i] += a * dtm[i]; s[i] += a * ds[i];
-        if (rt[i] == ROW_INEQ) s[i] = nudge_inside(s[i], lo[i], hi[i]);
-        vl[i] += a_d * dvl[i]; vu[i] += a_d * dvu[i];
-        if (rt[i] == ROW_INEQ) y[i] = vl[i] - vu[i]; else y[i] += a_d * dy[i];
-        zpv[i] -= a_d * dy[i]; zmv[i] += a_d * dy[i];
+        const int rti = rt[i];
+        const double tpi = tp[i], tmi = tm[i], si = s[i], vli = vl[i], vui = vu[i], yi = y[i], zpi = zpv[i], zmi = zmv[i],
+                     dtpi = dtp[i], dtmi = dtm[i], dsi = ds[i], dvli = dvl[i], dvui = dvu[i], dyi = dy[i], loi = lo[i], hii = hi[i];
+        if (rti == ROW_FREE) continue;
+        tp[i] = tpi + a * dtpi; tm[i] = tmi + a * dtmi;
+        double sn = si + a * dsi;
+        if (rti == ROW_INEQ) sn = nudge_inside(sn, loi, hii);
+        s[i] = sn;
+        const double vln = vli + a_d * dvli, vun = vui + a_d * dvui;
+        vl[i] = vln; vu[i] = vun;
+        y[i] = rti == ROW_INEQ ? vln - vun : yi + a_d * dyi;
+        zpv[i] = zpi - a_d * dyi; zmv[i] = zmi + a_d * dyi;
     }
+    VTR(11)
     if (threadIdx.x == 0) { st.iter++; d.phase[inst] = PH_PREP; }
 }
 
@@ -908,7 +1003,8 @@ void ipm_sweep(Ctx &C, bool sqp_level)
     C.n_sweeps++;
     hipLaunchKernelGGL(k_qp_finish, gB, bT, 0, s, d);
     if (sqp_level) sqp_stage_kernels(C);
-    hipLaunchKernelGGL(k_ipm_head, gB, bT, 0, s, d);
+    const size_t vlds = 8 * (size_t)d.vstage;
+    hipLaunchKernelGGL(k_ipm_head, gB, bT, vlds, s, d);
     if (!d.sparse) hipLaunchKernelGGL(k_kkt_assemble, dim3(d.Fpad, d.B), dim3(128), 0, s, d);
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (C.tm.enabled) { ev = C.tm.get(); hipEventRecord(ev.first, s); }
@@ -938,11 +1034,11 @@ void ipm_sweep(Ctx &C, bool sqp_level)
     const int last = d.condense != 0 ? 0 : 1;          // full form: no refinement
     // (the solve timer brackets the two solve slots separately: the vector stage between them is not a solve kernel)
     if (C.tm.enabled) { hipEventRecord(ev.second, s); C.tm.pending_solve.push_back(ev); }
-    hipLaunchKernelGGL(k_ipm_mid, gB, bT, 0, s, d, last);
+    hipLaunchKernelGGL(k_ipm_mid, gB, bT, vlds, s, d, last);
     if (C.tm.enabled) { ev = C.tm.get(); hipEventRecord(ev.first, s); }
     lin_solve(PH_RESOLVE, false);
     if (C.tm.enabled) { hipEventRecord(ev.second, s); C.tm.pending_solve.push_back(ev); }
-    hipLaunchKernelGGL(k_ipm_tail, gB, bT, 0, s, d, last);
+    hipLaunchKernelGGL(k_ipm_tail, gB, bT, vlds, s, d, last);
 }
 
 // Runs every instance whose IpmState.start flag is set until each has a final MOI status
