@@ -490,11 +490,17 @@ __device__ void load_solve_vector(const DV &d, int inst, const double *src, doub
         if (u >= d.n) v = src[d.n + (d.condense ? d.krow[u - d.n] : u - d.n)];
         else if (u >= 0) {
             v = src[u];
-            if (d.condense)
-                for (int k = d.jcolptr[u]; k < d.jcolptr[u + 1]; ++k) {
+            if (d.condense) {
+                const int k0 = d.jcolptr[u], k1 = d.jcolptr[u + 1];
+#pragma unroll 2
+                for (int k = k0; k < k1; ++k) {
                     const int i = d.jrowval[k];
-                    if (rt[i] != ROW_FREE && d.kpos[i] < 0) v += jv[k] * src[d.n + i] / (Dd[i] + IPM_REG_D);
+                    const double jk = jv[k];
+                    const int rti = rt[i], kp = d.kpos[i];                 // (every operand of the entry before the test)
+                    const double si = src[d.n + i], Di = Dd[i];
+                    if (rti != ROW_FREE && kp < 0) v += jk * si / (Di + IPM_REG_D);
                 }
+            }
         }
         xv[p] = v;
     }
@@ -623,15 +629,19 @@ static __device__ void b_refine(const DV &d, int last, int want)
         if (xs) __syncthreads();
         for (int i = threadIdx.x; i < d.m; i += TPB) {
             double v;
-            if (d.kpos[i] >= 0) v = xv[d.upos[d.n + d.kpos[i]]];
-            else if (rt[i] == ROW_FREE) v = -cur[d.n + i];
+            const int kp = d.kpos[i], rti = rt[i], t0 = d.jrowptr[i], t1 = d.jrowptr[i + 1];
+            const double ci = cur[d.n + i], Di = Dd[i], so = sol[d.n + i];
+            if (kp >= 0) v = xv[d.upos[d.n + kp]];
+            else if (rti == ROW_FREE) v = -ci;
             else {      // eliminated row: q_i = (J_i dp - b_i) / (D_i + reg)
                 double acc = 0.0;
-                if (xs) for (int t = d.jrowptr[i]; t < d.jrowptr[i + 1]; ++t) acc += jv[d.jrslot[t]] * xs[d.jrcol[t]];
-                else for (int t = d.jrowptr[i]; t < d.jrowptr[i + 1]; ++t) acc += jv[d.jrslot[t]] * xv[d.upos[d.jrcol[t]]];
-                v = (acc - cur[d.n + i]) / (Dd[i] + IPM_REG_D);
+                if (xs) {
+#pragma unroll 4
+                    for (int t = t0; t < t1; ++t) acc += jv[d.jrslot[t]] * xs[d.jrcol[t]];
+                } else for (int t = t0; t < t1; ++t) acc += jv[d.jrslot[t]] * xv[d.upos[d.jrcol[t]]];
+                v = (acc - ci) / (Di + IPM_REG_D);
             }
-            const double w = sol[d.n + i] + v;
+            const double w = so + v;
             sol[d.n + i] = w;
             if (ss) ss[d.n + i] = rt[i] != ROW_FREE ? w : 0.0;                       // (masked: jact_col_masked)
         }
@@ -751,19 +761,23 @@ static __device__ void b_mpc(const DV &d)
         double csum = 0.0, nc = 0.0;
 #define PR(zz, dz, xx, dx, dst) do { csum += ((zz) + ad1 * (dz)) * ((xx) + ap1 * (dx)); nc += 1; dst = (dz) * (dx); } while (0)
         for (int j = threadIdx.x; j < d.n; j += TPB) {
+            const double lbj = lb[j], ubj = ub[j], pj = p[j], dpj = dp[j], zlj = zl[j], zuj = zu[j], dzlj = dzl[j], dzuj = dzu[j];
             double a = 0.0, b = 0.0;
-            if (fin(lb[j])) PR(zl[j], dzl[j], p[j] - lb[j], dp[j], a);
-            if (fin(ub[j])) PR(zu[j], dzu[j], ub[j] - p[j], -dp[j], b);
+            if (fin(lbj)) PR(zlj, dzlj, pj - lbj, dpj, a);
+            if (fin(ubj)) PR(zuj, dzuj, ubj - pj, -dpj, b);
             sZL[j] = a; sZU[j] = b;
         }
         for (int i = threadIdx.x; i < d.m; i += TPB) {
+            const int rti = rt[i];
+            const double zp = zpv[i], zm = zmv[i], dyi = dy[i], tpi = tp[i], tmi = tm[i], dtpi = dtp[i], dtmi = dtm[i], si = s[i],
+                         dsi = ds[i], loi = lo[i], hii = hi[i], vli = vl[i], vui = vu[i], dvli = dvl[i], dvui = dvu[i];
             double a = 0.0, b = 0.0, e = 0.0, f = 0.0;
-            if (rt[i] != ROW_FREE) {
-                PR(zpv[i], -dy[i], tp[i], dtp[i], a);
-                PR(zmv[i], dy[i], tm[i], dtm[i], b);
-                if (rt[i] == ROW_INEQ) {
-                    if (fin(lo[i])) PR(vl[i], dvl[i], s[i] - lo[i], ds[i], e);
-                    if (fin(hi[i])) PR(vu[i], dvu[i], hi[i] - s[i], -ds[i], f);
+            if (rti != ROW_FREE) {
+                PR(zp, -dyi, tpi, dtpi, a);
+                PR(zm, dyi, tmi, dtmi, b);
+                if (rti == ROW_INEQ) {
+                    if (fin(loi)) PR(vli, dvli, si - loi, dsi, e);
+                    if (fin(hii)) PR(vui, dvui, hii - si, -dsi, f);
                 }
             }
             sZP[i] = a; sZM[i] = b; sVL[i] = e; sVU[i] = f;
