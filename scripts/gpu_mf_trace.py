@@ -68,14 +68,18 @@ if L.sqphip_mf_trace2_read(buf2.ctypes.data_as(C.POINTER(C.c_longlong)), ns) == 
 buf3 = np.zeros((ns, 16), dtype=np.int64)
 L.sqphip_mf_trace3_read.argtypes = [C.POINTER(C.c_longlong), C.c_int]
 if L.sqphip_mf_trace3_read(buf3.ctypes.data_as(C.POINTER(C.c_longlong)), ns) == 0:
-    print("four-wave solves, cycles: fwd: issue | wait+barrier | gather | blocks | rows-below   bwd: issue | wait+barrier | L21'x | blocks")
+    print("four-wave solves, cycles: fwd: wait+barrier | gather | blocks | rows-below   bwd: wait+barrier | L21'x | blocks   (nc, nr)")
+    nc_nr = {}
     for srow in range(ns):
         t = buf3[srow]
-        if t[8] == 0: continue
-        f = [t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4]] if t[0] else [0] * 5
-        b = [t[9] - t[8], t[10] - t[9], t[11] - t[10], t[12] - t[11]]
-        print(f"  front {srow:4d}: fwd " + " ".join(f"{int(v):6d}" for v in f) + "   bwd " + " ".join(f"{int(v):6d}" for v in b))
-
+        if t[9] == 0: continue
+        f = [t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4]] if t[1] else [0] * 4
+        b = [t[10] - t[9], t[11] - t[10], t[12] - t[11]]
+        print(f"  front {srow:4d}: fwd " + " ".join(f"{int(v):6d}" for v in f) + "   bwd " + " ".join(f"{int(v):6d}" for v in b)
+              + f"   fwd total {int(t[5] - t[1]) if t[1] else 0}  bwd total {int(t[12] - t[9])}  fwd-end -> bwd-start of same front {int(t[9] - t[5]) if t[1] else 0}")
+    tt = buf3[buf3[:, 9] > 0]
+    if len(tt):
+        print("  span first fwd stamp -> last bwd stamp (cycles):", int(tt[:, 12].max() - tt[tt[:, 1] > 0][:, 1].min()) if (tt[:, 1] > 0).any() else -1)
 # vector stages of the last sweeps (instance 0, thread 0), shader cycles
 vt = np.zeros(64, dtype=np.int64)
 L.sqphip_vec_trace_read.argtypes = [C.POINTER(C.c_longlong)]

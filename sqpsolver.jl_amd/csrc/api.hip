@@ -272,6 +272,15 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
                 M.desc = C.upload(P.desc);
                 M.ea_ent = C.upload(P.ea_ent.empty() ? std::vector<MfGather>(1) : P.ea_ent);
                 M.ev_ent = C.upload(P.ev_ent.empty() ? std::vector<MfGather>(1) : P.ev_ent);
+                int lds_max = 0;                 // LDS a workgroup may have on this device (gfx950: 160 KB)
+                if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, C.opt.device) != hipSuccess) lds_max = 0;
+                M.top_n = P.top2_lds_bytes > 0 && P.top2_lds_bytes <= lds_max ? (int)P.top_fr.size() : 0;
+                if (M.top_n > 0) {
+                    M.top_fr = C.upload(P.top_fr); M.top_gptr = C.upload(P.top_gptr); M.top_gsrc = C.upload(nz(P.top_gsrc));
+                    M.top_rows = C.upload(nz(P.top_rows)); M.top_ext = C.upload(nz(P.top_ext));
+                    M.top_next = (int)P.top_ext.size(); M.top_utotal = P.top_utotal; M.top_xtotal = P.top_xtotal;
+                    M.top_buf0 = P.top_buf0; M.top_buf1 = P.top_buf1;
+                }
                 M.nnzK = (int)P.nnzK;
                 M.vals = C.dalloc<double>((size_t)B * P.nnzK);
                 M.fronts = C.dalloc<double>((size_t)B * P.stride);

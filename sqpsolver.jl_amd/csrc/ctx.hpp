@@ -69,6 +69,10 @@ struct MfDev {
     const int *level_ptr, *level_sn;      // supernodes by level of the assembly tree (leaves first)
     int nlevels, max_front;
     const int *sched, *sol_items;
+    // the top of the assembly tree for k_mf_solve_top2 (sparse.hpp MfTopFront; top_n == 0: not in use)
+    const MfTopFront *top_fr;
+    const int *top_gptr, *top_gsrc, *top_rows, *top_ext;
+    int top_n, top_next, top_utotal, top_xtotal, top_buf0, top_buf1;
     int nnzK;                             // destinations (structural entries of the lower triangle)
     double *vals;                         // [B][nnzK] assembled values of the destinations (k_mf_values)
 };

@@ -232,6 +232,70 @@ MfPlan mf_build_plan(int n, int m, const std::vector<int> &kpos, int mk, const s
         P.top.lds_bytes = 8 * (P.top.cls + top_lcap);
     }
     P.bwd.assign(P.fwd.rbegin(), P.fwd.rend());
+    // The top again, for the streaming kernel (k_mf_solve_top2): fronts ascending (children before parents; every ancestor
+    // of a top front is a top front).  One wave walks the fronts with everything it touches in LDS -- the factor image of
+    // the front (prefetched by the other waves while the previous front is solved), the updates of the children, the
+    // solution of the ancestors -- so a front costs its dependent arithmetic, not a chain of memory round trips.
+    if (P.top.count > 0 && !(getenv("SQPHIP_MF_TOP2") && atoi(getenv("SQPHIP_MF_TOP2")) == 0)) {
+        std::vector<int> kof(S.ns, -1);
+        bool ok = true;
+        for (int s = 0; s < S.ns; ++s) {
+            if (S.sn_level[s] < P.top_level) continue;
+            const int nc = S.sn_nc[s], nr = S.sn_nr[s], fs = nc + nr;
+            if (fs > 128) { ok = false; break; }
+            kof[s] = (int)P.top_fr.size();
+            MfTopFront F{s, nc, nr, S.sn_first[s], (int)P.off[s], fs | 1, P.top_xtotal, P.top_utotal, 0, 0, 0, 0, 0, 0, 0, 0};
+            P.top_xtotal += nc; P.top_utotal += nr;
+            P.top_fr.push_back(F);
+        }
+        // gather lists: local row i of front s receives, children ascending, entry jj of child c where rel[jj] == i; a child
+        // inside the top hands its update over in LDS (index n_ext + uoff + jj, fixed up below), one below the top has
+        // left it in the arena, from where the kernel's prologue fetches all of them at once (top_ext)
+        std::vector<std::pair<int, int>> con;
+        for (size_t k = 0; ok && k < P.top_fr.size(); ++k) {
+            MfTopFront &F = P.top_fr[k];
+            const int s = F.s, fs = F.nc + F.nr;
+            con.clear();
+            for (int q = S.child_ptr[s]; q < S.child_ptr[s + 1]; ++q) {
+                const int c = S.child[q], cnc = S.sn_nc[c], cnr = S.sn_nr[c], cfs = cnc + cnr, cld = cfs + 1;
+                const int *rel = S.rel.data() + S.sn_rowptr[c];
+                for (int jj = 0; jj < cnr; ++jj) {
+                    int src;
+                    if (kof[c] >= 0) src = -1 - (P.top_fr[kof[c]].uoff + jj);
+                    else { src = (int)P.top_ext.size(); P.top_ext.push_back((int)(P.off[c] + (long)(cnc + jj) * cld + cfs)); }
+                    con.emplace_back(rel[jj], src);
+                }
+            }
+            std::stable_sort(con.begin(), con.end(), [](const std::pair<int, int> &a, const std::pair<int, int> &b) { return a.first < b.first; });
+            F.gptr = (int)P.top_gptr.size(); F.gsrc0 = (int)P.top_gsrc.size(); F.nsrc = (int)con.size();
+            size_t r = 0;
+            for (int i = 0; i <= fs; ++i) {
+                P.top_gptr.push_back((int)r);
+                while (r < con.size() && con[r].first == i) { P.top_gsrc.push_back(con[r].second); ++r; }
+            }
+            if (r != con.size()) { fprintf(stderr, "sqphip: mf_build_plan: update entry outside the parent front\n"); abort(); }
+            F.rloc = (int)P.top_rows.size();
+            for (int t = 0; t < F.nr; ++t) {
+                const int qpos = S.sn_rows[S.sn_rowptr[s] + t], p = S.col2sn[qpos];
+                if (kof[p] < 0) { fprintf(stderr, "sqphip: mf_build_plan: ancestor of a top front below the top\n"); abort(); }
+                P.top_rows.push_back(P.top_fr[kof[p]].xloc + qpos - S.sn_first[p]);
+            }
+            // LDS buffer: [L image nc x ll][1 / D: nc][right-hand side or D^-1 L^-1 b: nc][ints: fs + 1 pointers, sources, rows]
+            F.lbuf = F.nc * F.ll + 2 * F.nc + (fs + 1 + F.nsrc + F.nr + 1) / 2;
+            int &bmax = (k & 1) ? P.top_buf1 : P.top_buf0;
+            bmax = std::max(bmax, F.lbuf);
+        }
+        const int n_ext = (int)P.top_ext.size();
+        for (int &v : P.top_gsrc) if (v < 0) v = n_ext + (-1 - v);
+        // [buf0][buf1][updates: n_ext + utotal][x: xtotal][D^-1 L^-1 b: xtotal] + 128 doubles of slack behind the buffers (the
+        // chains read whole 64-lane columns of an image: the lanes beyond the front read past it and are discarded)
+        const long lds = 8L * ((long)P.top_buf0 + P.top_buf1 + n_ext + P.top_utotal + 2L * P.top_xtotal + 128);
+        if (getenv("SQPHIP_SYM_DUMP"))
+            fprintf(stderr, "top (streamed): %d fronts from level %d, %d external + %d internal update entries, %d columns, LDS %ld bytes (buffers %d + %d doubles)%s\n",
+                    (int)P.top_fr.size(), P.top_level, n_ext, P.top_utotal, P.top_xtotal, lds, P.top_buf0, P.top_buf1, ok ? "" : " -- a front of more than 128 rows: not used");
+        if (ok && !P.top_fr.empty() && lds <= 160 * 1024 - 2048) P.top2_lds_bytes = lds;
+        else { P.top_fr.clear(); P.top_gptr.clear(); P.top_gsrc.clear(); P.top_rows.clear(); P.top_ext.clear(); }
+    }
     // packed records for the kernels
     P.desc.resize(S.ns);
     for (int s = 0; s < S.ns; ++s)

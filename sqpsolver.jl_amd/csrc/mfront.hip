@@ -1086,6 +1086,204 @@ __global__ __launch_bounds__(64 * NWV) void k_mf_solve_inst(DV d, int want, int 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The top of the assembly tree, streamed (k_mf_solve_top2; plan: mfplan.hip, MfTopFront).  k_mf_solve_top spends ~12 us
+// per front and direction on a chain of dependent memory round trips and workgroup barriers (measured with the cycle
+// stamps above: 70 % of a forward visit is the blocked L11 chain, two barriers per sixteen columns, the rest waits for
+// global loads).  Here ONE wave does all the arithmetic of a front out of LDS and registers -- lane i owns row i (and
+// i + 64) of the front: its right-hand side plus the children's updates, then nc steps y_i -= L_ik y_k with y_k read
+// across the wave (v_readlane), which finishes the triangular solve AND the update for the ancestors in one loop; the
+// backward pass likewise with lane k owning column k -- while the other three waves fetch the NEXT front's factor image,
+// 1 / D, right-hand side and gather lists into the second LDS buffer.  Updates between top fronts, the solution of the
+// ancestors and D^-1 L^-1 b stay in LDS; global memory sees only the results (stores nobody waits for).  One
+// workgroup barrier per front, and it waits for LDS traffic only.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// loader wave lw of NLW: image of the front's L (rows below the diagonal of its nc columns), 1 / D, bsrc (right-hand
+// side or D^-1 L^-1 b; may be null), gather pointers / sources / row indices -> LDS buffer Bf
+template <int NLW>
+__device__ __forceinline__ void mf_top_load(const MfDev &M, const MfTopFront &F, double *Bf, const double *arena,
+                                            const double *dinv, const double *bsrc, int lw, int lane)
+{
+    const int nc = F.nc, fs = F.nc + F.nr, ld = fs + 1, ll = F.ll;
+    const double *G = arena + F.off;
+    constexpr int CH = 28;                       // columns per wave with all their loads in flight at once
+    if (fs <= 64) {
+        for (int c0 = lw; c0 < nc; c0 += CH * NLW) {
+            double v0[CH];
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                const int c = c0 + q * NLW;
+                v0[q] = (c < nc && lane > c && lane < fs) ? G[(long)c * ld + lane] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                const int c = c0 + q * NLW;
+                if (c < nc && lane < fs) Bf[c * ll + lane] = v0[q];
+            }
+        }
+    } else {
+        for (int c0 = lw; c0 < nc; c0 += CH * NLW) {
+            double v0[CH], v1[CH];
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                const int c = c0 + q * NLW;
+                v0[q] = (c < nc && lane > c) ? G[(long)c * ld + lane] : 0.0;
+                v1[q] = (c < nc && lane + 64 > c && lane + 64 < fs) ? G[(long)c * ld + lane + 64] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                const int c = c0 + q * NLW;
+                if (c < nc) { Bf[c * ll + lane] = v0[q]; if (lane + 64 < fs) Bf[c * ll + lane + 64] = v1[q]; }
+            }
+        }
+    }
+    double *dv = Bf + nc * ll, *bv = dv + nc;
+    int *gp = reinterpret_cast<int *>(bv + nc), *gs = gp + fs + 1, *rl = gs + F.nsrc;
+    if (lw == 0) {
+        for (int i = lane; i < nc; i += 64) { dv[i] = dinv[F.first + i]; if (bsrc) bv[i] = bsrc[F.first + i]; }
+        for (int i = lane; i < F.nr; i += 64) rl[i] = M.top_rows[F.rloc + i];
+    }
+    if (lw == NLW - 1) {
+        for (int i = lane; i <= fs; i += 64) gp[i] = M.top_gptr[F.gptr + i];
+        for (int i = lane; i < F.nsrc; i += 64) gs[i] = M.top_gsrc[F.gsrc0 + i];
+    }
+}
+
+// forward substitution of one top front by one wave; uvec = [updates from below the top | updates of top fronts]
+__device__ __forceinline__ void mf_top_fwd(const MfTopFront &F, const double *Bf, double *uvec, int next, double *ytop,
+                                           double *vv, int lane)
+{
+    const int nc = F.nc, fs = F.nc + F.nr, ll = F.ll;
+    const double *dv = Bf + nc * ll, *bv = dv + nc;
+    const int *gp = reinterpret_cast<const int *>(bv + nc), *gs = gp + fs + 1;
+    const int i0 = lane, i1 = lane + 64;
+    const int r0 = i0 < fs ? i0 : 0, r1 = i1 < fs ? i1 : 0;
+    double y0 = i0 < nc ? bv[i0] : 0.0, y1 = i1 < nc ? bv[i1] : 0.0;
+    if (i0 < fs) for (int q = gp[i0]; q < gp[i0 + 1]; ++q) y0 += uvec[gs[q]];
+    if (i1 < fs) for (int q = gp[i1]; q < gp[i1 + 1]; ++q) y1 += uvec[gs[q]];
+    if (fs <= 64) {
+#pragma unroll 4
+        for (int k = 0; k < nc; ++k) {
+            const double l0 = Bf[k * ll + r0];
+            const double yk = mf_readlane(y0, k);
+            y0 -= (i0 > k ? l0 : 0.0) * yk;
+        }
+    } else {
+        const int n0 = nc < 64 ? nc : 64;
+#pragma unroll 4
+        for (int k = 0; k < n0; ++k) {
+            const double l0 = Bf[k * ll + r0], l1 = Bf[k * ll + r1];
+            const double yk = mf_readlane(y0, k);
+            y0 -= (i0 > k ? l0 : 0.0) * yk;
+            y1 -= l1 * yk;                               // rows 64.. lie below every column k < 64
+        }
+#pragma unroll 4
+        for (int k = 64; k < nc; ++k) {
+            const double l1 = Bf[k * ll + r1];
+            const double yk = mf_readlane(y1, k - 64);
+            y1 -= (i1 > k ? l1 : 0.0) * yk;
+        }
+    }
+    if (i0 < nc) { const double v = y0 * dv[i0]; ytop[F.xloc + i0] = v; vv[F.first + i0] = v; }
+    else if (i0 < fs) uvec[next + F.uoff + i0 - nc] = y0;
+    if (i1 < nc) { const double v = y1 * dv[i1]; ytop[F.xloc + i1] = v; vv[F.first + i1] = v; }
+    else if (i1 < fs) uvec[next + F.uoff + i1 - nc] = y1;
+}
+
+// backward substitution of one top front by one wave: x_cols = L11^-T (vs - L21' x_rows); vs = D^-1 L^-1 b of its columns
+__device__ __forceinline__ void mf_top_bwd(const MfTopFront &F, const double *Bf, const double *vs, double *xtop, double *xg,
+                                           int lane)
+{
+    const int nc = F.nc, nr = F.nr, fs = nc + nr, ll = F.ll;
+    const double *bv = Bf + nc * ll + nc;
+    const int *rl = reinterpret_cast<const int *>(bv + nc) + fs + 1 + F.nsrc;
+    const int i0 = lane, i1 = lane + 64;
+    const int c0 = i0 < nc ? i0 : 0, c1 = i1 < nc ? i1 : 0;
+    double t0 = i0 < nc ? vs[i0] : 0.0, t1 = i1 < nc ? vs[i1] : 0.0;
+    const double xr0 = i0 < nr ? xtop[rl[i0]] : 0.0, xr1 = i1 < nr ? xtop[rl[i1]] : 0.0;
+    const bool two = nc > 64;
+    const int m0 = nr < 64 ? nr : 64;
+#pragma unroll 4
+    for (int r = 0; r < m0; ++r) {
+        const double xr = mf_readlane(xr0, r);
+        t0 -= Bf[c0 * ll + nc + r] * xr;
+        if (two) t1 -= Bf[c1 * ll + nc + r] * xr;
+    }
+#pragma unroll 4
+    for (int r = 64; r < nr; ++r) {
+        const double xr = mf_readlane(xr1, r - 64);
+        t0 -= Bf[c0 * ll + nc + r] * xr;
+        if (two) t1 -= Bf[c1 * ll + nc + r] * xr;
+    }
+    if (two) {
+#pragma unroll 4
+        for (int i = nc - 1; i >= 64; --i) {
+            const double xi = mf_readlane(t1, i - 64);
+            const double l0 = Bf[c0 * ll + i], l1 = Bf[c1 * ll + i];
+            t0 -= l0 * xi;                               // columns < 64 lie left of every row i >= 64
+            t1 -= (i1 < i ? l1 : 0.0) * xi;
+        }
+    }
+#pragma unroll 4
+    for (int i = (nc < 64 ? nc : 64) - 1; i > 0; --i) {
+        const double xi = mf_readlane(t0, i);
+        const double l0 = Bf[c0 * ll + i];
+        t0 -= (i0 < i ? l0 : 0.0) * xi;
+    }
+    if (i0 < nc) { xtop[F.xloc + i0] = t0; xg[F.first + i0] = t0; }
+    if (i1 < nc) { xtop[F.xloc + i1] = t1; xg[F.first + i1] = t1; }
+}
+
+__global__ __launch_bounds__(256) void k_mf_solve_top2(DV d, int want, int do_fwd)
+{
+    const int inst = blockIdx.x;
+    if (d.phase[inst] != want) return;
+    const MfDev &M = d.mf;
+    extern __shared__ double mf_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cand = d.ist[inst].sel;
+    const double *arena = mf_arena(d, inst, cand);
+    const double *dinv = mf_dinv(d, inst, cand);
+    double *vv = mf_vv(d, inst, cand);
+    double *xg = d.xv + (long)inst * d.Fpad;
+    const int n = M.top_n, next = M.top_next;
+    double *buf0 = mf_lds, *buf1 = buf0 + M.top_buf0, *uvec = buf1 + M.top_buf1 + 128, *xtop = uvec + next + M.top_utotal,
+           *ytop = xtop + M.top_xtotal;
+    const MfTopFront *T = M.top_fr;
+    // steps: forward over fronts 0 .. n-1, then backward n-1 .. 0 (the root does both in its step); or backward only
+    const int nsteps = do_fwd ? 2 * n - 1 : n;
+#define MF_TOP_FRONT_OF(j) (do_fwd ? ((j) < n ? (j) : 2 * n - 2 - (j)) : n - 1 - (j))
+    MfTopFront F = T[MF_TOP_FRONT_OF(0)];
+    if (do_fwd) for (int t = tid; t < next; t += 256) uvec[t] = arena[M.top_ext[t]];
+    {
+        const int k0 = MF_TOP_FRONT_OF(0);
+        mf_top_load<4>(M, F, (k0 & 1) ? buf1 : buf0, arena, dinv, do_fwd ? xg : vv, wave, lane);
+    }
+    lds_barrier();
+    for (int j = 0; j < nsteps; ++j) {
+        const int k = MF_TOP_FRONT_OF(j);
+        const int kn = j + 1 < nsteps ? MF_TOP_FRONT_OF(j + 1) : -1;
+        MfTopFront Fn = F;
+        if (kn >= 0) Fn = T[kn];
+        double *Bf = (k & 1) ? buf1 : buf0;
+        if (wave == 0) {
+            const bool fwd = do_fwd && j < n;
+            if (fwd) mf_top_fwd(F, Bf, uvec, next, ytop, vv, lane);
+            if (!fwd || j == n - 1) mf_top_bwd(F, Bf, do_fwd ? ytop + F.xloc : Bf + F.nc * F.ll + F.nc, xtop, xg, lane);
+        } else if (kn >= 0) {
+            const double *bsrc = do_fwd ? (j + 1 < n ? xg : nullptr) : vv;
+            mf_top_load<3>(M, Fn, (kn & 1) ? buf1 : buf0, arena, dinv, bsrc, wave - 1, lane);
+        }
+        lds_barrier();
+        F = Fn;
+    }
+#undef MF_TOP_FRONT_OF
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 static int mf_generic_solves()
 {
     static const int g = getenv("SQPHIP_MF_GENERIC") ? atoi(getenv("SQPHIP_MF_GENERIC")) : 0;
@@ -1156,7 +1354,13 @@ void mf_solve(Ctx &C, int want, bool skip_fwd)
     if (!skip_fwd)
         for (const MfLaunch &L : C.mfp().fwd)
             hipLaunchKernelGGL(k_mf_fwd, dim3(L.count, d.B), dim3(256), L.lds_bytes, s, d, L.begin, want, generic, L.tiles, L.cls, L.lds_bytes / 8 - L.cls);
-    if (const MfLaunch &T = C.mfp().top; T.count > 0)
+    if (d.mf.top_n > 0 && !generic) {
+        const size_t lds = (size_t)C.mfp().top2_lds_bytes;
+        // more than 64 KB of dynamic LDS has to be asked for, once (thread-safe: the instance groups launch concurrently)
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_solve_top2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        SQPHIP_HIP_OK(attr);
+        hipLaunchKernelGGL(k_mf_solve_top2, dim3(d.B), dim3(256), lds, s, d, want, skip_fwd ? 0 : 1);
+    } else if (const MfLaunch &T = C.mfp().top; T.count > 0)
         hipLaunchKernelGGL(k_mf_solve_top, dim3(d.B), dim3(256), T.lds_bytes, s, d, T.begin, T.count, want, skip_fwd ? 0 : 1, generic,
                            T.tiles, T.cls, T.lds_bytes / 8 - T.cls);
     for (const MfLaunch &L : C.mfp().bwd)

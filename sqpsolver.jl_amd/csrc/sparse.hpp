@@ -93,6 +93,13 @@ struct MfGather { int where, src_begin, src_end, src0; };
 // of the launch (sizes the LDS image), lds_bytes = dynamic LDS.
 struct MfLaunch { int begin, count, threads, lds_bytes, cls, tiles; };
 
+// One front of the narrow top of the assembly tree as the streaming solve kernel (k_mf_solve_top2, mfront.hip) sees it:
+// where its factor lives in the arena, the leading dimension of its LDS image (odd: the transposed reads of the
+// backward chain then hit different banks), where its columns sit in the kernel's LDS copies of x / D^-1 L^-1 b (xloc),
+// where its update vector goes (uoff, into the LDS vector of updates), its gather lists (pointers relative to the
+// front, sources = indices into that vector) and the LDS indices of its rows (rloc).  lbuf = doubles of its LDS buffer.
+struct MfTopFront { int s, nc, nr, first, off, ll, xloc, uoff, gptr, gsrc0, nsrc, rloc, lbuf, pad0, pad1, pad2; };
+
 struct MfPlan {
     SparseSym S;
     std::vector<long> off;                       // front offsets (doubles) with the (fs + 1) x fs layout
@@ -117,6 +124,12 @@ struct MfPlan {
     std::vector<MfLaunch> fac, fwd, bwd;
     MfLaunch top{0, 0, 256, 0, 0, 0};           // solves: the narrow top of the assembly tree (levels >= top_level) in one launch
     int top_level = 0;                            // = S.nlevels when there is no such launch
+    // the same fronts for k_mf_solve_top2 (fronts ascending = children first); top2_lds_bytes == 0: not applicable
+    // (a front of more than 128 rows, or the images do not fit the LDS) and k_mf_solve_top runs instead
+    std::vector<MfTopFront> top_fr;
+    std::vector<int> top_gptr, top_gsrc, top_rows, top_ext;     // gather pointers / sources, row indices, arena offsets of the updates that come from below the top
+    int top_xtotal = 0, top_utotal = 0, top_buf0 = 0, top_buf1 = 0;
+    long top2_lds_bytes = 0;
     long nnzK = 0;                               // structural entries of the lower triangle (destinations)
 };
 
