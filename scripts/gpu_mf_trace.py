@@ -80,6 +80,16 @@ if L.sqphip_mf_trace3_read(buf3.ctypes.data_as(C.POINTER(C.c_longlong)), ns) == 
     tt = buf3[buf3[:, 9] > 0]
     if len(tt):
         print("  span first fwd stamp -> last bwd stamp (cycles):", int(tt[:, 12].max() - tt[tt[:, 1] > 0][:, 1].min()) if (tt[:, 1] > 0).any() else -1)
+    # streamed top solve: rows 0..63 backward-only launch, 64..127 forward + backward launch
+    for base, name in ((0, "backward only"), (64, "forward + backward")):
+        rows = buf3[base:base + 64] if ns >= base + 64 else np.zeros((0, 16), dtype=np.int64)
+        rows = rows[rows[:, 0] > 0]
+        if len(rows):
+            print(f"k_mf_solve_top2 ({name}), cycles per step: compute | its wait at the barrier || loader: load | wait   (total {int(rows[-1, 2] - rows[0, 0])})")
+            for j, t in enumerate(rows):
+                fw = f"fwd: gather {int(t[8] - t[0]):6d} chain {int(t[9] - t[8]):6d}" if t[8] > t[0] else " " * 36
+                bw = f"bwd: start {int(t[10] - max(t[0], t[9])):6d} L21 {int(t[11] - t[10]):6d} chain {int(t[12] - t[11]):6d} tail {int(t[1] - t[12]):6d}" if t[10] > t[0] else ""
+                print(f"   step {j:2d}: {int(t[1] - t[0]):6d} {int(t[2] - t[1]):6d}  || {int(t[5] - t[4]):6d} {int(t[6] - t[5]):6d}    {fw} {bw}")
 # vector stages of the last sweeps (instance 0, thread 0), shader cycles
 vt = np.zeros(64, dtype=np.int64)
 L.sqphip_vec_trace_read.argtypes = [C.POINTER(C.c_longlong)]

@@ -287,9 +287,8 @@ MfPlan mf_build_plan(int n, int m, const std::vector<int> &kpos, int mk, const s
         }
         const int n_ext = (int)P.top_ext.size();
         for (int &v : P.top_gsrc) if (v < 0) v = n_ext + (-1 - v);
-        // [buf0][buf1][updates: n_ext + utotal][x: xtotal][D^-1 L^-1 b: xtotal] + 128 doubles of slack behind the buffers (the
-        // chains read whole 64-lane columns of an image: the lanes beyond the front read past it and are discarded)
-        const long lds = 8L * ((long)P.top_buf0 + P.top_buf1 + n_ext + P.top_utotal + 2L * P.top_xtotal + 128);
+        // [buf0][buf1][128 doubles of slack][updates: n_ext + utotal][x: xtotal][D^-1 L^-1 b: xtotal][front records: 16 ints each]
+        const long lds = 8L * ((long)P.top_buf0 + P.top_buf1 + n_ext + P.top_utotal + 2L * P.top_xtotal + 128 + 8L * (long)P.top_fr.size());
         if (getenv("SQPHIP_SYM_DUMP"))
             fprintf(stderr, "top (streamed): %d fronts from level %d, %d external + %d internal update entries, %d columns, LDS %ld bytes (buffers %d + %d doubles)%s\n",
                     (int)P.top_fr.size(), P.top_level, n_ext, P.top_utotal, P.top_xtotal, lds, P.top_buf0, P.top_buf1, ok ? "" : " -- a front of more than 128 rows: not used");

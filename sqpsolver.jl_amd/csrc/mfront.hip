@@ -69,10 +69,15 @@ __device__ long long g_mf_trace2[1 << 12][16];
 // ... and inside the four-wave solve routines (thread 0 of instance 0): [front][forward 0..7 | backward 8..15]
 __device__ long long g_mf_trace3[1 << 12][16];
 #define MF_TRS(i) if (inst == 0 && tid == 0 && s < (1 << 12)) g_mf_trace3[s][i] = (long long)clock64();
+// ... and in the streamed top-of-tree solve: per step [compute wave: start, done, past the barrier | -, loader wave 1: likewise]
+#define MF_TR2S(a, b) if (inst == 0 && lane == 0 && j < 64 && wave < 2) g_mf_trace3[(do_fwd ? 64 : 0) + j][wave == 0 ? (a) : (b)] = (long long)clock64();
+#define MF_TR2W(c) if (trj >= 0 && lane == 0) g_mf_trace3[trj][c] = (long long)clock64();
 #else
 #define MF_TR(i)
 #define MF_TRW(i)
 #define MF_TRS(i)
+#define MF_TR2S(a, b)
+#define MF_TR2W(c)
 #endif
 
 // Thread layout inside a front: RL row lanes x (NT / RL) column groups; RL = 16 / 32 / 64 by front height so that a
@@ -1107,8 +1112,32 @@ template <int NLW>
 __device__ __forceinline__ void mf_top_load(const MfDev &M, const MfTopFront &F, double *Bf, const double *arena,
                                             const double *dinv, const double *bsrc, int lw, int lane)
 {
-    const int nc = F.nc, fs = F.nc + F.nr, ld = fs + 1, ll = F.ll;
+    const int nc = F.nc, nr = F.nr, fs = F.nc + F.nr, ld = fs + 1, ll = F.ll;
     const double *G = arena + F.off;
+    double *dv = Bf + nc * ll, *bv = dv + nc;
+    int *gp = reinterpret_cast<int *>(bv + nc), *gs = gp + fs + 1, *rl = gs + F.nsrc;
+    // the small vectors ride with the first batch of image loads: EVERYTHING a wave fetches is requested before it waits
+    // once and writes to LDS (one exposed round trip per front; requested one after the other they were three)
+    double sd0 = 0.0, sd1 = 0.0, sb0 = 0.0, sb1 = 0.0;
+    int si0 = 0, si1 = 0, si2 = 0, sg0 = 0, sg1 = 0, sg2 = 0, sg3 = 0;
+    const int i0 = lane, i1 = lane + 64;
+    if (lw == 0) {
+        if (i0 < nc) { sd0 = dinv[F.first + i0]; if (bsrc) sb0 = bsrc[F.first + i0]; }
+        if (i1 < nc) { sd1 = dinv[F.first + i1]; if (bsrc) sb1 = bsrc[F.first + i1]; }
+    }
+    if (lw == 1 % NLW) {
+        if (i0 < nr) si0 = M.top_rows[F.rloc + i0];
+        if (i1 < nr) si1 = M.top_rows[F.rloc + i1];
+    }
+    if (lw == 2 % NLW) {
+        if (i0 <= fs) sg0 = M.top_gptr[F.gptr + i0];
+        if (i1 <= fs) sg1 = M.top_gptr[F.gptr + i1];
+        if (lane + 128 <= fs) sg2 = M.top_gptr[F.gptr + lane + 128];
+    }
+    if (lw == NLW - 1) {
+        if (i0 < F.nsrc) si2 = M.top_gsrc[F.gsrc0 + i0];
+        if (i1 < F.nsrc) sg3 = M.top_gsrc[F.gsrc0 + i1];
+    }
     constexpr int CH = 28;                       // columns per wave with all their loads in flight at once
     if (fs <= 64) {
         for (int c0 = lw; c0 < nc; c0 += CH * NLW) {
@@ -1140,101 +1169,194 @@ __device__ __forceinline__ void mf_top_load(const MfDev &M, const MfTopFront &F,
             }
         }
     }
-    double *dv = Bf + nc * ll, *bv = dv + nc;
-    int *gp = reinterpret_cast<int *>(bv + nc), *gs = gp + fs + 1, *rl = gs + F.nsrc;
     if (lw == 0) {
-        for (int i = lane; i < nc; i += 64) { dv[i] = dinv[F.first + i]; if (bsrc) bv[i] = bsrc[F.first + i]; }
-        for (int i = lane; i < F.nr; i += 64) rl[i] = M.top_rows[F.rloc + i];
+        if (i0 < nc) { dv[i0] = sd0; if (bsrc) bv[i0] = sb0; }
+        if (i1 < nc) { dv[i1] = sd1; if (bsrc) bv[i1] = sb1; }
+    }
+    if (lw == 1 % NLW) {
+        if (i0 < nr) rl[i0] = si0;
+        if (i1 < nr) rl[i1] = si1;
+    }
+    if (lw == 2 % NLW) {
+        if (i0 <= fs) gp[i0] = sg0;
+        if (i1 <= fs) gp[i1] = sg1;
+        if (lane + 128 <= fs) gp[lane + 128] = sg2;
     }
     if (lw == NLW - 1) {
-        for (int i = lane; i <= fs; i += 64) gp[i] = M.top_gptr[F.gptr + i];
-        for (int i = lane; i < F.nsrc; i += 64) gs[i] = M.top_gsrc[F.gsrc0 + i];
+        if (i0 < F.nsrc) gs[i0] = si2;
+        if (i1 < F.nsrc) gs[i1] = sg3;
+        for (int i = lane + 128; i < F.nsrc; i += 64) gs[i] = M.top_gsrc[F.gsrc0 + i];      // (a front with more than 128 update sources: rare)
     }
 }
 
+// A dependent chain, eight steps at a time, software-pipelined by hand: the LDS operands of the next eight steps are
+// requested before the current eight run, so a step costs its v_readlane + v_fma_f64 (the dependent v_fma_f64 alone is
+// 32 cycles on gfx950, with the v_readlane pair 64: scripts/probes/readlane_chain.hip), not an LDS round trip (left to
+// itself the compiler keeps one ds_read per iteration right in front of its use: ~150 cycles per step).
+// load(s0, p0, p1): operands of steps s0 .. s0 + 7; step(s0, p0, p1): those steps.  No branches and no selects on the
+// operands inside either (with branches the operand arrays went through scratch; a wave-uniform condition in a select
+// becomes a branch around the ds_read with a wait right behind it; per-lane selects cost more VALU issue than the chain
+// itself): operands are read unmasked -- the image holds zeros on and above the diagonal -- and a step beyond the end
+// of the chain gets a zero PIVOT (a scalar select) and changes nothing.
+template <class LoadF, class StepF>
+__device__ __forceinline__ void mf_pipe8(int nsteps, LoadF load, StepF step)
+{
+    double a0[8], a1[8], b0[8], b1[8];
+    load(0, a0, a1);
+    for (int sb = 0; sb < nsteps; sb += 16) {
+        load(sb + 8, b0, b1);
+        step(sb, a0, a1);
+        load(sb + 16, a0, a1);
+        if (sb + 8 < nsteps) step(sb + 8, b0, b1);
+    }
+}
+// lane `k` of x if k < lim, else 0 (wave-uniform k: two v_readlane and two scalar selects)
+__device__ __forceinline__ double mf_pivot(double x, int k, int lim)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), k), hi = __builtin_amdgcn_readlane(__double2hiint(x), k);
+    return __hiloint2double(k < lim ? hi : 0, k < lim ? lo : 0);
+}
+
 // forward substitution of one top front by one wave; uvec = [updates from below the top | updates of top fronts]
+template <bool TWO>
 __device__ __forceinline__ void mf_top_fwd(const MfTopFront &F, const double *Bf, double *uvec, int next, double *ytop,
-                                           double *vv, int lane)
+                                           double *vv, int lane, int trj)
 {
     const int nc = F.nc, fs = F.nc + F.nr, ll = F.ll;
     const double *dv = Bf + nc * ll, *bv = dv + nc;
     const int *gp = reinterpret_cast<const int *>(bv + nc), *gs = gp + fs + 1;
     const int i0 = lane, i1 = lane + 64;
     const int r0 = i0 < fs ? i0 : 0, r1 = i1 < fs ? i1 : 0;
-    double y0 = i0 < nc ? bv[i0] : 0.0, y1 = i1 < nc ? bv[i1] : 0.0;
-    if (i0 < fs) for (int q = gp[i0]; q < gp[i0 + 1]; ++q) y0 += uvec[gs[q]];
-    if (i1 < fs) for (int q = gp[i1]; q < gp[i1 + 1]; ++q) y1 += uvec[gs[q]];
-    if (fs <= 64) {
-#pragma unroll 4
-        for (int k = 0; k < nc; ++k) {
-            const double l0 = Bf[k * ll + r0];
-            const double yk = mf_readlane(y0, k);
-            y0 -= (i0 > k ? l0 : 0.0) * yk;
-        }
-    } else {
-        const int n0 = nc < 64 ? nc : 64;
-#pragma unroll 4
-        for (int k = 0; k < n0; ++k) {
-            const double l0 = Bf[k * ll + r0], l1 = Bf[k * ll + r1];
-            const double yk = mf_readlane(y0, k);
-            y0 -= (i0 > k ? l0 : 0.0) * yk;
-            y1 -= l1 * yk;                               // rows 64.. lie below every column k < 64
-        }
-#pragma unroll 4
-        for (int k = 64; k < nc; ++k) {
-            const double l1 = Bf[k * ll + r1];
-            const double yk = mf_readlane(y1, k - 64);
-            y1 -= (i1 > k ? l1 : 0.0) * yk;
+    double y0 = i0 < nc ? bv[i0] : 0.0, y1 = (TWO && i1 < nc) ? bv[i1] : 0.0;
+    {   // updates of the children, sources in list order (both rows of a lane side by side: one chain of LDS round trips)
+        const int q0 = gp[r0], e0 = i0 < fs ? gp[r0 + 1] : q0, q1 = TWO ? gp[r1] : 0, e1 = (TWO && i1 < fs) ? gp[r1 + 1] : q1;
+        const int cnt = max(e0 - q0, e1 - q1);
+        for (int t = 0; t < cnt; ++t) {
+            const int sa = q0 + t < e0 ? gs[q0 + t] : -1, sb = (TWO && q1 + t < e1) ? gs[q1 + t] : -1;
+            if (sa >= 0) y0 += uvec[sa];
+            if (TWO && sb >= 0) y1 += uvec[sb];
         }
     }
+    MF_TR2W(8)
+    // columns 0 .. 63: y_k lives in y0; rows 64.. (y1) lie below every one of them
+    const int n0 = nc < 64 ? nc : 64;
+    const double *R0 = Bf + r0, *R1 = Bf + r1;
+    mf_pipe8(n0,
+        [&](int s0, double (&p0)[8], double (&p1)[8]) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k = s0 + q, kk = k < n0 ? k : n0 - 1;
+                p0[q] = R0[kk * ll];
+                if constexpr (TWO) p1[q] = R1[kk * ll];
+            }
+        },
+        [&](int s0, double (&p0)[8], double (&p1)[8]) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const double yk = mf_pivot(y0, s0 + q, n0);
+                y0 -= p0[q] * yk;
+                if constexpr (TWO) y1 -= p1[q] * yk;
+            }
+        });
+    // columns 64 ..: y_k lives in y1
+    if constexpr (TWO) if (nc > 64)
+        mf_pipe8(nc - 64,
+            [&](int s0, double (&p0)[8], double (&p1)[8]) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int k = 64 + s0 + q, kk = k < nc ? k : nc - 1;
+                    p1[q] = R1[kk * ll];
+                }
+            },
+            [&](int s0, double (&p0)[8], double (&p1)[8]) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) y1 -= p1[q] * mf_pivot(y1, s0 + q, nc - 64);
+            });
+    MF_TR2W(9)
     if (i0 < nc) { const double v = y0 * dv[i0]; ytop[F.xloc + i0] = v; vv[F.first + i0] = v; }
     else if (i0 < fs) uvec[next + F.uoff + i0 - nc] = y0;
-    if (i1 < nc) { const double v = y1 * dv[i1]; ytop[F.xloc + i1] = v; vv[F.first + i1] = v; }
-    else if (i1 < fs) uvec[next + F.uoff + i1 - nc] = y1;
+    if constexpr (TWO) {
+        if (i1 < nc) { const double v = y1 * dv[i1]; ytop[F.xloc + i1] = v; vv[F.first + i1] = v; }
+        else if (i1 < fs) uvec[next + F.uoff + i1 - nc] = y1;
+    }
 }
 
-// backward substitution of one top front by one wave: x_cols = L11^-T (vs - L21' x_rows); vs = D^-1 L^-1 b of its columns
+// backward substitution of one top front by one wave: x_cols = L11^-T (vs - L21' x_rows); vs = D^-1 L^-1 b of its columns.
+// TWO: more than 64 columns (a second register per lane: column lane + 64)
+template <bool TWO>
 __device__ __forceinline__ void mf_top_bwd(const MfTopFront &F, const double *Bf, const double *vs, double *xtop, double *xg,
-                                           int lane)
+                                           int lane, int trj)
 {
     const int nc = F.nc, nr = F.nr, fs = nc + nr, ll = F.ll;
     const double *bv = Bf + nc * ll + nc;
     const int *rl = reinterpret_cast<const int *>(bv + nc) + fs + 1 + F.nsrc;
     const int i0 = lane, i1 = lane + 64;
     const int c0 = i0 < nc ? i0 : 0, c1 = i1 < nc ? i1 : 0;
-    double t0 = i0 < nc ? vs[i0] : 0.0, t1 = i1 < nc ? vs[i1] : 0.0;
+    double t0 = i0 < nc ? vs[i0] : 0.0, t1 = (TWO && i1 < nc) ? vs[i1] : 0.0;
     const double xr0 = i0 < nr ? xtop[rl[i0]] : 0.0, xr1 = i1 < nr ? xtop[rl[i1]] : 0.0;
-    const bool two = nc > 64;
-    const int m0 = nr < 64 ? nr : 64;
-#pragma unroll 4
-    for (int r = 0; r < m0; ++r) {
-        const double xr = mf_readlane(xr0, r);
-        t0 -= Bf[c0 * ll + nc + r] * xr;
-        if (two) t1 -= Bf[c1 * ll + nc + r] * xr;
-    }
-#pragma unroll 4
-    for (int r = 64; r < nr; ++r) {
-        const double xr = mf_readlane(xr1, r - 64);
-        t0 -= Bf[c0 * ll + nc + r] * xr;
-        if (two) t1 -= Bf[c1 * ll + nc + r] * xr;
-    }
-    if (two) {
-#pragma unroll 4
-        for (int i = nc - 1; i >= 64; --i) {
-            const double xi = mf_readlane(t1, i - 64);
-            const double l0 = Bf[c0 * ll + i], l1 = Bf[c1 * ll + i];
-            t0 -= l0 * xi;                               // columns < 64 lie left of every row i >= 64
-            t1 -= (i1 < i ? l1 : 0.0) * xi;
-        }
-    }
-#pragma unroll 4
-    for (int i = (nc < 64 ? nc : 64) - 1; i > 0; --i) {
-        const double xi = mf_readlane(t0, i);
-        const double l0 = Bf[c0 * ll + i];
-        t0 -= (i0 < i ? l0 : 0.0) * xi;
-    }
+    const double *L0 = Bf + c0 * ll, *L1 = Bf + c1 * ll;          // lane k reads along its column k (ll odd: no bank conflicts)
+    MF_TR2W(10)
+    // x_cols -= L21' x_rows: row r of the rows below, x_r read across the wave
+    mf_pipe8(nr,
+        [&](int s0, double (&p0)[8], double (&p1)[8]) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = s0 + q, rr = r < nr ? r : nr - 1;
+                p0[q] = L0[nc + rr];
+                if constexpr (TWO) p1[q] = L1[nc + rr];
+            }
+        },
+        [&](int s0, double (&p0)[8], double (&p1)[8]) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const double xr = s0 < 64 ? mf_pivot(xr0, s0 + q, nr) : mf_pivot(xr1, s0 + q - 64, nr - 64);     // (blocks of eight never straddle 64)
+                t0 -= p0[q] * xr;
+                if constexpr (TWO) t1 -= p1[q] * xr;
+            }
+        });
+    MF_TR2W(11)
+    // rows nc - 1 .. 64 of the triangle: x_i lives in t1; columns < 64 (t0) lie left of every one of them
+    if constexpr (TWO) if (nc > 64)
+        mf_pipe8(nc - 64,
+            [&](int s0, double (&p0)[8], double (&p1)[8]) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int i = nc - 1 - (s0 + q), ii = i >= 64 ? i : 64;
+                    p0[q] = L0[ii]; p1[q] = L1[ii];
+                }
+            },
+            [&](int s0, double (&p0)[8], double (&p1)[8]) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    // step s reads lane nc - 65 - s of t1: a valid step iff that lane index is >= 0
+                    const int l = nc - 65 - (s0 + q);
+                    const int lo = __builtin_amdgcn_readlane(__double2loint(t1), l), hi = __builtin_amdgcn_readlane(__double2hiint(t1), l);
+                    const double xi = __hiloint2double(l >= 0 ? hi : 0, l >= 0 ? lo : 0);
+                    t0 -= p0[q] * xi;
+                    t1 -= p1[q] * xi;
+                }
+            });
+    // rows min(nc, 64) - 1 .. 1: x_i lives in t0
+    const int h0 = nc < 64 ? nc : 64;
+    mf_pipe8(h0 - 1,
+        [&](int s0, double (&p0)[8], double (&p1)[8]) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i = h0 - 1 - (s0 + q), ii = i >= 1 ? i : 1;
+                p0[q] = L0[ii];
+            }
+        },
+        [&](int s0, double (&p0)[8], double (&p1)[8]) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int l = h0 - 1 - (s0 + q);
+                const int lo = __builtin_amdgcn_readlane(__double2loint(t0), l), hi = __builtin_amdgcn_readlane(__double2hiint(t0), l);
+                t0 -= p0[q] * __hiloint2double(l >= 1 ? hi : 0, l >= 1 ? lo : 0);
+            }
+        });
+    MF_TR2W(12)
     if (i0 < nc) { xtop[F.xloc + i0] = t0; xg[F.first + i0] = t0; }
-    if (i1 < nc) { xtop[F.xloc + i1] = t1; xg[F.first + i1] = t1; }
+    if constexpr (TWO) if (i1 < nc) { xtop[F.xloc + i1] = t1; xg[F.first + i1] = t1; }
 }
 
 __global__ __launch_bounds__(256) void k_mf_solve_top2(DV d, int want, int do_fwd)
@@ -1252,12 +1374,25 @@ __global__ __launch_bounds__(256) void k_mf_solve_top2(DV d, int want, int do_fw
     const int n = M.top_n, next = M.top_next;
     double *buf0 = mf_lds, *buf1 = buf0 + M.top_buf0, *uvec = buf1 + M.top_buf1 + 128, *xtop = uvec + next + M.top_utotal,
            *ytop = xtop + M.top_xtotal;
-    const MfTopFront *T = M.top_fr;
+    int *recs = reinterpret_cast<int *>(ytop + M.top_xtotal);       // the front records, staged once: [n][16]
     // steps: forward over fronts 0 .. n-1, then backward n-1 .. 0 (the root does both in its step); or backward only
     const int nsteps = do_fwd ? 2 * n - 1 : n;
 #define MF_TOP_FRONT_OF(j) (do_fwd ? ((j) < n ? (j) : 2 * n - 2 - (j)) : n - 1 - (j))
-    MfTopFront F = T[MF_TOP_FRONT_OF(0)];
-    if (do_fwd) for (int t = tid; t < next; t += 256) uvec[t] = arena[M.top_ext[t]];
+    // record k out of LDS into scalar registers (every lane reads the same words)
+    auto rec = [&](int k) {
+        MfTopFront R;
+        int *w = reinterpret_cast<int *>(&R);
+#pragma unroll
+        for (int q = 0; q < 13; ++q) w[q] = __builtin_amdgcn_readfirstlane(recs[16 * k + q]);
+        return R;
+    };
+    {
+        const int *Tg = reinterpret_cast<const int *>(M.top_fr);
+        for (int t = tid; t < 16 * n; t += 256) recs[t] = Tg[t];
+        if (do_fwd) for (int t = tid; t < next; t += 256) uvec[t] = arena[M.top_ext[t]];
+    }
+    lds_barrier();
+    MfTopFront F = rec(MF_TOP_FRONT_OF(0));
     {
         const int k0 = MF_TOP_FRONT_OF(0);
         mf_top_load<4>(M, F, (k0 & 1) ? buf1 : buf0, arena, dinv, do_fwd ? xg : vv, wave, lane);
@@ -1266,19 +1401,34 @@ __global__ __launch_bounds__(256) void k_mf_solve_top2(DV d, int want, int do_fw
     for (int j = 0; j < nsteps; ++j) {
         const int k = MF_TOP_FRONT_OF(j);
         const int kn = j + 1 < nsteps ? MF_TOP_FRONT_OF(j + 1) : -1;
-        MfTopFront Fn = F;
-        if (kn >= 0) Fn = T[kn];
         double *Bf = (k & 1) ? buf1 : buf0;
+        MF_TR2S(0, 4)
         if (wave == 0) {
+#ifdef SQPHIP_MF_TRACE
+            const int trj = inst == 0 && j < 64 ? (do_fwd ? 64 : 0) + j : -1;
+#else
+            const int trj = -1;
+#endif
             const bool fwd = do_fwd && j < n;
-            if (fwd) mf_top_fwd(F, Bf, uvec, next, ytop, vv, lane);
-            if (!fwd || j == n - 1) mf_top_bwd(F, Bf, do_fwd ? ytop + F.xloc : Bf + F.nc * F.ll + F.nc, xtop, xg, lane);
+            // (a front of up to 64 rows needs one register per lane, a taller one two: rows / columns i and i + 64)
+            const double *vs = do_fwd ? ytop + F.xloc : Bf + F.nc * F.ll + F.nc;
+            if (fwd) {
+                if (F.nc + F.nr <= 64) mf_top_fwd<false>(F, Bf, uvec, next, ytop, vv, lane, trj);
+                else mf_top_fwd<true>(F, Bf, uvec, next, ytop, vv, lane, trj);
+            }
+            if (!fwd || j == n - 1) {
+                if (F.nc <= 64) mf_top_bwd<false>(F, Bf, vs, xtop, xg, lane, trj);
+                else mf_top_bwd<true>(F, Bf, vs, xtop, xg, lane, trj);
+            }
+            if (kn >= 0) F = rec(kn);
         } else if (kn >= 0) {
+            F = rec(kn);
             const double *bsrc = do_fwd ? (j + 1 < n ? xg : nullptr) : vv;
-            mf_top_load<3>(M, Fn, (kn & 1) ? buf1 : buf0, arena, dinv, bsrc, wave - 1, lane);
+            mf_top_load<3>(M, F, (kn & 1) ? buf1 : buf0, arena, dinv, bsrc, wave - 1, lane);
         }
+        MF_TR2S(1, 5)
         lds_barrier();
-        F = Fn;
+        MF_TR2S(2, 6)
     }
 #undef MF_TOP_FRONT_OF
 }
