@@ -242,7 +242,7 @@ MfPlan mf_build_plan(int n, int m, const std::vector<int> &kpos, int mk, const s
         for (int s = 0; s < S.ns; ++s) {
             if (S.sn_level[s] < P.top_level) continue;
             const int nc = S.sn_nc[s], nr = S.sn_nr[s], fs = nc + nr;
-            if (fs > 128) { ok = false; break; }
+            if (fs > 128 || nc > 84) { ok = false; break; }      // two rows per lane; 28 columns per loader wave (MF_TOP_CH)
             kof[s] = (int)P.top_fr.size();
             MfTopFront F{s, nc, nr, S.sn_first[s], (int)P.off[s], fs | 1, P.top_xtotal, P.top_utotal, 0, 0, 0, 0, 0, 0, 0, 0};
             P.top_xtotal += nc; P.top_utotal += nr;

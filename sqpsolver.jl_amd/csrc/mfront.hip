@@ -1106,86 +1106,99 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// loader wave lw of NLW: image of the front's L (rows below the diagonal of its nc columns), 1 / D, bsrc (right-hand
-// side or D^-1 L^-1 b; may be null), gather pointers / sources / row indices -> LDS buffer Bf
+// What a loader wave holds of a front between requesting it and writing it to LDS: its share of the image of L (rows
+// below the diagonal of the nc columns: columns lw, lw + NLW, ...; rows lane and lane + 64), and one of the small
+// vectors (1 / D and the right-hand side or D^-1 L^-1 b; the LDS indices of the rows; gather pointers; gather sources).
+constexpr int MF_TOP_CH = 28;                    // columns per loader wave (three loaders: fronts of up to 84 columns)
+struct MfTopStage { double v0[MF_TOP_CH], v1[MF_TOP_CH], sd0, sd1, sb0, sb1; int si0, si1, sg0, sg1, sg2, ss0, ss1; };
+
+// request: every load of the wave in flight at once, nothing waited for
 template <int NLW>
-__device__ __forceinline__ void mf_top_load(const MfDev &M, const MfTopFront &F, double *Bf, const double *arena,
-                                            const double *dinv, const double *bsrc, int lw, int lane)
+__device__ __forceinline__ void mf_top_issue(const MfDev &M, const MfTopFront &F, const double *arena, const double *dinv,
+                                             const double *bsrc, int lw, int lane, MfTopStage &S)
 {
-    const int nc = F.nc, nr = F.nr, fs = F.nc + F.nr, ld = fs + 1, ll = F.ll;
+    const int nc = F.nc, nr = F.nr, fs = F.nc + F.nr, ld = fs + 1;
     const double *G = arena + F.off;
-    double *dv = Bf + nc * ll, *bv = dv + nc;
-    int *gp = reinterpret_cast<int *>(bv + nc), *gs = gp + fs + 1, *rl = gs + F.nsrc;
-    // the small vectors ride with the first batch of image loads: EVERYTHING a wave fetches is requested before it waits
-    // once and writes to LDS (one exposed round trip per front; requested one after the other they were three)
-    double sd0 = 0.0, sd1 = 0.0, sb0 = 0.0, sb1 = 0.0;
-    int si0 = 0, si1 = 0, si2 = 0, sg0 = 0, sg1 = 0, sg2 = 0, sg3 = 0;
     const int i0 = lane, i1 = lane + 64;
+    S.sd0 = S.sd1 = S.sb0 = S.sb1 = 0.0;
+    S.si0 = S.si1 = S.sg0 = S.sg1 = S.sg2 = S.ss0 = S.ss1 = 0;
     if (lw == 0) {
-        if (i0 < nc) { sd0 = dinv[F.first + i0]; if (bsrc) sb0 = bsrc[F.first + i0]; }
-        if (i1 < nc) { sd1 = dinv[F.first + i1]; if (bsrc) sb1 = bsrc[F.first + i1]; }
+        if (i0 < nc) { S.sd0 = dinv[F.first + i0]; if (bsrc) S.sb0 = bsrc[F.first + i0]; }
+        if (i1 < nc) { S.sd1 = dinv[F.first + i1]; if (bsrc) S.sb1 = bsrc[F.first + i1]; }
     }
     if (lw == 1 % NLW) {
-        if (i0 < nr) si0 = M.top_rows[F.rloc + i0];
-        if (i1 < nr) si1 = M.top_rows[F.rloc + i1];
+        if (i0 < nr) S.si0 = M.top_rows[F.rloc + i0];
+        if (i1 < nr) S.si1 = M.top_rows[F.rloc + i1];
     }
     if (lw == 2 % NLW) {
-        if (i0 <= fs) sg0 = M.top_gptr[F.gptr + i0];
-        if (i1 <= fs) sg1 = M.top_gptr[F.gptr + i1];
-        if (lane + 128 <= fs) sg2 = M.top_gptr[F.gptr + lane + 128];
+        if (i0 <= fs) S.sg0 = M.top_gptr[F.gptr + i0];
+        if (i1 <= fs) S.sg1 = M.top_gptr[F.gptr + i1];
+        if (lane + 128 <= fs) S.sg2 = M.top_gptr[F.gptr + lane + 128];
     }
     if (lw == NLW - 1) {
-        if (i0 < F.nsrc) si2 = M.top_gsrc[F.gsrc0 + i0];
-        if (i1 < F.nsrc) sg3 = M.top_gsrc[F.gsrc0 + i1];
+        if (i0 < F.nsrc) S.ss0 = M.top_gsrc[F.gsrc0 + i0];
+        if (i1 < F.nsrc) S.ss1 = M.top_gsrc[F.gsrc0 + i1];
     }
-    constexpr int CH = 28;                       // columns per wave with all their loads in flight at once
+    // the image: plain loads at clamped rows (a lane beyond the front re-reads its last row), 32-bit offsets from one
+    // base, the only test per column a scalar one -- the loader waves are bound by the instructions they issue, not by
+    // the memory behind them (with a predicate per lane and load: ~1100 instructions per front and wave)
+    const unsigned r0 = i0 < fs ? i0 : fs - 1, r1 = i1 < fs ? i1 : fs - 1;
     if (fs <= 64) {
-        for (int c0 = lw; c0 < nc; c0 += CH * NLW) {
-            double v0[CH];
 #pragma unroll
-            for (int q = 0; q < CH; ++q) {
-                const int c = c0 + q * NLW;
-                v0[q] = (c < nc && lane > c && lane < fs) ? G[(long)c * ld + lane] : 0.0;
-            }
-#pragma unroll
-            for (int q = 0; q < CH; ++q) {
-                const int c = c0 + q * NLW;
-                if (c < nc && lane < fs) Bf[c * ll + lane] = v0[q];
-            }
+        for (int q = 0; q < MF_TOP_CH; ++q) {
+            const int c = lw + q * NLW;
+            S.v0[q] = 0.0; S.v1[q] = 0.0;
+            if (c < nc) S.v0[q] = G[(unsigned)(c * ld) + r0];
         }
     } else {
-        for (int c0 = lw; c0 < nc; c0 += CH * NLW) {
-            double v0[CH], v1[CH];
 #pragma unroll
-            for (int q = 0; q < CH; ++q) {
-                const int c = c0 + q * NLW;
-                v0[q] = (c < nc && lane > c) ? G[(long)c * ld + lane] : 0.0;
-                v1[q] = (c < nc && lane + 64 > c && lane + 64 < fs) ? G[(long)c * ld + lane + 64] : 0.0;
-            }
+        for (int q = 0; q < MF_TOP_CH; ++q) {
+            const int c = lw + q * NLW;
+            S.v0[q] = 0.0; S.v1[q] = 0.0;
+            if (c < nc) { S.v0[q] = G[(unsigned)(c * ld) + r0]; S.v1[q] = G[(unsigned)(c * ld) + r1]; }
+        }
+    }
+}
+// ... and write what has arrived to the front's LDS buffer (zeros on and above the diagonal: the chains read unmasked)
+template <int NLW>
+__device__ __forceinline__ void mf_top_commit(const MfDev &M, const MfTopFront &F, double *Bf, bool with_b, int lw, int lane,
+                                              const MfTopStage &S)
+{
+    const int nc = F.nc, nr = F.nr, fs = F.nc + F.nr, ll = F.ll;
+    double *dv = Bf + nc * ll, *bv = dv + nc;
+    int *gp = reinterpret_cast<int *>(bv + nc), *gs = gp + fs + 1, *rl = gs + F.nsrc;
+    const int i0 = lane, i1 = lane + 64;
+    const int r0 = i0 < fs ? i0 : fs - 1, r1 = i1 < fs ? i1 : fs - 1;      // (lanes beyond the front write their last row again)
+    if (fs <= 64) {
 #pragma unroll
-            for (int q = 0; q < CH; ++q) {
-                const int c = c0 + q * NLW;
-                if (c < nc) { Bf[c * ll + lane] = v0[q]; if (lane + 64 < fs) Bf[c * ll + lane + 64] = v1[q]; }
-            }
+        for (int q = 0; q < MF_TOP_CH; ++q) {
+            const int c = lw + q * NLW;
+            if (c < nc) Bf[c * ll + r0] = r0 > c ? S.v0[q] : 0.0;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < MF_TOP_CH; ++q) {
+            const int c = lw + q * NLW;
+            if (c < nc) { Bf[c * ll + r0] = r0 > c ? S.v0[q] : 0.0; Bf[c * ll + r1] = r1 > c ? S.v1[q] : 0.0; }
         }
     }
     if (lw == 0) {
-        if (i0 < nc) { dv[i0] = sd0; if (bsrc) bv[i0] = sb0; }
-        if (i1 < nc) { dv[i1] = sd1; if (bsrc) bv[i1] = sb1; }
+        if (i0 < nc) { dv[i0] = S.sd0; if (with_b) bv[i0] = S.sb0; }
+        if (i1 < nc) { dv[i1] = S.sd1; if (with_b) bv[i1] = S.sb1; }
     }
     if (lw == 1 % NLW) {
-        if (i0 < nr) rl[i0] = si0;
-        if (i1 < nr) rl[i1] = si1;
+        if (i0 < nr) rl[i0] = S.si0;
+        if (i1 < nr) rl[i1] = S.si1;
     }
     if (lw == 2 % NLW) {
-        if (i0 <= fs) gp[i0] = sg0;
-        if (i1 <= fs) gp[i1] = sg1;
-        if (lane + 128 <= fs) gp[lane + 128] = sg2;
+        if (i0 <= fs) gp[i0] = S.sg0;
+        if (i1 <= fs) gp[i1] = S.sg1;
+        if (lane + 128 <= fs) gp[lane + 128] = S.sg2;
     }
     if (lw == NLW - 1) {
-        if (i0 < F.nsrc) gs[i0] = si2;
-        if (i1 < F.nsrc) gs[i1] = sg3;
-        for (int i = lane + 128; i < F.nsrc; i += 64) gs[i] = M.top_gsrc[F.gsrc0 + i];      // (a front with more than 128 update sources: rare)
+        if (i0 < F.nsrc) gs[i0] = S.ss0;
+        if (i1 < F.nsrc) gs[i1] = S.ss1;
+        for (int i = lane + 128; i < F.nsrc; i += 64) gs[i] = M.top_gsrc[F.gsrc0 + i];      // (more than 128 update sources: rare)
     }
 }
 
@@ -1296,24 +1309,30 @@ __device__ __forceinline__ void mf_top_bwd(const MfTopFront &F, const double *Bf
     const double xr0 = i0 < nr ? xtop[rl[i0]] : 0.0, xr1 = i1 < nr ? xtop[rl[i1]] : 0.0;
     const double *L0 = Bf + c0 * ll, *L1 = Bf + c1 * ll;          // lane k reads along its column k (ll odd: no bank conflicts)
     MF_TR2W(10)
-    // x_cols -= L21' x_rows: row r of the rows below, x_r read across the wave
-    mf_pipe8(nr,
-        [&](int s0, double (&p0)[8], double (&p1)[8]) {
+    // x_cols -= L21' x_rows: row r of the rows below, x_r read across the wave; four partial sums per column (nothing
+    // in this loop depends on the step before but the accumulation itself: 32 cycles per dependent v_fma_f64)
+    {
+        double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
+        mf_pipe8(nr,
+            [&](int s0, double (&p0)[8], double (&p1)[8]) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int r = s0 + q, rr = r < nr ? r : nr - 1;
-                p0[q] = L0[nc + rr];
-                if constexpr (TWO) p1[q] = L1[nc + rr];
-            }
-        },
-        [&](int s0, double (&p0)[8], double (&p1)[8]) {
+                for (int q = 0; q < 8; ++q) {
+                    const int r = s0 + q, rr = r < nr ? r : nr - 1;
+                    p0[q] = L0[nc + rr];
+                    if constexpr (TWO) p1[q] = L1[nc + rr];
+                }
+            },
+            [&](int s0, double (&p0)[8], double (&p1)[8]) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const double xr = s0 < 64 ? mf_pivot(xr0, s0 + q, nr) : mf_pivot(xr1, s0 + q - 64, nr - 64);     // (blocks of eight never straddle 64)
-                t0 -= p0[q] * xr;
-                if constexpr (TWO) t1 -= p1[q] * xr;
-            }
-        });
+                for (int q = 0; q < 8; ++q) {
+                    const double xr = s0 < 64 ? mf_pivot(xr0, s0 + q, nr) : mf_pivot(xr1, s0 + q - 64, nr - 64);     // (blocks of eight never straddle 64)
+                    a0[q & 3] += p0[q] * xr;
+                    if constexpr (TWO) a1[q & 3] += p1[q] * xr;
+                }
+            });
+        t0 -= (a0[0] + a0[1]) + (a0[2] + a0[3]);
+        if constexpr (TWO) t1 -= (a1[0] + a1[1]) + (a1[2] + a1[3]);
+    }
     MF_TR2W(11)
     // rows nc - 1 .. 64 of the triangle: x_i lives in t1; columns < 64 (t0) lie left of every one of them
     if constexpr (TWO) if (nc > 64)
@@ -1386,18 +1405,35 @@ __global__ __launch_bounds__(256) void k_mf_solve_top2(DV d, int want, int do_fw
         for (int q = 0; q < 13; ++q) w[q] = __builtin_amdgcn_readfirstlane(recs[16 * k + q]);
         return R;
     };
-    {
-        const int *Tg = reinterpret_cast<const int *>(M.top_fr);
-        for (int t = tid; t < 16 * n; t += 256) recs[t] = Tg[t];
-        if (do_fwd) for (int t = tid; t < next; t += 256) uvec[t] = arena[M.top_ext[t]];
-    }
-    lds_barrier();
-    MfTopFront F = rec(MF_TOP_FRONT_OF(0));
+    // prologue, one round trip deep: the first front straight from its global record (all four waves fetch), the records
+    // and the updates from below the top alongside
+    MfTopStage St;
+    MfTopFront F;
     {
         const int k0 = MF_TOP_FRONT_OF(0);
-        mf_top_load<4>(M, F, (k0 & 1) ? buf1 : buf0, arena, dinv, do_fwd ? xg : vv, wave, lane);
+        const int *Tg = reinterpret_cast<const int *>(M.top_fr);
+        int *w = reinterpret_cast<int *>(&F);
+#pragma unroll
+        for (int q = 0; q < 13; ++q) w[q] = __builtin_amdgcn_readfirstlane(Tg[16 * k0 + q]);
+        int xs[4] = {0, 0, 0, 0};
+        if (do_fwd) for (int t = tid, q = 0; t < next && q < 4; t += 256, ++q) xs[q] = M.top_ext[t];
+        mf_top_issue<4>(M, F, arena, dinv, do_fwd ? xg : vv, wave, lane, St);
+        for (int t = tid; t < 16 * n; t += 256) recs[t] = Tg[t];
+        if (do_fwd) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (tid + 256 * q < next) uvec[tid + 256 * q] = arena[xs[q]];
+            for (int t = tid + 1024; t < next; t += 256) uvec[t] = arena[M.top_ext[t]];
+        }
+        mf_top_commit<4>(M, F, (k0 & 1) ? buf1 : buf0, true, wave, lane, St);
     }
     lds_barrier();
+    // the loader waves run one front ahead of the buffer they fill: during step j they write front(j + 1), requested a
+    // whole step ago, into the buffer front(j - 1) has left, and request front(j + 2); the round trip of a request
+    // (~3 us here: the factor of an instance is cold) overlaps a whole step of arithmetic
+    if (wave > 0 && nsteps > 1) {
+        const MfTopFront F1 = rec(MF_TOP_FRONT_OF(1));
+        mf_top_issue<3>(M, F1, arena, dinv, do_fwd ? (1 < n ? xg : nullptr) : vv, wave - 1, lane, St);
+    }
     for (int j = 0; j < nsteps; ++j) {
         const int k = MF_TOP_FRONT_OF(j);
         const int kn = j + 1 < nsteps ? MF_TOP_FRONT_OF(j + 1) : -1;
@@ -1422,9 +1458,13 @@ __global__ __launch_bounds__(256) void k_mf_solve_top2(DV d, int want, int do_fw
             }
             if (kn >= 0) F = rec(kn);
         } else if (kn >= 0) {
-            F = rec(kn);
-            const double *bsrc = do_fwd ? (j + 1 < n ? xg : nullptr) : vv;
-            mf_top_load<3>(M, F, (kn & 1) ? buf1 : buf0, arena, dinv, bsrc, wave - 1, lane);
+            const MfTopFront Fn = rec(kn);
+            const bool with_b = do_fwd ? j + 1 < n : true;
+            mf_top_commit<3>(M, Fn, (kn & 1) ? buf1 : buf0, with_b, wave - 1, lane, St);
+            if (j + 2 < nsteps) {
+                const MfTopFront F2 = rec(MF_TOP_FRONT_OF(j + 2));
+                mf_top_issue<3>(M, F2, arena, dinv, do_fwd ? (j + 2 < n ? xg : nullptr) : vv, wave - 1, lane, St);
+            }
         }
         MF_TR2S(1, 5)
         lds_barrier();
