@@ -221,6 +221,16 @@ MfPlan mf_build_plan(int n, int m, const std::vector<int> &kpos, int mk, const s
         L.tiles = big_solve ? 64 : maxfs;
         L.cls = std::max(4 * L.tiles, maxfs + 16);                     // doubles of the vector area (cls is free in solve launches)
         L.lds_bytes = 8 * (L.cls + lcap);
+        {   // LDS-staged kernels: four waves x (64-entry vector + image nc x ll) or one front of up to 128 rows (128 + image)
+            int wimg = 0; long bigimg = 0; bool ok2 = big_solve;
+            for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; ++q) {
+                const int s = S.level_sn[q], nc = S.sn_nc[s], fs = nc + S.sn_nr[s];
+                if (fs > 128 || nc > 112) { ok2 = false; break; }
+                if (fs > 64) bigimg = std::max(bigimg, (long)nc * (fs | 1)); else wimg = std::max(wimg, nc * (fs | 1));
+            }
+            const long lds2 = 8 * std::max(4L * (64 + wimg), 128 + bigimg);
+            if (ok2 && lds2 <= 150 * 1024) { L.wimg = wimg; L.lds2 = (int)lds2; }
+        }
         if (!top) { P.fwd.push_back(L); continue; }
         if (l == P.top_level) P.top.begin = L.begin;
         P.top.count += L.count;

@@ -1230,27 +1230,14 @@ __device__ __forceinline__ double mf_pivot(double x, int k, int lim)
     return __hiloint2double(k < lim ? hi : 0, k < lim ? lo : 0);
 }
 
-// forward substitution of one top front by one wave; uvec = [updates from below the top | updates of top fronts]
+// The two chains on an LDS image Bf of a front's L (column-major, leading dimension ll, zeros on and above the diagonal),
+// by one wave.  Forward: lane i holds y_i (y0) and y_{i + 64} (y1; TWO: the front has more than 64 rows) of the
+// front's fs rows; on return rows < nc hold L11^-1 y, rows >= nc the update y_i - L21 (L11^-1 y).
 template <bool TWO>
-__device__ __forceinline__ void mf_top_fwd(const MfTopFront &F, const double *Bf, double *uvec, int next, double *ytop,
-                                           double *vv, int lane, int trj)
+__device__ __forceinline__ void mf_chain_fwd(const double *Bf, int ll, int nc, int fs, int lane, double &y0, double &y1)
 {
-    const int nc = F.nc, fs = F.nc + F.nr, ll = F.ll;
-    const double *dv = Bf + nc * ll, *bv = dv + nc;
-    const int *gp = reinterpret_cast<const int *>(bv + nc), *gs = gp + fs + 1;
     const int i0 = lane, i1 = lane + 64;
     const int r0 = i0 < fs ? i0 : 0, r1 = i1 < fs ? i1 : 0;
-    double y0 = i0 < nc ? bv[i0] : 0.0, y1 = (TWO && i1 < nc) ? bv[i1] : 0.0;
-    {   // updates of the children, sources in list order (both rows of a lane side by side: one chain of LDS round trips)
-        const int q0 = gp[r0], e0 = i0 < fs ? gp[r0 + 1] : q0, q1 = TWO ? gp[r1] : 0, e1 = (TWO && i1 < fs) ? gp[r1 + 1] : q1;
-        const int cnt = max(e0 - q0, e1 - q1);
-        for (int t = 0; t < cnt; ++t) {
-            const int sa = q0 + t < e0 ? gs[q0 + t] : -1, sb = (TWO && q1 + t < e1) ? gs[q1 + t] : -1;
-            if (sa >= 0) y0 += uvec[sa];
-            if (TWO && sb >= 0) y1 += uvec[sb];
-        }
-    }
-    MF_TR2W(8)
     // columns 0 .. 63: y_k lives in y0; rows 64.. (y1) lie below every one of them
     const int n0 = nc < 64 ? nc : 64;
     const double *R0 = Bf + r0, *R1 = Bf + r1;
@@ -1285,30 +1272,16 @@ __device__ __forceinline__ void mf_top_fwd(const MfTopFront &F, const double *Bf
 #pragma unroll
                 for (int q = 0; q < 8; ++q) y1 -= p1[q] * mf_pivot(y1, s0 + q, nc - 64);
             });
-    MF_TR2W(9)
-    if (i0 < nc) { const double v = y0 * dv[i0]; ytop[F.xloc + i0] = v; vv[F.first + i0] = v; }
-    else if (i0 < fs) uvec[next + F.uoff + i0 - nc] = y0;
-    if constexpr (TWO) {
-        if (i1 < nc) { const double v = y1 * dv[i1]; ytop[F.xloc + i1] = v; vv[F.first + i1] = v; }
-        else if (i1 < fs) uvec[next + F.uoff + i1 - nc] = y1;
-    }
 }
-
-// backward substitution of one top front by one wave: x_cols = L11^-T (vs - L21' x_rows); vs = D^-1 L^-1 b of its columns.
-// TWO: more than 64 columns (a second register per lane: column lane + 64)
+// Backward: lane k holds t_k (t0) and t_{k + 64} (t1; TWO: more than 64 columns) = D^-1 L^-1 b of the front's columns
+// and x of its rows below (xr0: row lane, xr1: row lane + 64); on return t = L11^-T (t - L21' x_rows).
 template <bool TWO>
-__device__ __forceinline__ void mf_top_bwd(const MfTopFront &F, const double *Bf, const double *vs, double *xtop, double *xg,
-                                           int lane, int trj)
+__device__ __forceinline__ void mf_chain_bwd(const double *Bf, int ll, int nc, int nr, int lane, double xr0, double xr1,
+                                             double &t0, double &t1)
 {
-    const int nc = F.nc, nr = F.nr, fs = nc + nr, ll = F.ll;
-    const double *bv = Bf + nc * ll + nc;
-    const int *rl = reinterpret_cast<const int *>(bv + nc) + fs + 1 + F.nsrc;
     const int i0 = lane, i1 = lane + 64;
     const int c0 = i0 < nc ? i0 : 0, c1 = i1 < nc ? i1 : 0;
-    double t0 = i0 < nc ? vs[i0] : 0.0, t1 = (TWO && i1 < nc) ? vs[i1] : 0.0;
-    const double xr0 = i0 < nr ? xtop[rl[i0]] : 0.0, xr1 = i1 < nr ? xtop[rl[i1]] : 0.0;
     const double *L0 = Bf + c0 * ll, *L1 = Bf + c1 * ll;          // lane k reads along its column k (ll odd: no bank conflicts)
-    MF_TR2W(10)
     // x_cols -= L21' x_rows: row r of the rows below, x_r read across the wave; four partial sums per column (nothing
     // in this loop depends on the step before but the accumulation itself: 32 cycles per dependent v_fma_f64)
     {
@@ -1333,7 +1306,6 @@ __device__ __forceinline__ void mf_top_bwd(const MfTopFront &F, const double *Bf
         t0 -= (a0[0] + a0[1]) + (a0[2] + a0[3]);
         if constexpr (TWO) t1 -= (a1[0] + a1[1]) + (a1[2] + a1[3]);
     }
-    MF_TR2W(11)
     // rows nc - 1 .. 64 of the triangle: x_i lives in t1; columns < 64 (t0) lie left of every one of them
     if constexpr (TWO) if (nc > 64)
         mf_pipe8(nc - 64,
@@ -1373,6 +1345,53 @@ __device__ __forceinline__ void mf_top_bwd(const MfTopFront &F, const double *Bf
                 t0 -= p0[q] * __hiloint2double(l >= 1 ? hi : 0, l >= 1 ? lo : 0);
             }
         });
+}
+
+// forward substitution of one top front by one wave; uvec = [updates from below the top | updates of top fronts]
+template <bool TWO>
+__device__ __forceinline__ void mf_top_fwd(const MfTopFront &F, const double *Bf, double *uvec, int next, double *ytop,
+                                           double *vv, int lane, int trj)
+{
+    const int nc = F.nc, fs = F.nc + F.nr, ll = F.ll;
+    const double *dv = Bf + nc * ll, *bv = dv + nc;
+    const int *gp = reinterpret_cast<const int *>(bv + nc), *gs = gp + fs + 1;
+    const int i0 = lane, i1 = lane + 64;
+    const int r0 = i0 < fs ? i0 : 0, r1 = i1 < fs ? i1 : 0;
+    double y0 = i0 < nc ? bv[i0] : 0.0, y1 = (TWO && i1 < nc) ? bv[i1] : 0.0;
+    {   // updates of the children, sources in list order (both rows of a lane side by side: one chain of LDS round trips)
+        const int q0 = gp[r0], e0 = i0 < fs ? gp[r0 + 1] : q0, q1 = TWO ? gp[r1] : 0, e1 = (TWO && i1 < fs) ? gp[r1 + 1] : q1;
+        const int cnt = max(e0 - q0, e1 - q1);
+        for (int t = 0; t < cnt; ++t) {
+            const int sa = q0 + t < e0 ? gs[q0 + t] : -1, sb = (TWO && q1 + t < e1) ? gs[q1 + t] : -1;
+            if (sa >= 0) y0 += uvec[sa];
+            if (TWO && sb >= 0) y1 += uvec[sb];
+        }
+    }
+    MF_TR2W(8)
+    mf_chain_fwd<TWO>(Bf, ll, nc, fs, lane, y0, y1);
+    MF_TR2W(9)
+    if (i0 < nc) { const double v = y0 * dv[i0]; ytop[F.xloc + i0] = v; vv[F.first + i0] = v; }
+    else if (i0 < fs) uvec[next + F.uoff + i0 - nc] = y0;
+    if constexpr (TWO) {
+        if (i1 < nc) { const double v = y1 * dv[i1]; ytop[F.xloc + i1] = v; vv[F.first + i1] = v; }
+        else if (i1 < fs) uvec[next + F.uoff + i1 - nc] = y1;
+    }
+}
+
+// backward substitution of one top front by one wave: x_cols = L11^-T (vs - L21' x_rows); vs = D^-1 L^-1 b of its columns.
+// TWO: more than 64 columns (a second register per lane: column lane + 64)
+template <bool TWO>
+__device__ __forceinline__ void mf_top_bwd(const MfTopFront &F, const double *Bf, const double *vs, double *xtop, double *xg,
+                                           int lane, int trj)
+{
+    const int nc = F.nc, nr = F.nr, fs = nc + nr, ll = F.ll;
+    const double *bv = Bf + nc * ll + nc;
+    const int *rl = reinterpret_cast<const int *>(bv + nc) + fs + 1 + F.nsrc;
+    const int i0 = lane, i1 = lane + 64;
+    double t0 = i0 < nc ? vs[i0] : 0.0, t1 = (TWO && i1 < nc) ? vs[i1] : 0.0;
+    const double xr0 = i0 < nr ? xtop[rl[i0]] : 0.0, xr1 = i1 < nr ? xtop[rl[i1]] : 0.0;
+    MF_TR2W(10)
+    mf_chain_bwd<TWO>(Bf, ll, nc, nr, lane, xr0, xr1, t0, t1);
     MF_TR2W(12)
     if (i0 < nc) { xtop[F.xloc + i0] = t0; xg[F.first + i0] = t0; }
     if constexpr (TWO) if (i1 < nc) { xtop[F.xloc + i1] = t1; xg[F.first + i1] = t1; }
@@ -1474,6 +1493,121 @@ __global__ __launch_bounds__(256) void k_mf_solve_top2(DV d, int want, int do_fw
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Level launches with the chains of the streamed kernel (k_mf_fwd2 / k_mf_bwd2).  k_mf_fwd / k_mf_bwd walk a front
+// straight out of the arena: descriptor, right-hand side, gather entries, their sources, then the columns of L a few
+// at a time inside the dependent loop -- six to eight exposed round trips of ~3 us for a front whose arithmetic takes
+// one.  Here a wave requests the whole image of its front, the vectors and the gather entries at once (three round
+// trips: descriptor, everything, the gathered sources), stages the image in its LDS buffer and runs mf_chain_fwd /
+// mf_chain_bwd on it; a front of more than 64 rows is fetched by the four waves of the workgroup and solved by one.
+template <int NLW, int CH, bool TWO>
+__device__ __forceinline__ void mf_img_load(const double *G, int ld, int nc, int fs, double *Bf, int ll, int lw, int lane)
+{
+    const int i0 = lane, i1 = lane + 64;
+    const int r0 = i0 < fs ? i0 : fs - 1, r1 = i1 < fs ? i1 : fs - 1;
+    for (int cb = lw; cb < nc; cb += CH * NLW) {
+        double v0[CH], v1[CH];
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+            const int c = cb + q * NLW;
+            v0[q] = 0.0; v1[q] = 0.0;
+            if (c < nc) { v0[q] = G[(unsigned)(c * ld) + (unsigned)r0]; if constexpr (TWO) v1[q] = G[(unsigned)(c * ld) + (unsigned)r1]; }
+        }
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+            const int c = cb + q * NLW;
+            if (c < nc) { Bf[c * ll + r0] = r0 > c ? v0[q] : 0.0; if constexpr (TWO) Bf[c * ll + r1] = r1 > c ? v1[q] : 0.0; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 4) void k_mf_fwd2(DV d, int ibegin, int want, int wimg)
+{
+    const int inst = blockIdx.y;
+    if (d.phase[inst] != want) return;
+    extern __shared__ double mf_lds[];
+    const MfDev &M = d.mf;
+    const int4 it = reinterpret_cast<const int4 *>(M.sol_items)[ibegin + blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool big = it.y == -2;
+    const int s = big ? it.x : (wave == 0 ? it.x : (wave == 1 ? it.y : (wave == 2 ? it.z : it.w)));
+    if (s < 0) return;                                        // (no workgroup barrier on the wave-per-front path)
+    const MfFrontDesc Fd = M.desc[s];
+    const int nc = Fd.nc, nr = Fd.nr, fs = nc + nr, ld = fs + 1, f0 = Fd.first, ll = fs | 1;
+    const int cand = d.ist[inst].sel;
+    const double *arena = mf_arena(d, inst, cand);
+    double *G = mf_arena(d, inst, cand) + Fd.off;
+    const double *b = d.xv + (long)inst * d.Fpad + f0, *dinv = mf_dinv(d, inst, cand) + f0;
+    double *vv = mf_vv(d, inst, cand) + f0;
+    double *y = big ? mf_lds : mf_lds + wave * (64 + wimg), *Bf = y + (big ? 128 : 64);
+    const int i0 = lane, i1 = lane + 64;
+    if (!big || wave == 0) {
+        // the vectors and the gather entries ride with the image loads; only the gathered sources wait for their entries
+        const int t0 = Fd.ev_begin + i0, t1 = Fd.ev_begin + i1;
+        MfGather g0{0, 0, 0, 0}, g1{0, 0, 0, 0};
+        const bool h0 = t0 < Fd.ev_end, h1 = big && t1 < Fd.ev_end;
+        if (h0) g0 = M.ev_ent[t0];
+        if (h1) g1 = M.ev_ent[t1];
+        const double b0 = i0 < nc ? b[i0] : 0.0, b1 = (big && i1 < nc) ? b[i1] : 0.0;
+        const double d0 = i0 < nc ? dinv[i0] : 0.0, d1 = (big && i1 < nc) ? dinv[i1] : 0.0;
+        if (!big) mf_img_load<1, 24, false>(G, ld, nc, fs, Bf, ll, 0, lane);
+        else mf_img_load<4, 14, true>(G, ld, nc, fs, Bf, ll, 0, lane);
+        if (i0 < fs) y[i0] = b0;
+        if (big && i1 < fs) y[i1] = b1;
+        wave_sync();
+        if (h0) { double a = arena[g0.src0]; for (int q = g0.src_begin + 1; q < g0.src_end; ++q) a += arena[M.ev_src[q]]; y[g0.where] += a; }
+        wave_sync();
+        if (h1) { double a = arena[g1.src0]; for (int q = g1.src_begin + 1; q < g1.src_end; ++q) a += arena[M.ev_src[q]]; y[g1.where] += a; }
+        wave_sync();
+        double y0 = i0 < fs ? y[i0] : 0.0, y1 = (big && i1 < fs) ? y[i1] : 0.0;
+        if (big) __syncthreads();                             // the image: four waves wrote it
+        if (!big) { wave_sync(); mf_chain_fwd<false>(Bf, ll, nc, fs, lane, y0, y1); }
+        else mf_chain_fwd<true>(Bf, ll, nc, fs, lane, y0, y1);
+        if (i0 < nc) vv[i0] = y0 * d0; else if (i0 < fs) G[(long)i0 * ld + fs] = y0;
+        if (big) { if (i1 < nc) vv[i1] = y1 * d1; else if (i1 < fs) G[(long)i1 * ld + fs] = y1; }
+    } else {
+        mf_img_load<4, 14, true>(G, ld, nc, fs, Bf, ll, wave, lane);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256, 4) void k_mf_bwd2(DV d, int ibegin, int want, int wimg)
+{
+    const int inst = blockIdx.y;
+    if (d.phase[inst] != want) return;
+    extern __shared__ double mf_lds[];
+    const MfDev &M = d.mf;
+    const int4 it = reinterpret_cast<const int4 *>(M.sol_items)[ibegin + blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool big = it.y == -2;
+    const int s = big ? it.x : (wave == 0 ? it.x : (wave == 1 ? it.y : (wave == 2 ? it.z : it.w)));
+    if (s < 0) return;
+    const MfFrontDesc Fd = M.desc[s];
+    const int nc = Fd.nc, nr = Fd.nr, fs = nc + nr, ld = fs + 1, f0 = Fd.first, ll = fs | 1;
+    const int cand = d.ist[inst].sel;
+    const double *G = mf_arena(d, inst, cand) + Fd.off;
+    double *xg = d.xv + (long)inst * d.Fpad;
+    const double *vv = mf_vv(d, inst, cand) + f0;
+    const int *rows = M.rows + Fd.rowptr;
+    double *Bf = (big ? mf_lds : mf_lds + wave * (64 + wimg)) + (big ? 128 : 64);
+    const int i0 = lane, i1 = lane + 64;
+    if (!big || wave == 0) {
+        const int q0 = i0 < nr ? rows[i0] : -1, q1 = (big && i1 < nr) ? rows[i1] : -1;
+        double t0 = i0 < nc ? vv[i0] : 0.0, t1 = (big && i1 < nc) ? vv[i1] : 0.0;
+        if (!big) mf_img_load<1, 24, false>(G, ld, nc, fs, Bf, ll, 0, lane);
+        else mf_img_load<4, 14, true>(G, ld, nc, fs, Bf, ll, 0, lane);
+        const double xr0 = q0 >= 0 ? xg[q0] : 0.0, xr1 = q1 >= 0 ? xg[q1] : 0.0;
+        if (big) __syncthreads(); else wave_sync();
+        if (nc <= 64) mf_chain_bwd<false>(Bf, ll, nc, nr, lane, xr0, xr1, t0, t1);
+        else mf_chain_bwd<true>(Bf, ll, nc, nr, lane, xr0, xr1, t0, t1);
+        if (i0 < nc) xg[f0 + i0] = t0;
+        if (big && i1 < nc) xg[f0 + i1] = t1;
+    } else {
+        mf_img_load<4, 14, true>(G, ld, nc, fs, Bf, ll, wave, lane);
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 static int mf_generic_solves()
 {
     static const int g = getenv("SQPHIP_MF_GENERIC") ? atoi(getenv("SQPHIP_MF_GENERIC")) : 0;
@@ -1541,9 +1675,16 @@ void mf_solve(Ctx &C, int want, bool skip_fwd)
         hipLaunchKernelGGL(k_mf_solve_inst<16>, dim3(d.B), dim3(1024), (size_t)d.mf.max_front * 8 * 16, s, d, want, skip_fwd ? 0 : 1, generic);
         return;
     }
+    // level launches: the LDS-staged kernels where every front of the level fits them (mfplan.hip: L.wimg >= 0)
+    static const bool lvl2 = !(getenv("SQPHIP_MF_LEVEL2") && atoi(getenv("SQPHIP_MF_LEVEL2")) == 0);
+    static const hipError_t attr_f = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_fwd2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static const hipError_t attr_b = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_bwd2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    SQPHIP_HIP_OK(attr_f); SQPHIP_HIP_OK(attr_b);
     if (!skip_fwd)
-        for (const MfLaunch &L : C.mfp().fwd)
-            hipLaunchKernelGGL(k_mf_fwd, dim3(L.count, d.B), dim3(256), L.lds_bytes, s, d, L.begin, want, generic, L.tiles, L.cls, L.lds_bytes / 8 - L.cls);
+        for (const MfLaunch &L : C.mfp().fwd) {
+            if (lvl2 && !generic && L.wimg >= 0) hipLaunchKernelGGL(k_mf_fwd2, dim3(L.count, d.B), dim3(256), L.lds2, s, d, L.begin, want, L.wimg);
+            else hipLaunchKernelGGL(k_mf_fwd, dim3(L.count, d.B), dim3(256), L.lds_bytes, s, d, L.begin, want, generic, L.tiles, L.cls, L.lds_bytes / 8 - L.cls);
+        }
     if (d.mf.top_n > 0 && !generic) {
         const size_t lds = (size_t)C.mfp().top2_lds_bytes;
         // more than 64 KB of dynamic LDS has to be asked for, once (thread-safe: the instance groups launch concurrently)
@@ -1553,8 +1694,10 @@ void mf_solve(Ctx &C, int want, bool skip_fwd)
     } else if (const MfLaunch &T = C.mfp().top; T.count > 0)
         hipLaunchKernelGGL(k_mf_solve_top, dim3(d.B), dim3(256), T.lds_bytes, s, d, T.begin, T.count, want, skip_fwd ? 0 : 1, generic,
                            T.tiles, T.cls, T.lds_bytes / 8 - T.cls);
-    for (const MfLaunch &L : C.mfp().bwd)
-        hipLaunchKernelGGL(k_mf_bwd, dim3(L.count, d.B), dim3(256), L.lds_bytes, s, d, L.begin, want, generic, L.tiles, L.cls, L.lds_bytes / 8 - L.cls);
+    for (const MfLaunch &L : C.mfp().bwd) {
+        if (lvl2 && !generic && L.wimg >= 0) hipLaunchKernelGGL(k_mf_bwd2, dim3(L.count, d.B), dim3(256), L.lds2, s, d, L.begin, want, L.wimg);
+        else hipLaunchKernelGGL(k_mf_bwd, dim3(L.count, d.B), dim3(256), L.lds_bytes, s, d, L.begin, want, generic, L.tiles, L.cls, L.lds_bytes / 8 - L.cls);
+    }
 }
 
 }  // namespace sqphip

@@ -91,7 +91,9 @@ struct MfGather { int where, src_begin, src_end, src0; };
 // one kernel launch of the factorisation / of a solve sweep: fronts [begin, begin + count) of `sched`, all of one
 // size class.  Factorisation: cls = kernel variant (mfront.hip, mf_factor), tiles = 16-row tiles of the largest front
 // of the launch (sizes the LDS image), lds_bytes = dynamic LDS.
-struct MfLaunch { int begin, count, threads, lds_bytes, cls, tiles; };
+// Solve launches also carry what the LDS-staged kernels (k_mf_fwd2 / k_mf_bwd2) need: wimg = doubles of a wave's image
+// buffer (-1: a front of the level does not fit them), lds2 = their dynamic LDS.
+struct MfLaunch { int begin, count, threads, lds_bytes, cls, tiles; int wimg = -1, lds2 = 0; };
 
 // One front of the narrow top of the assembly tree as the streaming solve kernel (k_mf_solve_top2, mfront.hip) sees it:
 // where its factor lives in the arena, the leading dimension of its LDS image (odd: the transposed reads of the
