@@ -1636,6 +1636,14 @@ void mf_factor(Ctx &C, int want, bool with_rhs)
         // 512 x IEEE-118 5565 / 5507 / 5259, 64 x IEEE-118 1372 / - / 1315, 9241 shape 20.6 / 24.3 / 23.4, IEEE-14 50.9 k /
         // 55.4 k / 53.9 k.  SQPHIP_MF_STATIC_MIN moves the threshold (tests run it at 1 to cover every instantiation).
         const int stat_min = getenv("SQPHIP_MF_STATIC_MIN") ? atoi(getenv("SQPHIP_MF_STATIC_MIN")) : 4;
+        static const bool big_img = [] {
+            if (getenv("SQPHIP_MF_BIG_LDSIMG") && atoi(getenv("SQPHIP_MF_BIG_LDSIMG")) == 0) return false;
+            bool ok = true;
+            ok &= hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_front<6, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+            ok &= hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_front<7, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+            ok &= hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_front<8, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+            return ok;
+        }();
         if (!stat || T > 8 || T < stat_min) {
             if (T <= 2) MF_GENERIC(1, 3, true);
             else if (T <= 4) MF_GENERIC(2, 5, true);
@@ -1650,9 +1658,12 @@ void mf_factor(Ctx &C, int want, bool with_rhs)
         case 3: MF_STATIC(3, 1, true); break;
         case 4: MF_STATIC(4, 2, true); break;
         case 5: MF_STATIC(5, 2, true); break;
-        case 6: MF_STATIC(6, 4, false); break;
-        case 7: MF_STATIC(7, 4, false); break;
-        default: MF_STATIC(8, 4, false); break;
+        // (six to eight tile rows: the image fits the 160 KB of LDS of gfx950 too -- 74 / 100 / 131 KB -- once more than
+        //  64 KB of dynamic LDS has been asked for; only for the handful of fronts of a level near the top of the tree, where
+        //  one workgroup per CU is all there is anyway: +0.3 % on 512 x IEEE-118; SQPHIP_MF_BIG_LDSIMG=0: image in the arena)
+        case 6: if (big_img && L.count <= 8) MF_STATIC(6, 4, true); else MF_STATIC(6, 4, false); break;
+        case 7: if (big_img && L.count <= 8) MF_STATIC(7, 4, true); else MF_STATIC(7, 4, false); break;
+        default: if (big_img && L.count <= 8) MF_STATIC(8, 4, true); else MF_STATIC(8, 4, false); break;
         }
 #undef MF_GENERIC
 #undef MF_STATIC
