@@ -327,8 +327,9 @@ def main():
                     traffic_src = os.path.relpath(tpath, _ROOT)
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "k_mf_values + k_mf_factor2<*> (factor, v_mfma_f64_16x16x4_f64 rank-4 blocks) + "
-                                              "k_mf_fwd / k_mf_bwd (solves)",
+        roofline = {"bound": "hbm", "kernel": "k_mf_values + k_mf_front<*> / k_mf_factor2<*> (factor, v_mfma_f64_16x16x4_f64 rank-4 blocks) + "
+                                              "k_mf_fwd2 / k_mf_bwd2 / k_mf_solve_top2 (solves; k_mf_fwd / k_mf_bwd / k_mf_solve_top where a front "
+                                              "exceeds the LDS-staged kernels)",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "traffic_static": True, "traffic_source": traffic_src,
                     "bytes_per_instance_factorisation": b_sparse, "nnz_k_lower": int(c1["nnz_k"]), "nnz_l": int(c1["nnz_l"]),
