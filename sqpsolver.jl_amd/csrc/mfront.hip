@@ -1636,14 +1636,14 @@ void mf_factor(Ctx &C, int want, bool with_rhs)
         // 512 x IEEE-118 5565 / 5507 / 5259, 64 x IEEE-118 1372 / - / 1315, 9241 shape 20.6 / 24.3 / 23.4, IEEE-14 50.9 k /
         // 55.4 k / 53.9 k.  SQPHIP_MF_STATIC_MIN moves the threshold (tests run it at 1 to cover every instantiation).
         const int stat_min = getenv("SQPHIP_MF_STATIC_MIN") ? atoi(getenv("SQPHIP_MF_STATIC_MIN")) : 4;
-        static const bool big_img = [] {
-            if (getenv("SQPHIP_MF_BIG_LDSIMG") && atoi(getenv("SQPHIP_MF_BIG_LDSIMG")) == 0) return false;
+        static const bool big_attr = [] {
             bool ok = true;
             ok &= hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_front<6, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
             ok &= hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_front<7, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
             ok &= hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_front<8, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
             return ok;
         }();
+        const bool big_img = big_attr && !(getenv("SQPHIP_MF_BIG_LDSIMG") && atoi(getenv("SQPHIP_MF_BIG_LDSIMG")) == 0);     // (read per call: tests flip it)
         if (!stat || T > 8 || T < stat_min) {
             if (T <= 2) MF_GENERIC(1, 3, true);
             else if (T <= 4) MF_GENERIC(2, 5, true);
@@ -1687,7 +1687,7 @@ void mf_solve(Ctx &C, int want, bool skip_fwd)
         return;
     }
     // level launches: the LDS-staged kernels where every front of the level fits them (mfplan.hip: L.wimg >= 0)
-    static const bool lvl2 = !(getenv("SQPHIP_MF_LEVEL2") && atoi(getenv("SQPHIP_MF_LEVEL2")) == 0);
+    const bool lvl2 = !(getenv("SQPHIP_MF_LEVEL2") && atoi(getenv("SQPHIP_MF_LEVEL2")) == 0);      // (read per call: tests flip it)
     static const hipError_t attr_f = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_fwd2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     static const hipError_t attr_b = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_bwd2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     SQPHIP_HIP_OK(attr_f); SQPHIP_HIP_OK(attr_b);
