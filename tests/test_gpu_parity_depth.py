@@ -9,7 +9,7 @@ scripts/gpu_decisions_depth.py: 4 of 12 random bench scenarios take a different 
 between iterations 13 and 23, |dx| up to 0.18 at iteration 25).  What does hold, and is asserted here, is parity of
 every sub-problem along the device's own trajectory: the request the batched run worked on is fetched from the device
 and solved again by the drop-in seat of a fresh context (must reproduce the batched run's status and work counters
-exactly) and by the oracle's seat (same status; step and multipliers at 1e-8 / 1e-7 for the trust-region and correction
+exactly) and by the oracle's seat (same status; step and multipliers at 1e-8 / 1e-6 for the trust-region and correction
 QPs; the optimal VALUE for restoration LPs).  Data behind the tolerances: scripts/gpu_replay_depth.py, 200 sub-problems:
 status 200 / 200, counters 196 / 200 equal, max |dp| 4.3e-9, max |dlambda| 1.1e-8, restoration optimal value 1.9e-7."""
 import os
@@ -90,7 +90,11 @@ def test_subproblems_of_the_bench_run_replay_through_both_seats():
                 assert abs(vg - vo) <= 1e-6 * max(1.0, abs(vo)), (b, vg, vo)
             else:
                 assert rel(rg["p"], ro["p"]) < TOL, (b, rq["mode"])
-                assert rel(rg["lam"], ro["lam"]) < 1e-7 and rel(rg["mult_x_L"] - rg["mult_x_U"], ro["mult_x_L"] - ro["mult_x_U"]) < 1e-7
+                # multipliers: the least determined output of an interior-point solve that stops on a scaled error of 1e-9
+                # (a bound multiplier is mu / gap of the last iterate).  Data: two collections of 200 sub-problems along
+                # two different trajectories of this run (the rounding of the solve kernels changed between them): row
+                # multipliers at most 1.1e-8 and 9.0e-8, reduced costs at most 1.0e-8 and 2.1e-7 of the largest one
+                assert rel(rg["lam"], ro["lam"]) < 1e-6 and rel(rg["mult_x_L"] - rg["mult_x_U"], ro["mult_x_L"] - ro["mult_x_U"]) < 1e-6
     assert n_sub >= 8 * iters - 8 and {O.MODE_QP, O.MODE_SOC, O.MODE_FR} <= modes
     # equal interior-point iteration AND factorisation counts on all but a few sub-problems (degenerate LPs, one
     # infeasible QP in the collection run): two implementations with different elimination orders
