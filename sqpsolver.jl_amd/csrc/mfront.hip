@@ -1636,6 +1636,10 @@ void mf_factor(Ctx &C, int want, bool with_rhs)
         // 512 x IEEE-118 5565 / 5507 / 5259, 64 x IEEE-118 1372 / - / 1315, 9241 shape 20.6 / 24.3 / 23.4, IEEE-14 50.9 k /
         // 55.4 k / 53.9 k.  SQPHIP_MF_STATIC_MIN moves the threshold (tests run it at 1 to cover every instantiation).
         const int stat_min = getenv("SQPHIP_MF_STATIC_MIN") ? atoi(getenv("SQPHIP_MF_STATIC_MIN")) : 4;
+        // four waves instead of two for fronts of four (bit 0) / five (bit 1) tile rows on the levels near the top of the
+        // tree (a handful of fronts: latency, not occupancy, is what counts there): 512 x IEEE-118 7 100 -> 7 154 / 7 297 / 7 326
+        // QP/s with bit 0 / bit 1 / both, same bits (SQPHIP_MF_NW4=0: two waves everywhere)
+        const int nw4 = L.count <= 8 ? (getenv("SQPHIP_MF_NW4") ? atoi(getenv("SQPHIP_MF_NW4")) : 3) : 0;
         static const bool big_attr = [] {
             bool ok = true;
             ok &= hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_front<6, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
@@ -1656,8 +1660,8 @@ void mf_factor(Ctx &C, int want, bool with_rhs)
         case 1: MF_STATIC(1, 1, true); break;
         case 2: MF_STATIC(2, 1, true); break;
         case 3: MF_STATIC(3, 1, true); break;
-        case 4: MF_STATIC(4, 2, true); break;
-        case 5: MF_STATIC(5, 2, true); break;
+        case 4: if (nw4 & 1) MF_STATIC(4, 4, true); else MF_STATIC(4, 2, true); break;
+        case 5: if (nw4 & 2) MF_STATIC(5, 4, true); else MF_STATIC(5, 2, true); break;
         // (six to eight tile rows: the image fits the 160 KB of LDS of gfx950 too -- 74 / 100 / 131 KB -- once more than
         //  64 KB of dynamic LDS has been asked for; only for the handful of fronts of a level near the top of the tree, where
         //  one workgroup per CU is all there is anyway: +0.3 % on 512 x IEEE-118; SQPHIP_MF_BIG_LDSIMG=0: image in the arena)
