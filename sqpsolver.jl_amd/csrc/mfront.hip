@@ -1639,12 +1639,17 @@ void mf_factor(Ctx &C, int want, bool with_rhs)
         // four waves instead of two for fronts of four (bit 0) / five (bit 1) tile rows on the levels near the top of the
         // tree (a handful of fronts: latency, not occupancy, is what counts there): 512 x IEEE-118 7 100 -> 7 154 / 7 297 / 7 326
         // QP/s with bit 0 / bit 1 / both, same bits (SQPHIP_MF_NW4=0: two waves everywhere)
+        // ... and eight instead of four for six to eight tile rows there: 7 323 -> 7 403 QP/s, same bits (SQPHIP_MF_NW8=0: four)
+        const bool nw8 = !(getenv("SQPHIP_MF_NW8") && atoi(getenv("SQPHIP_MF_NW8")) == 0);
         const int nw4 = L.count <= 8 ? (getenv("SQPHIP_MF_NW4") ? atoi(getenv("SQPHIP_MF_NW4")) : 3) : 0;
         static const bool big_attr = [] {
             bool ok = true;
             ok &= hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_front<6, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
             ok &= hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_front<7, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
             ok &= hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_front<8, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+            ok &= hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_front<6, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+            ok &= hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_front<7, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+            ok &= hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_front<8, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
             return ok;
         }();
         const bool big_img = big_attr && !(getenv("SQPHIP_MF_BIG_LDSIMG") && atoi(getenv("SQPHIP_MF_BIG_LDSIMG")) == 0);     // (read per call: tests flip it)
@@ -1665,9 +1670,9 @@ void mf_factor(Ctx &C, int want, bool with_rhs)
         // (six to eight tile rows: the image fits the 160 KB of LDS of gfx950 too -- 74 / 100 / 131 KB -- once more than
         //  64 KB of dynamic LDS has been asked for; only for the handful of fronts of a level near the top of the tree, where
         //  one workgroup per CU is all there is anyway: +0.3 % on 512 x IEEE-118; SQPHIP_MF_BIG_LDSIMG=0: image in the arena)
-        case 6: if (big_img && L.count <= 8) MF_STATIC(6, 4, true); else MF_STATIC(6, 4, false); break;
-        case 7: if (big_img && L.count <= 8) MF_STATIC(7, 4, true); else MF_STATIC(7, 4, false); break;
-        default: if (big_img && L.count <= 8) MF_STATIC(8, 4, true); else MF_STATIC(8, 4, false); break;
+        case 6: if (big_img && L.count <= 8) { if (nw8) MF_STATIC(6, 8, true); else MF_STATIC(6, 4, true); } else MF_STATIC(6, 4, false); break;
+        case 7: if (big_img && L.count <= 8) { if (nw8) MF_STATIC(7, 8, true); else MF_STATIC(7, 4, true); } else MF_STATIC(7, 4, false); break;
+        default: if (big_img && L.count <= 8) { if (nw8) MF_STATIC(8, 8, true); else MF_STATIC(8, 4, true); } else MF_STATIC(8, 4, false); break;
         }
 #undef MF_GENERIC
 #undef MF_STATIC
