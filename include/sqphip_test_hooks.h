@@ -20,6 +20,10 @@ int sqphip_mf_host_solve(int64_t n, int64_t m, int64_t nnzJ, const int64_t *jrow
                          int32_t condense, const double *Jval, const double *Hval, const double *Dd,
                          const double *sigp, const double *hd, const int32_t *rtype, double hsc, double dw,
                          const double *rhs, double *sol, double *dinv_by_unknown, int32_t *npos);
+/* After sqphip_mf_host_solve: relative error of the host replay of the streamed top-of-tree solve (k_mf_solve_top2) from
+ * its own plan arrays against the plain recursion of the same call; -1 when the plan has no such top (a front of more than
+ * 128 rows or 84 columns, or SQPHIP_MF_TOP2=0).  Not thread safe (one global). */
+double sqphip_mf_host_top2_err(void);
 /* Device twin of sqphip_mf_host_solve (kernel-level parity tests): the same Newton matrix, assembled, factorised and
  * solved by the multifrontal kernels in instance `inst` of a context that uses the sparse solver (kkt_mode 2, or 0
  * where it selects it).  sol_fused: right-hand side carried through the factorisation; sol_standalone: the

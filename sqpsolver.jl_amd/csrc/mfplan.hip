@@ -330,6 +330,8 @@ static inline double item_value(const MfItem &it, const MfValues &V)
     }
 }
 
+static double g_top2_err = -1.0;          // last replay of the streamed top solve on the host: relative error, -1: not applicable
+
 void mf_host_factor_solve(const MfPlan &P, const MfValues &V, const double *rhs, double *sol, double *dinv)
 {
     const SparseSym &S = P.S;
@@ -363,6 +365,35 @@ void mf_host_factor_solve(const MfPlan &P, const MfValues &V, const double *rhs,
             v[f0 + k] = A[k * ld + fs];
         }
     }
+    // the streamed top-of-tree solve (k_mf_solve_top2) replayed on the host from ITS plan arrays -- front records, gather
+    // lists whose sources are indices into the vector of updates, row -> index maps -- against the plain recursion above
+    // and below: validates those arrays without a GPU (CPU tests read the error through sqphip_mf_host_top2_err)
+    g_top2_err = -1.0;
+    std::vector<double> xtop, ytop;
+    if (P.top2_lds_bytes > 0) {
+        const int n_ext = (int)P.top_ext.size();
+        std::vector<double> uvec(n_ext + P.top_utotal, 0.0), y;
+        xtop.assign(P.top_xtotal, 0.0); ytop.assign(P.top_xtotal, 0.0);
+        for (int t = 0; t < n_ext; ++t) uvec[t] = F[P.top_ext[t]];
+        double err = 0.0, scale = 0.0;
+        for (const MfTopFront &T : P.top_fr) {
+            const int nc = T.nc, fs = T.nc + T.nr, ld = fs + 1;
+            const double *A = F.data() + T.off;
+            y.assign(fs, 0.0);
+            for (int i = 0; i < fs; ++i) {
+                if (i < nc) y[i] = x[T.first + i];
+                for (int q = P.top_gptr[T.gptr + i]; q < P.top_gptr[T.gptr + i + 1]; ++q) y[i] += uvec[P.top_gsrc[T.gsrc0 + q]];
+            }
+            for (int k = 0; k < nc; ++k)
+                for (int i = k + 1; i < fs; ++i) y[i] -= A[k * ld + i] * y[k];
+            for (int i = 0; i < nc; ++i) {
+                ytop[T.xloc + i] = y[i] * dinv[T.first + i];
+                err = std::max(err, std::fabs(ytop[T.xloc + i] - v[T.first + i])); scale = std::max(scale, std::fabs(v[T.first + i]));
+            }
+            for (int i = nc; i < fs; ++i) uvec[n_ext + T.uoff + i - nc] = y[i];
+        }
+        g_top2_err = err / std::max(scale, 1e-300);
+    }
     // backward: x_cols = L11^-T (z - L21' x_rows), roots first
     for (int s = S.ns - 1; s >= 0; --s) {
         const int nc = S.sn_nc[s], nr = S.sn_nr[s], fs = nc + nr, ld = fs + 1, f0 = S.sn_first[s];
@@ -375,10 +406,33 @@ void mf_host_factor_solve(const MfPlan &P, const MfValues &V, const double *rhs,
             x[f0 + k] = a;
         }
     }
+    if (P.top2_lds_bytes > 0) {
+        double err = 0.0, scale = 0.0;
+        std::vector<double> t;
+        for (int k = (int)P.top_fr.size() - 1; k >= 0; --k) {
+            const MfTopFront &T = P.top_fr[k];
+            const int nc = T.nc, nr = T.nr, fs = nc + nr, ld = fs + 1;
+            const double *A = F.data() + T.off;
+            t.assign(nc, 0.0);
+            for (int c = 0; c < nc; ++c) {
+                t[c] = ytop[T.xloc + c];
+                for (int r = 0; r < nr; ++r) t[c] -= A[c * ld + nc + r] * xtop[P.top_rows[T.rloc + r]];
+            }
+            for (int i = nc - 1; i >= 1; --i)
+                for (int c = 0; c < i; ++c) t[c] -= A[c * ld + i] * t[i];
+            for (int c = 0; c < nc; ++c) {
+                xtop[T.xloc + c] = t[c];
+                err = std::max(err, std::fabs(t[c] - x[T.first + c])); scale = std::max(scale, std::fabs(x[T.first + c]));
+            }
+        }
+        g_top2_err = std::max(g_top2_err, err / std::max(scale, 1e-300));
+    }
     for (int u = 0; u < S.nu; ++u) sol[u] = x[S.pos[u]];
 }
 
 }  // namespace sqphip
+
+extern "C" double sqphip_mf_host_top2_err(void) { return sqphip::g_top2_err; }
 
 // C-ABI test hook (host only, no GPU): plan + host reference of the numeric phase for the NLP structure given as in
 // sqphip_create; values in the library's internal layouts (see include/sqphip.h).

@@ -108,6 +108,12 @@ def mf_host_solve(n, m, jrow, jcol, hrow, hcol, gL, gU, condense, jval, hval, Dd
     return sol, dinv, npos.value
 
 
+def mf_host_top2_err() -> float:
+    """After `mf_host_solve`: relative error of the host replay of the streamed top-of-tree solve from its own plan arrays
+    against the plain recursion of that call (-1: the plan has no such top)."""
+    return float(_lib.lib().sqphip_mf_host_top2_err())
+
+
 class Context:
     """Owns a sqphip_ctx (one NLP structure, `batch` instances)."""
 

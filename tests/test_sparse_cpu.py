@@ -56,6 +56,11 @@ def test_multifrontal_plan_reproduces_a_dense_solve(case, cond, free):
                                         Dd, sigp, hd, rt, 0.7, 1e-3, rhs)
     ref = np.linalg.solve(K, rhs)
     assert np.abs(sol - ref).max() <= 1e-11 * np.abs(ref).max()
+    # the streamed top-of-tree solve (k_mf_solve_top2) replayed on the host from its own plan arrays (front records,
+    # gather lists over the vector of updates, row maps) must reproduce the plain recursion; -1: no such top (the full
+    # forms end in fronts beyond the kernel's 84 columns / 128 rows: 96 x 0 for IEEE-14, 162 columns for IEEE-118)
+    err = pkg.mf_host_top2_err()
+    assert (err == -1.0 and cond == 0) or 0.0 <= err <= 1e-12, err
     assert npos == lay.n == int((np.linalg.eigvalsh(K) > 0).sum())
     assert np.all(np.isfinite(dinv)) and int((dinv > 0).sum()) == lay.n
 
