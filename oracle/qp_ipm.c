@@ -844,7 +844,7 @@ static int ipm_run(ora_qp *q, const double *p_start, const double *y_start)
     const double tol = q->opt.ipm_tol;
     const double mu_min = tol / 10.0;
     double mu = 1.0;
-    int n_acc = 0, n_acc2 = 0;
+    int n_acc = 0, n_acc2 = 0, n_acc3 = 0;
     double dw_prev = 0.0;
     /* predictor-corrector mode (opt.ipm_corrector) until the first inertia correction of this solve */
     int mpc = q->opt.ipm_corrector != 0;
@@ -867,7 +867,13 @@ static int ipm_run(ora_qp *q, const double *p_start, const double *y_start)
          * regularisation leaves a row residual of 1e-8 |dy| that full Newton steps cannot remove when the multiplier
          * steps stay large (seen at trust-region radii ~1e-5: rp stalls at 1.9e-7) */
         n_acc2 = e0 <= 1000.0 * tol ? n_acc2 + 1 : 0;
-        if (n_acc >= 8 || n_acc2 >= 15) { rc = 0; break; }
+        /* ... or 25 within 10^4 x tol (round 3): on the 9241-bus shape the regularised Newton iteration of a sub-problem with
+         * nearly flat directions (delta_w 1e-4 ... 1e-3 against curvatures of 1e-6) stalls at an error of 1e-6 ... 4e-6 for as
+         * long as it is allowed to -- 98 of 128 line-outage scenarios ran their second trust-region QP into the
+         * 200-iteration limit and run! gave up on them.  The rule never fires on the IEEE-118 bench workload (1 282
+         * sub-problems: same iteration and factorisation counts with and without it); same rule in ipm.hip (b_ipm_prepare) */
+        n_acc3 = e0 <= 1e4 * tol ? n_acc3 + 1 : 0;
+        if (n_acc >= 8 || n_acc2 >= 15 || n_acc3 >= 25) { rc = 0; break; }
         /* barrier update */
         for (int k = 0; k < 20 && !mpc; ++k) {
             double emu = fmax(fmax(ms.rd / sd, ms.rp), ipm_compl_err(q, mu) / sd);

@@ -25,7 +25,7 @@ struct IpmState {
     double sf, rho_big, soft_w, hsc;
     // iteration
     double mu, tau, dw, dw_last, dw_floor, cn, relres, rn, e0;
-    int iter, rc, fac_attempt, dir_attempt, refine_it, n_acc, n_acc2;
+    int iter, rc, fac_attempt, dir_attempt, refine_it, n_acc, n_acc2, n_acc3;
     int mpc, use_soc;              // predictor-corrector mode of this solve; second-order terms valid for the step
     double cavg;                   // average complementarity at the top of the iteration
     // outcome

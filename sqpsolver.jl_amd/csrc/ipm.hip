@@ -268,7 +268,7 @@ static __device__ void b_ipm_start(const DV &d)
     }
     if (threadIdx.x == 0) {
         st.sf = sf; st.soft_w = soft_w; st.hsc = (st.stage == 0 && use_obj) ? sf : 0.0;
-        st.mu = 1.0; st.iter = 0; st.rc = -1; st.dw = 0.0; st.dw_floor = 0.0; st.n_acc = 0; st.n_acc2 = 0;
+        st.mu = 1.0; st.iter = 0; st.rc = -1; st.dw = 0.0; st.dw_floor = 0.0; st.n_acc = 0; st.n_acc2 = 0; st.n_acc3 = 0;
         st.dw_last = 0.0;
         st.cn = 0.0;
         st.mpc = d.ipm_corrector != 0; st.use_soc = 0; st.cavg = 0.0;
@@ -291,7 +291,7 @@ static __device__ void b_ipm_prepare(const DV &d)
         return;
     }
     const double hsc = st.hsc;
-    const int n_acc_prev = st.n_acc, n_acc2_prev = st.n_acc2;   // read here: thread 0 updates them below, after the reductions' barriers
+    const int n_acc_prev = st.n_acc, n_acc2_prev = st.n_acc2, n_acc3_prev = st.n_acc3;   // read here: thread 0 updates them below, after the reductions' barriers
     VTR(16)
     const double *pv = p, *yv = y;
     if (d.vstage) {                                  // p and y are gathered from below: LDS copies
@@ -352,11 +352,14 @@ static __device__ void b_ipm_prepare(const DV &d)
     // converged, or acceptable: 8 consecutive iterates within 100 x tol
     const int n_acc = e0 <= 100.0 * d.ipm_tol ? n_acc_prev + 1 : 0;
     const int n_acc2 = e0 <= 1000.0 * d.ipm_tol ? n_acc2_prev + 1 : 0;     // ... or 15 within 1000 x tol
-    if (e0 <= d.ipm_tol || n_acc >= 8 || n_acc2 >= 15) {
+    // ... or 25 within 10^4 x tol: a sub-problem with nearly flat directions stalls there under the regularisation the inertia
+    // test demands (9241-bus shape; never fires on the IEEE-118 workload; oracle/qp_ipm.c, ipm_run, has the data)
+    const int n_acc3 = e0 <= 1e4 * d.ipm_tol ? n_acc3_prev + 1 : 0;
+    if (e0 <= d.ipm_tol || n_acc >= 8 || n_acc2 >= 15 || n_acc3 >= 25) {
         if (threadIdx.x == 0) { st.rc = 0; d.phase[inst] = PH_DONE; }
         return;
     }
-    if (threadIdx.x == 0) { st.n_acc = n_acc; st.n_acc2 = n_acc2; }
+    if (threadIdx.x == 0) { st.n_acc = n_acc; st.n_acc2 = n_acc2; st.n_acc3 = n_acc3; }
     // barrier update: mu <- max(mu_min, min(0.2 mu, mu^1.5)) while the barrier problem is solved
     double mu = st.mu;
     const double mu_min = d.ipm_tol / 10.0;
