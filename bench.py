@@ -36,7 +36,7 @@ sys.path.insert(0, _ROOT)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet fp64 matrix peak; MI355X_MICROARCH.md has no fp64 row.  The on-box
                                # register-resident MFMA probe (printed next to it) sustains 77.6 of it.
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~ 8 TB/s
-DEFAULT_BATCH = {"case14": 512, "case118": 512, "case1354": 512, "case9241": 128}
+DEFAULT_BATCH = {"case14": 512, "case118": 512, "case1354": 512, "case9241": 256}    # (9241: 40 GB of fronts; 128 leave half of the CUs without a vector stage)
 
 
 def host_cores():
