@@ -198,6 +198,8 @@ MfPlan mf_build_plan(int n, int m, const std::vector<int> &kpos, int mk, const s
         while (l > 0 && joins(l - 1)) --l;
         if (S.nlevels - l >= 2) P.top_level = l;
     }
+    auto build_solve_launches = [&]() {
+    P.sol_items.clear(); P.fwd.clear(); P.bwd.clear(); P.top = MfLaunch{0, 0, 256, 0, 0, 0};
     int top_maxfs = 64, top_lcap = 0;
     for (int l = 0; l < S.nlevels; ++l) {
         const bool top = l >= P.top_level;
@@ -242,6 +244,8 @@ MfPlan mf_build_plan(int n, int m, const std::vector<int> &kpos, int mk, const s
         P.top.lds_bytes = 8 * (P.top.cls + top_lcap);
     }
     P.bwd.assign(P.fwd.rbegin(), P.fwd.rend());
+    };
+    build_solve_launches();
     // The top again, for the streaming kernel (k_mf_solve_top2): fronts ascending (children before parents; every ancestor
     // of a top front is a top front).  One wave walks the fronts with everything it touches in LDS -- the factor image of
     // the front (prefetched by the other waves while the previous front is solved), the updates of the children, the
@@ -303,7 +307,14 @@ MfPlan mf_build_plan(int n, int m, const std::vector<int> &kpos, int mk, const s
             fprintf(stderr, "top (streamed): %d fronts from level %d, %d external + %d internal update entries, %d columns, LDS %ld bytes (buffers %d + %d doubles)%s\n",
                     (int)P.top_fr.size(), P.top_level, n_ext, P.top_utotal, P.top_xtotal, lds, P.top_buf0, P.top_buf1, ok ? "" : " -- a front of more than 128 rows: not used");
         if (ok && !P.top_fr.empty() && lds <= 160 * 1024 - 2048) P.top2_lds_bytes = lds;
-        else { P.top_fr.clear(); P.top_gptr.clear(); P.top_gsrc.clear(); P.top_rows.clear(); P.top_ext.clear(); }
+        else {
+            P.top_fr.clear(); P.top_gptr.clear(); P.top_gsrc.clear(); P.top_rows.clear(); P.top_ext.clear();
+            // no streamed top for this structure (fronts beyond 128 rows or 84 columns): then the levels of the top go back
+            // to level launches, which have the LDS-staged kernels for every level they fit -- k_mf_solve_top, one
+            // workgroup per instance walking the fronts with the round-2 routines, is the slower of the two by now
+            // (1354-bus shape: 495 -> 524 QP/s); SQPHIP_MF_TOP=1 keeps it
+            if (!(getenv("SQPHIP_MF_TOP") && atoi(getenv("SQPHIP_MF_TOP")) == 1)) { P.top_level = S.nlevels; build_solve_launches(); }
+        }
     }
     // packed records for the kernels
     P.desc.resize(S.ns);
