@@ -231,7 +231,7 @@ MfPlan mf_build_plan(int n, int m, const std::vector<int> &kpos, int mk, const s
                 if (fs > 64) bigimg = std::max(bigimg, (long)nc * (fs | 1)); else wimg = std::max(wimg, nc * (fs | 1));
             }
             const long lds2 = 8 * std::max(4L * (64 + wimg), 128 + bigimg);
-            if (ok2 && lds2 <= 150 * 1024) { L.wimg = wimg; L.lds2 = (int)lds2; }
+            if (ok2 && lds2 <= 150 * 1024) { L.wimg = wimg; L.lds2 = (int)lds2; L.hasbig = bigimg > 0 ? 1 : 0; }
         }
         if (!top) { P.fwd.push_back(L); continue; }
         if (l == P.top_level) P.top.begin = L.begin;

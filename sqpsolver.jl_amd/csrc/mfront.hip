@@ -1520,7 +1520,10 @@ __device__ __forceinline__ void mf_img_load(const double *G, int ld, int nc, int
     }
 }
 
-__global__ __launch_bounds__(256, 4) void k_mf_fwd2(DV d, int ibegin, int want, int wimg)
+// HASBIG = false: a launch without fronts of more than 64 rows (the wide bottom levels): the four-wave path is compiled out
+// and the kernel fits more waves per CU
+template <bool HASBIG>
+__global__ __launch_bounds__(256, HASBIG ? 4 : 6) void k_mf_fwd2(DV d, int ibegin, int want, int wimg)
 {
     const int inst = blockIdx.y;
     if (d.phase[inst] != want) return;
@@ -1528,7 +1531,7 @@ __global__ __launch_bounds__(256, 4) void k_mf_fwd2(DV d, int ibegin, int want, 
     const MfDev &M = d.mf;
     const int4 it = reinterpret_cast<const int4 *>(M.sol_items)[ibegin + blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool big = it.y == -2;
+    const bool big = HASBIG && it.y == -2;
     const int s = big ? it.x : (wave == 0 ? it.x : (wave == 1 ? it.y : (wave == 2 ? it.z : it.w)));
     if (s < 0) return;                                        // (no workgroup barrier on the wave-per-front path)
     const MfFrontDesc Fd = M.desc[s];
@@ -1570,7 +1573,8 @@ __global__ __launch_bounds__(256, 4) void k_mf_fwd2(DV d, int ibegin, int want, 
     }
 }
 
-__global__ __launch_bounds__(256, 4) void k_mf_bwd2(DV d, int ibegin, int want, int wimg)
+template <bool HASBIG>
+__global__ __launch_bounds__(256, HASBIG ? 4 : 5) void k_mf_bwd2(DV d, int ibegin, int want, int wimg)
 {
     const int inst = blockIdx.y;
     if (d.phase[inst] != want) return;
@@ -1578,7 +1582,7 @@ __global__ __launch_bounds__(256, 4) void k_mf_bwd2(DV d, int ibegin, int want, 
     const MfDev &M = d.mf;
     const int4 it = reinterpret_cast<const int4 *>(M.sol_items)[ibegin + blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool big = it.y == -2;
+    const bool big = HASBIG && it.y == -2;
     const int s = big ? it.x : (wave == 0 ? it.x : (wave == 1 ? it.y : (wave == 2 ? it.z : it.w)));
     if (s < 0) return;
     const MfFrontDesc Fd = M.desc[s];
@@ -1697,12 +1701,17 @@ void mf_solve(Ctx &C, int want, bool skip_fwd)
     }
     // level launches: the LDS-staged kernels where every front of the level fits them (mfplan.hip: L.wimg >= 0)
     const bool lvl2 = !(getenv("SQPHIP_MF_LEVEL2") && atoi(getenv("SQPHIP_MF_LEVEL2")) == 0);      // (read per call: tests flip it)
-    static const hipError_t attr_f = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_fwd2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    static const hipError_t attr_b = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_bwd2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    SQPHIP_HIP_OK(attr_f); SQPHIP_HIP_OK(attr_b);
+    static const hipError_t attr_f = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_fwd2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static const hipError_t attr_b = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_bwd2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static const hipError_t attr_f0 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_fwd2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static const hipError_t attr_b0 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_bwd2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    SQPHIP_HIP_OK(attr_f); SQPHIP_HIP_OK(attr_b); SQPHIP_HIP_OK(attr_f0); SQPHIP_HIP_OK(attr_b0);
     if (!skip_fwd)
         for (const MfLaunch &L : C.mfp().fwd) {
-            if (lvl2 && !generic && L.wimg >= 0) hipLaunchKernelGGL(k_mf_fwd2, dim3(L.count, d.B), dim3(256), L.lds2, s, d, L.begin, want, L.wimg);
+            if (lvl2 && !generic && L.wimg >= 0) {
+                if (L.hasbig) hipLaunchKernelGGL(k_mf_fwd2<true>, dim3(L.count, d.B), dim3(256), L.lds2, s, d, L.begin, want, L.wimg);
+                else hipLaunchKernelGGL(k_mf_fwd2<false>, dim3(L.count, d.B), dim3(256), L.lds2, s, d, L.begin, want, L.wimg);
+            }
             else hipLaunchKernelGGL(k_mf_fwd, dim3(L.count, d.B), dim3(256), L.lds_bytes, s, d, L.begin, want, generic, L.tiles, L.cls, L.lds_bytes / 8 - L.cls);
         }
     if (d.mf.top_n > 0 && !generic) {
@@ -1715,7 +1724,10 @@ void mf_solve(Ctx &C, int want, bool skip_fwd)
         hipLaunchKernelGGL(k_mf_solve_top, dim3(d.B), dim3(256), T.lds_bytes, s, d, T.begin, T.count, want, skip_fwd ? 0 : 1, generic,
                            T.tiles, T.cls, T.lds_bytes / 8 - T.cls);
     for (const MfLaunch &L : C.mfp().bwd) {
-        if (lvl2 && !generic && L.wimg >= 0) hipLaunchKernelGGL(k_mf_bwd2, dim3(L.count, d.B), dim3(256), L.lds2, s, d, L.begin, want, L.wimg);
+        if (lvl2 && !generic && L.wimg >= 0) {
+            if (L.hasbig) hipLaunchKernelGGL(k_mf_bwd2<true>, dim3(L.count, d.B), dim3(256), L.lds2, s, d, L.begin, want, L.wimg);
+            else hipLaunchKernelGGL(k_mf_bwd2<false>, dim3(L.count, d.B), dim3(256), L.lds2, s, d, L.begin, want, L.wimg);
+        }
         else hipLaunchKernelGGL(k_mf_bwd, dim3(L.count, d.B), dim3(256), L.lds_bytes, s, d, L.begin, want, generic, L.tiles, L.cls, L.lds_bytes / 8 - L.cls);
     }
 }

@@ -93,7 +93,7 @@ struct MfGather { int where, src_begin, src_end, src0; };
 // of the launch (sizes the LDS image), lds_bytes = dynamic LDS.
 // Solve launches also carry what the LDS-staged kernels (k_mf_fwd2 / k_mf_bwd2) need: wimg = doubles of a wave's image
 // buffer (-1: a front of the level does not fit them), lds2 = their dynamic LDS.
-struct MfLaunch { int begin, count, threads, lds_bytes, cls, tiles; int wimg = -1, lds2 = 0; };
+struct MfLaunch { int begin, count, threads, lds_bytes, cls, tiles; int wimg = -1, lds2 = 0, hasbig = 1; };
 
 // One front of the narrow top of the assembly tree as the streaming solve kernel (k_mf_solve_top2, mfront.hip) sees it:
 // where its factor lives in the arena, the leading dimension of its LDS image (odd: the transposed reads of the
