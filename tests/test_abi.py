@@ -265,3 +265,22 @@ def test_bench_refuses_a_rank_count_it_was_not_launched_with():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True)
     assert r.returncode == 2 and "torch.distributed.run" in r.stderr and r.stdout.strip() == ""
+
+
+def test_acceptable_termination_rules_are_the_same_in_oracle_and_device():
+    """The interior-point method ends on `e0 <= tol` or acceptably: 8 iterates within 100 x tol, 15 within 1000 x, 25 within
+    10^4 x (the third rule is what lets the 9241-bus line-outage scenarios get past their flat QPs).
+    Oracle (oracle/qp_ipm.c, ipm_run) and device (ipm.hip, b_ipm_prepare) must carry the same ladder: the parity tests
+    compare their iteration counts."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ora = open(os.path.join(root, "oracle", "qp_ipm.c")).read()
+    dev = open(os.path.join(root, "sqpsolver.jl_amd", "csrc", "ipm.hip")).read()
+    def ladder(src, tol):
+        fac = [float(m) for m in re.findall(r"e0 <= ([0-9.e]+) \* " + re.escape(tol) + r" \? n_acc", src)]
+        cnt = [int(m) for m in re.findall(r"n_acc\d? >= (\d+)", src)]
+        return fac, sorted(set(cnt))
+    fo, co = ladder(ora, "tol")
+    fd, cd = ladder(dev, "d.ipm_tol")
+    assert fo == fd == [100.0, 1000.0, 1e4], (fo, fd)
+    assert co == cd == [8, 15, 25], (co, cd)
