@@ -114,7 +114,13 @@ void make_lanes(Ctx &C)
 {
     C.lanes.clear();
     int G = 1;
-    if (C.d.sparse) G = C.d.B >= 128 ? 4 : (C.d.B >= 64 ? 2 : 1);
+    // (round 3, with the shorter solve kernels: four groups from 64 instances on -- 64 resident scenarios 1 955 -> 2 015 QP/s;
+    //  SQPHIP_GROUP_RULE=<g32>,<g16>: groups for batches of 32 .. 63 and 16 .. 31, experiment)
+    if (C.d.sparse) {
+        int g32 = 4, g16 = 2;           // (32 resident scenarios: 1 034 / 1 074 / 1 119 QP/s with one / two / four groups)
+        if (const char *e = getenv("SQPHIP_GROUP_RULE")) sscanf(e, "%d,%d", &g32, &g16);
+        G = C.d.B >= 64 ? 4 : (C.d.B >= 32 ? g32 : (C.d.B >= 16 ? g16 : 1));
+    }
     if (const char *e = getenv("SQPHIP_GROUPS")) G = atoi(e);
     if (G > C.d.B) G = C.d.B;
     if (G > 7) G = 7;                       // counter slots
