@@ -969,6 +969,9 @@ __global__ __launch_bounds__(TPB, SQPHIP_VEC_WAVES_PER_EU) void k_ipm_head(DV d)
     b_build_rhs(d);
 }
 
+// the head of a sweep in which no sub-problem is finished or started (see ipm_sweep): the Newton right-hand side only
+__global__ __launch_bounds__(TPB, SQPHIP_VEC_WAVES_PER_EU) void k_ipm_rhs(DV d) { b_build_rhs(d); }
+
 // behind solve slot A: residual check of the first solve, then the corrector's system in predictor-corrector mode
 __global__ __launch_bounds__(TPB, SQPHIP_VEC_WAVES_PER_EU) void k_ipm_mid(DV d, int last)
 {
@@ -1018,10 +1021,22 @@ void ipm_sweep(Ctx &C, bool sqp_level)
     hipStream_t s = C.stream;
     const dim3 gB(d.B), bT(TPB);
     C.n_sweeps++;
-    hipLaunchKernelGGL(k_qp_finish, gB, bT, 0, s, d);
-    if (sqp_level) sqp_stage_kernels(C);
     const size_t vlds = 8 * (size_t)d.vstage;
-    hipLaunchKernelGGL(k_ipm_head, gB, bT, vlds, s, d);
+    // Transitions between sub-problems -- k_qp_finish, the stage kernel of run!, the start of the next sub-problem in
+    // k_ipm_head -- concern three or four of the 128 instances of a group in any one sweep, and each of these kernels
+    // lasts as long as its slowest instance (20 + 95 + 120 us against ~25 us for the right-hand sides of everybody else):
+    // with a period P > 1 they run every P-th sweep only, an instance that has finished waits up to P - 1 sweeps for them
+    // (gated out of everything meanwhile), and the sweeps in between start with k_ipm_rhs.  Which sweep an instance
+    // moves on in changes nothing it computes.  Measured (driver's command, 512 x IEEE-118, groups of 128): P = 1 / 2 / 3 / 4
+    // -> 7 443 / 7 682 / 7 769 / 7 763 QP/s with identical work counters; 64 scenarios (groups of 16): 2 020 / 2 023 / 2 002.
+    // Default: 3 for groups of 64 instances and more, 2 from 32 on, else 1; SQPHIP_TRANS_PERIOD overrides.
+    const int period = getenv("SQPHIP_TRANS_PERIOD") ? atoi(getenv("SQPHIP_TRANS_PERIOD")) : (d.B >= 64 ? 3 : (d.B >= 32 ? 2 : 1));
+    const bool trans = !sqp_level || period <= 1 || (C.n_sweeps % period) == 1 % period;
+    if (trans) {
+        hipLaunchKernelGGL(k_qp_finish, gB, bT, 0, s, d);
+        if (sqp_level) sqp_stage_kernels(C);
+        hipLaunchKernelGGL(k_ipm_head, gB, bT, vlds, s, d);
+    } else hipLaunchKernelGGL(k_ipm_rhs, gB, bT, vlds, s, d);
     if (!d.sparse) hipLaunchKernelGGL(k_kkt_assemble, dim3(d.Fpad, d.B), dim3(128), 0, s, d);
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (C.tm.enabled) { ev = C.tm.get(); hipEventRecord(ev.first, s); }
