@@ -509,13 +509,33 @@ static int kkt_factor(ora_qp *q, double dw_floor, double *delta_w_out)
                         }
                     }
                 }
+                if (q->sparse && getenv("ORA_INERTIA_STATS")) {  /* experiment aid: signs of the VARIABLE pivots of accepted matrices */
+                    static long nacc = 0, nacc_neg = 0, nneg = 0, nacc_dw = 0, nacc_dw_neg = 0;
+                    const int64_t *perm = ora_sldl_perm(q->sl);
+                    const double *Dp = ora_sldl_pivots(q->sl);
+                    long neg = 0;
+                    for (int64_t k = 0; k < Nf; ++k) if (perm[k] < q->n && Dp[k] < 0.0) ++neg;
+                    ++nacc; nneg += neg; if (neg) ++nacc_neg;
+                    if (dw > 0.0) { ++nacc_dw; if (neg) ++nacc_dw_neg; }
+                    if (nacc % 500 == 0)
+                        fprintf(stderr, "[inertia-stats] accepted %ld, with negative variable pivots %ld (sum %ld); with dw > 0: %ld, of those with negative variable pivots %ld\n",
+                                nacc, nacc_neg, nneg, nacc_dw, nacc_dw_neg);
+                }
                 if (dw > 0.0) q->delta_w_last = dw;
                 *delta_w_out = dw;
                 return 0;
             }
         }
         if (dw == 0.0) dw = q->delta_w_last == 0.0 ? 1e-4 : fmax(1e-20, q->delta_w_last / 3.0);
-        else dw *= (q->delta_w_last == 0.0 ? 100.0 : 8.0);
+        else {
+            double grow = q->delta_w_last == 0.0 ? 100.0 : 8.0;
+            if (getenv("ORA_DW_ADAPT")) {       /* experiment: after k failed trials of one call grow by g instead */
+                int k = 2; double g = 64.0;
+                sscanf(getenv("ORA_DW_ADAPT"), "%d,%lf", &k, &g);
+                if (attempt >= k) grow = g;
+            }
+            dw *= grow;
+        }
         if (dw > 1e40) break;
     }
     if (getenv("ORA_IPM_DEBUG")) {
@@ -850,6 +870,9 @@ static int ipm_run(ora_qp *q, const double *p_start, const double *y_start)
     int mpc = q->opt.ipm_corrector != 0;
     double *soc = mpc ? (double *)calloc((size_t)(2 * n + 4 * m + 1), sizeof(double)) : NULL;
     int verbose = getenv("ORA_IPM_VERBOSE") != NULL;
+    int short_lim = 0, n_short = 0;
+    double short_a = 0.1;
+    if (getenv("ORA_MPC_SHORT")) sscanf(getenv("ORA_MPC_SHORT"), "%d,%lf", &short_lim, &short_a);
     /* iteration limit; half of it for a second-order correction: one that has not converged by then is abandoned,
      * which for run! is the same as any other unsuccessful correction (same rule as the product, ipm.hip k_ipm_prepare) */
     const int it_max = q->cur_mode == ORA_MODE_SOC ? q->opt.ipm_max_iter / 2 : q->opt.ipm_max_iter;
@@ -960,6 +983,10 @@ static int ipm_run(ora_qp *q, const double *p_start, const double *y_start)
         }
         if (!ok) { rc = 2; break; }
         dw_prev = dw;
+        if (mpc && short_lim > 0) {     /* experiment (ORA_MPC_SHORT=k,a): k consecutive predictor-corrector steps below a end that mode */
+            n_short = alpha < short_a ? n_short + 1 : 0;
+            if (n_short >= short_lim) { mpc = 0; mu = fmax(mu_min, fmin(1.0, ms.cavg)); }
+        }
         for (int64_t j = 0; j < n; ++j) {
             q->p[j] = nudge_inside(q->p[j] + alpha * q->dp[j], q->lb[j], q->ub[j]);
             q->zl[j] += a_d * q->dzl[j];

@@ -200,6 +200,7 @@ void ora_sldl_free(ora_sldl *S)
 
 int64_t ora_sldl_nnz_l(const ora_sldl *S) { return S->nnzL; }
 const int64_t *ora_sldl_perm(const ora_sldl *S) { return S->perm; }
+const double *ora_sldl_pivots(const ora_sldl *S) { return S->D; }
 
 /* numeric factorisation from the triplet values (duplicates summed in triplet order); returns the number of
  * positive pivots, *nbad = pivots that are zero or not finite */

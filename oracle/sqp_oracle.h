@@ -86,6 +86,7 @@ ora_sldl *ora_sldl_analyse(int64_t n, int64_t nt, const int64_t *ti, const int64
 void ora_sldl_free(ora_sldl *S);
 int64_t ora_sldl_nnz_l(const ora_sldl *S);
 const int64_t *ora_sldl_perm(const ora_sldl *S);
+const double *ora_sldl_pivots(const ora_sldl *S);   /* D of the last numeric factorisation, elimination order */
 int64_t ora_sldl_numeric(ora_sldl *S, const double *tv, int64_t *nbad);
 void ora_sldl_solve(const ora_sldl *S, double *x);
 
