@@ -870,6 +870,7 @@ static int ipm_run(ora_qp *q, const double *p_start, const double *y_start)
     int mpc = q->opt.ipm_corrector != 0;
     double *soc = mpc ? (double *)calloc((size_t)(2 * n + 4 * m + 1), sizeof(double)) : NULL;
     int verbose = getenv("ORA_IPM_VERBOSE") != NULL;
+    const int eq_steps = getenv("ORA_EQ_STEPS") ? atoi(getenv("ORA_EQ_STEPS")) : 0;
     int short_lim = 0, n_short = 0;
     double short_a = 0.1;
     if (getenv("ORA_MPC_SHORT")) sscanf(getenv("ORA_MPC_SHORT"), "%d,%lf", &short_lim, &short_a);
@@ -977,6 +978,7 @@ static int ipm_run(ora_qp *q, const double *p_start, const double *y_start)
             ipm_max_steps(q, &apm, &adm);
             alpha = fmin(1.0, tau * apm);
             a_d = fmin(1.0, tau * adm);
+            if (eq_steps == 1 || (eq_steps == 2 && !mpc) || (eq_steps == 3 && dw > 0.0)) alpha = a_d = fmin(alpha, a_d);   /* experiment */
             if (isfinite(relres) && relres < 1e-6 && isfinite(alpha) && isfinite(a_d)) { ok = 1; break; }
             dw_floor = dw > 0.0 ? 8.0 * dw : (q->delta_w_last > 0.0 ? q->delta_w_last : 1e-4);
             if (dw_floor > 1e20) break;
