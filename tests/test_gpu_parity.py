@@ -1355,6 +1355,32 @@ def test_instance_groups_change_nothing_but_the_schedule():
         assert [t["ipm_iters"] for t in a[3]] == [t["ipm_iters"] for t in b[3]]
 
 
+def test_transition_period_changes_nothing_but_the_schedule(monkeypatch):
+    """ipm_sweep runs the transitions between sub-problems (k_qp_finish, the stage kernel of run!, the start in k_ipm_head)
+    every third sweep for groups of 64 instances and more, and k_ipm_rhs in the sweeps between (ipm.hip).  An instance that
+    has finished a sub-problem waits, gated out of everything, for the next transition sweep: which sweep it moves on in
+    changes nothing it computes.  Periods 1 (every sweep), 2 and 3 forced on a batch of eight: the same iterates bit for
+    bit, the same per-sub-problem logs and work counters, more sweeps."""
+    nb, ng, nl, seed = CASES["case14"]
+    base = acopf_synth(nb, ng, nl, seed)
+    nets = [base] + [contingency(base, s, seed) for s in range(1, 8)]
+    lays = [acopf_layout(nt) for nt in nets]
+    kw = dict(max_iter=12, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=1)
+    got = {}
+    for period in ("1", "2", "3"):
+        monkeypatch.setenv("SQPHIP_TRANS_PERIOD", period)
+        ctx = _run_batch(nets, lays, kw, kkt_mode=2)
+        c = ctx.counters()
+        got[period] = ([ctx.sqp_get(b)["x"] for b in range(8)], [ctx.sqp_qp_log(b) for b in range(8)],
+                       [(ctx.sqp_get(b)["status"], ctx.sqp_get(b)["iter"]) for b in range(8)],
+                       (c["n_qp"], c["n_ipm_iter"], c["n_factor"]), c["n_sweeps"])
+        ctx.close()
+    for period in ("2", "3"):
+        assert all(np.array_equal(a, b) for a, b in zip(got[period][0], got["1"][0]))
+        assert got[period][1] == got["1"][1] and got[period][2] == got["1"][2] and got[period][3] == got["1"][3]
+    assert got["1"][4] <= got["2"][4] <= got["3"][4]
+
+
 def test_speculative_second_shift_changes_nothing_but_the_schedule(monkeypatch):
     """Below ~256 resident instances a sweep factorises the shift delta_w AND the next shift of the inertia-correction
     schedule for every instance whose first shift is a shrink attempt or a retry; k_inertia then books the work exactly
