@@ -62,6 +62,29 @@ static __device__ __forceinline__ void block_reduce6(double &v0, double &v1, dou
         v3 = O3::f(v3, sh6[3][w]); v4 = O4::f(v4, sh6[4][w]); v5 = O5::f(v5, sh6[5][w]);
     }
 }
+template <class O0, class O1, class O2, class O3, class O4, class O5, class O6>
+static __device__ __forceinline__ void block_reduce7(double &v0, double &v1, double &v2, double &v3, double &v4, double &v5, double &v6)
+{
+    __shared__ double sh7[7][TPB / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        v0 = O0::f(v0, __shfl_xor(v0, o)); v1 = O1::f(v1, __shfl_xor(v1, o)); v2 = O2::f(v2, __shfl_xor(v2, o));
+        v3 = O3::f(v3, __shfl_xor(v3, o)); v4 = O4::f(v4, __shfl_xor(v4, o)); v5 = O5::f(v5, __shfl_xor(v5, o));
+        v6 = O6::f(v6, __shfl_xor(v6, o));
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        sh7[0][w] = v0; sh7[1][w] = v1; sh7[2][w] = v2; sh7[3][w] = v3; sh7[4][w] = v4; sh7[5][w] = v5; sh7[6][w] = v6;
+    }
+    __syncthreads();
+    v0 = sh7[0][0]; v1 = sh7[1][0]; v2 = sh7[2][0]; v3 = sh7[3][0]; v4 = sh7[4][0]; v5 = sh7[5][0]; v6 = sh7[6][0];
+#pragma unroll
+    for (int w = 1; w < TPB / 64; ++w) {
+        v0 = O0::f(v0, sh7[0][w]); v1 = O1::f(v1, sh7[1][w]); v2 = O2::f(v2, sh7[2][w]);
+        v3 = O3::f(v3, sh7[3][w]); v4 = O4::f(v4, sh7[4][w]); v5 = O5::f(v5, sh7[5][w]); v6 = O6::f(v6, sh7[6][w]);
+    }
+}
 template <class O0, class O1>
 static __device__ __forceinline__ void block_reduce2(double &v0, double &v1)
 {

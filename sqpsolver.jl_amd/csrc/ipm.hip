@@ -19,6 +19,10 @@
 #include "dev_util.hpp"
 #include <cmath>
 
+#ifndef SQPHIP_VEC_FUSE
+#define SQPHIP_VEC_FUSE 1      // rows of H v / J v formed inside the loops that consume them (0: separate passes + barrier)
+#endif
+
 namespace sqphip {
 
 // Gathered vectors in LDS (round 3).  The sparse products of the vector stages -- H v, J v, J' w, the expansion of the
@@ -46,32 +50,36 @@ extern "C" int sqphip_vec_trace_read(long long *out) { return (int)hipMemcpyFrom
 #define IPM_REG_D 1e-8
 
 // out_j = hsc * (H v)_j + hd_j v_j   (H full symmetric CSC, gather by column)
+// one row of (hsc H + diag hd) v and of J v (the caller has excluded free rows): the sums hess_mul / jac_mul store, for the
+// loops that consume a row's product in the thread that formed it (no trip through global memory, no barrier)
+__device__ __forceinline__ double hess_row(const DV &d, const double *hv, const double *hd, double hsc, const double *v, int j)
+{
+    double acc = 0.0;
+    const int k0 = d.hcolptr[j], k1 = d.hcolptr[j + 1];
+    const double hdj = hd[j], vj = v[j];
+#pragma unroll 4
+    for (int k = k0; k < k1; ++k) acc += hv[k] * v[d.hrowval[k]];
+    return hsc * acc + hdj * vj;
+}
+__device__ __forceinline__ double jac_row(const DV &d, const double *jv, const double *v, int i)
+{
+    double acc = 0.0;
+    const int k0 = d.jrowptr[i], k1 = d.jrowptr[i + 1];
+#pragma unroll 4
+    for (int k = k0; k < k1; ++k) acc += jv[d.jrslot[k]] * v[d.jrcol[k]];
+    return acc;
+}
 __device__ void hess_mul(const DV &d, int inst, double hsc, const double *v, double *out)
 {
     const double *hv = d.hv + (long)inst * d.nnzhc, *hd = d.hd + (long)inst * d.n;
-    for (int j = threadIdx.x; j < d.n; j += TPB) {
-        double acc = 0.0;
-        const int k0 = d.hcolptr[j], k1 = d.hcolptr[j + 1];
-        const double hdj = hd[j], vj = v[j];
-#pragma unroll 4
-        for (int k = k0; k < k1; ++k) acc += hv[k] * v[d.hrowval[k]];
-        out[j] = hsc * acc + hdj * vj;
-    }
+    for (int j = threadIdx.x; j < d.n; j += TPB) out[j] = hess_row(d, hv, hd, hsc, v, j);
 }
 // out_i = J_i v over active rows (CSR view)
 __device__ void jac_mul(const DV &d, int inst, const double *v, double *out)
 {
     const double *jv = d.jv + (long)inst * d.nnzjc;
     const int *rt = d.rtype + (long)inst * d.m;
-    for (int i = threadIdx.x; i < d.m; i += TPB) {
-        double acc = 0.0;
-        const int k0 = d.jrowptr[i], k1 = d.jrowptr[i + 1];
-        if (rt[i] != ROW_FREE) {
-#pragma unroll 4
-            for (int k = k0; k < k1; ++k) acc += jv[d.jrslot[k]] * v[d.jrcol[k]];
-        }
-        out[i] = acc;
-    }
+    for (int i = threadIdx.x; i < d.m; i += TPB) out[i] = rt[i] != ROW_FREE ? jac_row(d, jv, v, i) : 0.0;
 }
 // (J' w)_j, w from an LDS copy in which the entries of free rows are zero: no row-type gather (the product of a free row
 // is then + 0.0 instead of being skipped -- the same sum)
@@ -83,6 +91,8 @@ __device__ __forceinline__ double jact_col_masked(const DV &d, const double *jv,
     for (int k = k0; k < k1; ++k) acc += jv[k] * w[d.jrowval[k]];
     return acc;
 }
+// |z g - mu| of one complementarity pair, the product and the subtraction in one rounding wherever it is taken
+__device__ __forceinline__ double compl_err(double z, double g, double mu) { return fabs(fma(z, g, -mu)); }
 // (J' w)_j over active rows
 __device__ __forceinline__ double jact_col(const DV &d, const double *jv, const int *rt, const double *w, int j)
 {
@@ -302,45 +312,65 @@ static __device__ void b_ipm_prepare(const DV &d)
         pv = sp; yv = sy;
     }
     VTR(17)
+    // (H p and J p are formed row by row inside the loops that consume them: SQPHIP_VEC_FUSE=0 restores the two passes
+    //  through rd / rp with a barrier behind them -- same sums, same bits)
+    const double *hvp = d.hv + (long)inst * d.nnzhc;
+#if !SQPHIP_VEC_FUSE
     hess_mul(d, inst, hsc, pv, rd);
     VTR(18)
     jac_mul(d, inst, pv, rp);
     __syncthreads();
+#endif
     VTR(19)
     double csum = 0, cmax = 0, rdn = 0, rpn = 0, dl1 = 0, nc = 0;
+    // ce0: the complementarity error against the barrier value this iteration starts from -- the first pass of the barrier
+    // update below, taken in the same loops (the products are the ones summed here) and reduced with the other six
+    double ce0 = 0.0;
+    const double mu_in = st.mu;
     // (loop bodies: every operand is loaded before the first test on one of them -- a load behind a branch on another
     //  load is a second memory round trip, and these loops are round trips and little else)
     for (int j = threadIdx.x; j < d.n; j += TPB) {
-        const double rdj = rd[j], cj = c[j], pj = p[j], lbj = lb[j], ubj = ub[j], zlj = zl[j], zuj = zu[j];
+#if SQPHIP_VEC_FUSE
+        const double rdj = hess_row(d, hvp, hd, hsc, pv, j);
+#else
+        const double rdj = rd[j];
+#endif
+        const double cj = c[j], pj = p[j], lbj = lb[j], ubj = ub[j], zlj = zl[j], zuj = zu[j];
         double r = rdj + cj - (d.vstage ? jact_col_masked(d, jv, yv, j) : jact_col(d, jv, rt, yv, j));
         const double g_l = pj - lbj, g_u = ubj - pj;
         double sg = 0.0;
-        if (fin(lbj)) { r -= zlj; const double cc = zlj * g_l; csum += cc; cmax = fmax(cmax, cc); nc += 1; dl1 += zlj; sg += zlj / g_l; }
-        if (fin(ubj)) { r += zuj; const double cc = zuj * g_u; csum += cc; cmax = fmax(cmax, cc); nc += 1; dl1 += zuj; sg += zuj / g_u; }
+        if (fin(lbj)) { r -= zlj; const double cc = zlj * g_l; csum += cc; cmax = fmax(cmax, cc); nc += 1; dl1 += zlj; sg += zlj / g_l; ce0 = fmax(ce0, compl_err(zlj, g_l, mu_in)); }
+        if (fin(ubj)) { r += zuj; const double cc = zuj * g_u; csum += cc; cmax = fmax(cmax, cc); nc += 1; dl1 += zuj; sg += zuj / g_u; ce0 = fmax(ce0, compl_err(zuj, g_u, mu_in)); }
         rd[j] = r; sigp[j] = sg;
         rdn = fmax(rdn, fabs(r));
     }
     for (int i = threadIdx.x; i < d.m; i += TPB) {
         const int rti = rt[i];
-        const double rpi = rp[i], tpi = tp[i], tmi = tm[i], si = s[i], zp = zpv[i], zm = zmv[i], yi = y[i], loi = lo[i], hii = hi[i],
+        const double tpi = tp[i], tmi = tm[i], si = s[i], zp = zpv[i], zm = zmv[i], yi = y[i], loi = lo[i], hii = hi[i],
                      vli = vl[i], vui = vu[i];
+#if SQPHIP_VEC_FUSE
+        const double rpi = rti != ROW_FREE ? jac_row(d, jv, pv, i) : 0.0;
+#else
+        const double rpi = rp[i];
+#endif
         if (rti == ROW_FREE) { rp[i] = 0.0; Dd[i] = 1.0; continue; }
         const double r = rpi + tpi - tmi - si;
         rp[i] = r; rpn = fmax(rpn, fabs(r));
         double cc = zp * tpi; csum += cc; cmax = fmax(cmax, cc);
         cc = zm * tmi; csum += cc; cmax = fmax(cmax, cc); nc += 2;
+        ce0 = fmax(ce0, fmax(compl_err(zp, tpi, mu_in), compl_err(zm, tmi, mu_in)));
         dl1 += fabs(yi);
         double dd = tpi / zp + tmi / zm;
         if (rti == ROW_INEQ) {
             double sig = 0.0;
-            if (fin(loi)) { const double al = si - loi; cc = vli * al; csum += cc; cmax = fmax(cmax, cc); nc += 1; sig += vli / al; }
-            if (fin(hii)) { const double au = hii - si; cc = vui * au; csum += cc; cmax = fmax(cmax, cc); nc += 1; sig += vui / au; }
+            if (fin(loi)) { const double al = si - loi; cc = vli * al; csum += cc; cmax = fmax(cmax, cc); nc += 1; sig += vli / al; ce0 = fmax(ce0, compl_err(vli, al, mu_in)); }
+            if (fin(hii)) { const double au = hii - si; cc = vui * au; csum += cc; cmax = fmax(cmax, cc); nc += 1; sig += vui / au; ce0 = fmax(ce0, compl_err(vui, au, mu_in)); }
             dd += 1.0 / sig;
         }
         Dd[i] = dd;
     }
     VTR(20)
-    block_reduce6<OpSum, OpMax, OpMax, OpMax, OpSum, OpSum>(csum, cmax, rdn, rpn, dl1, nc);
+    block_reduce7<OpSum, OpMax, OpMax, OpMax, OpSum, OpSum, OpMax>(csum, cmax, rdn, rpn, dl1, nc, ce0);
     VTR(21)
     const double cavg = nc > 0 ? csum / nc : 0.0;
     if (!fin(rdn) || !fin(cavg) || !fin(rpn)) {
@@ -365,21 +395,24 @@ static __device__ void b_ipm_prepare(const DV &d)
     const double mu_min = d.ipm_tol / 10.0;
     const int mpc = st.mpc;           // predictor-corrector mode picks mu after the predictor (k_mpc)
     for (int kk = 0; kk < 20 && !mpc; ++kk) {
-        double ce = 0.0;
-        for (int j = threadIdx.x; j < d.n; j += TPB) {
-            if (fin(lb[j])) ce = fmax(ce, fabs(zl[j] * (p[j] - lb[j]) - mu));
-            if (fin(ub[j])) ce = fmax(ce, fabs(zu[j] * (ub[j] - p[j]) - mu));
-        }
-        for (int i = threadIdx.x; i < d.m; i += TPB) {
-            if (rt[i] == ROW_FREE) continue;
-            ce = fmax(ce, fabs(zpv[i] * tp[i] - mu));
-            ce = fmax(ce, fabs(zmv[i] * tm[i] - mu));
-            if (rt[i] == ROW_INEQ) {
-                if (fin(lo[i])) ce = fmax(ce, fabs(vl[i] * (s[i] - lo[i]) - mu));
-                if (fin(hi[i])) ce = fmax(ce, fabs(vu[i] * (hi[i] - s[i]) - mu));
+        double ce = ce0;                 // first pass: taken with the residual loops above (mu is still the value they used)
+        if (kk > 0) {
+            ce = 0.0;
+            for (int j = threadIdx.x; j < d.n; j += TPB) {
+                if (fin(lb[j])) ce = fmax(ce, compl_err(zl[j], p[j] - lb[j], mu));
+                if (fin(ub[j])) ce = fmax(ce, compl_err(zu[j], ub[j] - p[j], mu));
             }
+            for (int i = threadIdx.x; i < d.m; i += TPB) {
+                if (rt[i] == ROW_FREE) continue;
+                ce = fmax(ce, compl_err(zpv[i], tp[i], mu));
+                ce = fmax(ce, compl_err(zmv[i], tm[i], mu));
+                if (rt[i] == ROW_INEQ) {
+                    if (fin(lo[i])) ce = fmax(ce, compl_err(vl[i], s[i] - lo[i], mu));
+                    if (fin(hi[i])) ce = fmax(ce, compl_err(vu[i], hi[i] - s[i], mu));
+                }
+            }
+            ce = block_reduce<OpMax>(ce);
         }
-        ce = block_reduce<OpMax>(ce);
         const double emu = fmax(fmax(rdn / sd, rpn), ce / sd);
         if (emu > 10.0 * mu || mu <= mu_min) break;
         mu = fmax(mu_min, fmin(0.2 * mu, pow(mu, 1.5)));
@@ -654,14 +687,22 @@ static __device__ void b_refine(const DV &d, int last, int want)
     const double hsc = st.hsc;
     const double *sv = ss ? ss : sol;
     // res = rhs - K sol : top block (H + hd + sigp + dw) dp + J' q ; bottom J dp - D q
+    const double *hvp = d.hv + (long)inst * d.nnzhc;
+#if !SQPHIP_VEC_FUSE
     hess_mul(d, inst, hsc, sv, wn);
     jac_mul(d, inst, sv, wN + d.n);
     __syncthreads();
+#endif
     VTR(want == PH_RESOLVE ? 2 : 34)
     double en = 0.0;
     const double dwv = st.dw;
     for (int j = threadIdx.x; j < d.n; j += TPB) {
-        const double wnj = wn[j], sgj = sigp[j], rhj = rhs[j], svj = sv[j];
+#if SQPHIP_VEC_FUSE
+        const double wnj = hess_row(d, hvp, hd, hsc, sv, j);
+#else
+        const double wnj = wn[j];
+#endif
+        const double sgj = sigp[j], rhj = rhs[j], svj = sv[j];
         const double kx = wnj + (sgj + dwv + IPM_REG_P) * svj +
                           (ss ? jact_col_masked(d, jv, sv + d.n, j) : jact_col(d, jv, rt, sv + d.n, j));
         const double r = rhj - kx;
@@ -669,7 +710,12 @@ static __device__ void b_refine(const DV &d, int last, int want)
     }
     for (int i = threadIdx.x; i < d.m; i += TPB) {
         const int rti = rt[i];
-        const double Ddi = Dd[i], rhi = rhs[d.n + i], wi = wN[d.n + i], soli = sol[d.n + i];
+        const double Ddi = Dd[i], rhi = rhs[d.n + i], soli = sol[d.n + i];
+#if SQPHIP_VEC_FUSE
+        const double wi = rti != ROW_FREE ? jac_row(d, jv, sv, i) : 0.0;
+#else
+        const double wi = wN[d.n + i];
+#endif
         const double dd = rti == ROW_FREE ? 1.0 : Ddi + IPM_REG_D;
         const double r = rhi - (wi - dd * soli);
         wN[d.n + i] = r; en = fmax(en, fabs(r));
