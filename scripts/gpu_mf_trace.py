@@ -5,9 +5,10 @@ import numpy as np
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
 from sqpsolver_jl_amd import _lib
-so = "/tmp/libsqphip_trace.so"
+so = os.environ.get("SQPHIP_TRACE_SO", "/tmp/libsqphip_trace.so")       # (a traced build made beforehand, or built here)
 srcs = [os.path.join(_lib._CSRC, s) for s in _lib.SOURCES]
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w",
+if "SQPHIP_TRACE_SO" not in os.environ:
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w",
                        "-DSQPHIP_MF_TRACE", "-mllvm", "-amdgpu-mfma-vgpr-form", "-o", so] + srcs + ["-ldl"])
 _lib.SO_PATH = so
 import sqpsolver_jl_amd as pkg
