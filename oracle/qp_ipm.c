@@ -873,7 +873,8 @@ static int ipm_run(ora_qp *q, const double *p_start, const double *y_start)
     const int eq_steps = getenv("ORA_EQ_STEPS") ? atoi(getenv("ORA_EQ_STEPS")) : 0;
     int short_lim = 0, n_short = 0;
     double short_a = 0.1;
-    if (getenv("ORA_MPC_SHORT")) sscanf(getenv("ORA_MPC_SHORT"), "%d,%lf", &short_lim, &short_a);
+    double short_dw = 0.0;
+    if (getenv("ORA_MPC_SHORT")) sscanf(getenv("ORA_MPC_SHORT"), "%d,%lf,%lf", &short_lim, &short_a, &short_dw);
     /* iteration limit; half of it for a second-order correction: one that has not converged by then is abandoned,
      * which for run! is the same as any other unsuccessful correction (same rule as the product, ipm.hip k_ipm_prepare) */
     const int it_max = q->cur_mode == ORA_MODE_SOC ? q->opt.ipm_max_iter / 2 : q->opt.ipm_max_iter;
@@ -985,9 +986,10 @@ static int ipm_run(ora_qp *q, const double *p_start, const double *y_start)
         }
         if (!ok) { rc = 2; break; }
         dw_prev = dw;
-        if (mpc && short_lim > 0) {     /* experiment (ORA_MPC_SHORT=k,a): k consecutive predictor-corrector steps below a end that mode */
+        if (mpc && short_lim > 0) {     /* experiment (ORA_MPC_SHORT=k,a[,dw]): k consecutive predictor-corrector steps below a end that mode
+                                         * (and, with dw, the next iteration starts from that regularisation: a Levenberg-Marquardt damping) */
             n_short = alpha < short_a ? n_short + 1 : 0;
-            if (n_short >= short_lim) { mpc = 0; mu = fmax(mu_min, fmin(1.0, ms.cavg)); }
+            if (n_short >= short_lim) { mpc = 0; mu = fmax(mu_min, fmin(1.0, ms.cavg)); if (short_dw > 0.0) dw_prev = 3.0 * short_dw; }
         }
         for (int64_t j = 0; j < n; ++j) {
             q->p[j] = nudge_inside(q->p[j] + alpha * q->dp[j], q->lb[j], q->ub[j]);
