@@ -49,7 +49,6 @@ extern "C" int sqphip_vec_trace_read(long long *out) { return (int)hipMemcpyFrom
 #define IPM_REG_P 1e-8
 #define IPM_REG_D 1e-8
 
-// out_j = hsc * (H v)_j + hd_j v_j   (H full symmetric CSC, gather by column)
 // one row of (hsc H + diag hd) v and of J v (the caller has excluded free rows): the sums hess_mul / jac_mul store, for the
 // loops that consume a row's product in the thread that formed it (no trip through global memory, no barrier)
 __device__ __forceinline__ double hess_row(const DV &d, const double *hv, const double *hd, double hsc, const double *v, int j)
@@ -69,6 +68,7 @@ __device__ __forceinline__ double jac_row(const DV &d, const double *jv, const d
     for (int k = k0; k < k1; ++k) acc += jv[d.jrslot[k]] * v[d.jrcol[k]];
     return acc;
 }
+// out_j = hsc * (H v)_j + hd_j v_j   (H full symmetric CSC, gather by column)
 __device__ void hess_mul(const DV &d, int inst, double hsc, const double *v, double *out)
 {
     const double *hv = d.hv + (long)inst * d.nnzhc, *hd = d.hd + (long)inst * d.n;
