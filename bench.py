@@ -192,7 +192,7 @@ def main():
         solved_here = 0
         for s_id in range(M):
             r_ = qctx.stream_get(s_id)
-            if r_["iter"] > 0:
+            if r_["iter"] >= 0:          # (-1: not filed by this rank since the ids were assigned, sqphip.h)
                 st[s_id], it[s_id], obj[s_id] = r_["status"], r_["iter"], r_["obj_val"]; solved_here += 1
         tabs = [(st, it, obj, solved_here, int(qc["n_qp"]))]
         if world > 1:

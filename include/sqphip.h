@@ -142,6 +142,12 @@ int sqphip_qp_solve(sqphip_ctx *ctx, int32_t mode, const double *x_k, double del
                     double *slack, int32_t *moi_status);
 /* statistics of the last sqphip_qp_solve: interior-point iterations, KKT factorisations */
 int sqphip_qp_stats(const sqphip_ctx *ctx, int32_t *ipm_iters, int32_t *n_factor);
+/* ... how its last interior-point run ended: rule 0 = scaled optimality error <= options.ipm_tol, 1 / 2 / 3 = one of the
+ * acceptable-termination rules (8 consecutive iterates within 100 x the tolerance, 15 within 1 000 x, 25 within 10^4 x:
+ * what Ipopt's acceptable_tol / acceptable_iter do for the reference's sub-solver, test/ext_solver.jl:2-6), -1 = not
+ * converged; scaled_error = that error at the final iterate.  A sub-problem reported LOCALLY_SOLVED under rule 3 is
+ * accurate to 1e4 x ipm_tol only. */
+int sqphip_qp_termination(const sqphip_ctx *ctx, int32_t *rule, double *scaled_error);
 
 /* ---- merit / acceptance path (device reductions over host-supplied vectors) -------------------- */
 /* common.jl:54-77; pnorm 1, 2 or 0 (=Inf) */
@@ -275,7 +281,8 @@ int sqphip_sqp_run(sqphip_ctx *ctx, int32_t max_outer);
  * 8f-4, load re-balancing of stragglers).  Which slot solves which scenario depends on timing, the result of a
  * scenario does not.  _begin allocates tables for n_scenarios; _set uploads one scenario (the arguments of
  * sqphip_set_bounds and sqphip_acopf_set_instance); _run solves them all; _get returns one result (final point,
- * objective, status as src/status.jl, iterations). */
+ * objective, status as src/status.jl, iterations; iterations = -1: this context has filed no result for the scenario since
+ * the last _stream_run / _stream_assign -- another rank solved it, or it is still waiting or in progress). */
 int sqphip_sqp_stream_begin(sqphip_ctx *ctx, int32_t n_scenarios);
 int sqphip_sqp_stream_set(sqphip_ctx *ctx, int32_t scenario, const double *xL, const double *xU, const double *gL,
                           const double *gU, const double *ohm, const double *c2, const double *c1, const double *x0);
@@ -355,6 +362,12 @@ int sqphip_sqp_work(sqphip_ctx *ctx, int64_t *sub_problems, int64_t *ipm_iterati
 /* The last (up to 64) sub-problems of one instance in the order they finished: rows of four int32 (mode, MOI status,
  * interior-point iterations, factorisations); *n_rows receives the number written (cap: rows available in `rows`). */
 int sqphip_sqp_qp_log(sqphip_ctx *ctx, int32_t inst, int32_t *rows, int32_t cap, int32_t *n_rows);
+/* ... and for the same rows: the scaled optimality error each ended with and the rule that ended it (as
+ * sqphip_qp_termination; either array may be NULL) */
+int sqphip_sqp_qp_log_term(sqphip_ctx *ctx, int32_t inst, double *scaled_error, int32_t *rule, int32_t cap, int32_t *n_rows);
+/* Sub-problems of the batched run since sqphip_sqp_reset by the way their interior-point run ended: out4[0] tolerance
+ * reached, out4[1..3] acceptable-termination rule 1 / 2 / 3 (sqphip_qp_termination). */
+int sqphip_get_termination_counters(sqphip_ctx *ctx, int64_t *out4);
 /* Diagnostics: the sub-problem request instance `inst` of the batched run worked on last, in the argument convention of
  * sqphip_qp_solve (x_k[n], c[n], b[m], jac_coo[nnzJ], hess_coo[nnzH]; any pointer may be NULL), so that a sub-problem
  * seen on the device can be replayed through sqphip_qp_solve or another solver. */

@@ -4,6 +4,7 @@
  * catalogued in SURVEY.md Appendix C. */
 #include "sqp_oracle.h"
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -175,6 +176,10 @@ static int qp_call(sqp_t *s, int mode, const double *b, double *p, double *lam, 
     int a, b2; ora_qp_stats(s->optimizer, &a, &b2, NULL);
     s->res->n_qp++; s->res->n_ipm_iter += a; s->res->n_factor += b2;
     s->it_ipm += a; s->it_fac += b2;
+    if (getenv("ORA_QP_LOG")) {          /* experiment aid: one line per sub-problem (mode, status, work, radius, last acceptance) */
+        FILE *fh = fopen(getenv("ORA_QP_LOG"), "a");
+        if (fh) { fprintf(fh, "%d %d %d %d %d %.6e %d\n", mode, st, a, b2, s->iter, s->Delta, s->step_acceptance); fclose(fh); }
+    }
     return st;
 }
 

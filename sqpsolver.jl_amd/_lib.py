@@ -151,6 +151,9 @@ def lib():
             L.sqphip_qp_solve.argtypes = [vp, C.c_int32, dp, C.c_double, C.c_double, dp, dp, dp, dp,
                                           dp, dp, dp, dp, dp, ip]
             L.sqphip_qp_stats.argtypes = [vp, ip, ip]
+            L.sqphip_qp_termination.argtypes = [vp, ip, dp]
+            L.sqphip_sqp_qp_log_term.argtypes = [vp, C.c_int32, dp, ip, C.c_int32, ip]
+            L.sqphip_get_termination_counters.argtypes = [vp, C.POINTER(C.c_int64)]
             L.sqphip_norm_violations.argtypes = [vp, dp, dp, C.c_int32, dp]
             L.sqphip_kt_residuals.argtypes = [vp, dp, dp, dp, dp, dp, dp]
             L.sqphip_norm_complementarity.argtypes = [vp, dp, dp, C.c_int32, dp]
@@ -207,7 +210,7 @@ def lib():
 
 EXPORTS = [
     "sqphip_default_options", "sqphip_create", "sqphip_destroy", "sqphip_last_error",
-    "sqphip_set_bounds", "sqphip_qp_solve", "sqphip_qp_stats", "sqphip_norm_violations",
+    "sqphip_set_bounds", "sqphip_qp_solve", "sqphip_qp_stats", "sqphip_qp_termination", "sqphip_sqp_qp_log_term", "sqphip_get_termination_counters", "sqphip_norm_violations",
     "sqphip_kt_residuals", "sqphip_norm_complementarity", "sqphip_compute_phi",
     "sqphip_compute_qmodel", "sqphip_compute_derivative", "sqphip_compute_derivative_full", "sqphip_compute_mu_rule_dev",
     "sqphip_acopf_armijo", "sqphip_tr_update",

@@ -131,6 +131,7 @@ void make_lanes(Ctx &C)
         L->is_lane = true;
         L->opt = C.opt; L->n = C.n; L->m = C.m; L->acopf_attached = C.acopf_attached;
         L->mfp_ = C.mfp_;
+        L->trans_period = C.trans_period; L->mf_big_lds = C.mf_big_lds;
         L->d = group_view(C.d, lo, hi - lo, g);
         // the first group runs on the owner's stream (idle during sqphip_sqp_run): HIP maps streams onto four hardware
         // queues by default, and a fifth stream would share one -- measured: 3131 QP/s with five streams against 5216
@@ -373,6 +374,8 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
             C.plan.init_lookahead();
         }
         SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        if (const char *e = getenv("SQPHIP_TRANS_PERIOD")) C.trans_period = atoi(e);      // experiment switch, read once per context
+        if (d.sparse) mf_device_setup(C);
         make_lanes(C);
         return SQPHIP_OK;
     });
@@ -446,6 +449,7 @@ extern "C" int sqphip_qp_solve(sqphip_ctx *h, int32_t mode, const double *x_k, d
         SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
         *moi_status = st.status;
         C.last_ipm_iters = st.ipm_iters; C.last_n_factor = st.n_factor;
+        C.last_rule = st.rc == 0 ? st.acc_rule : -1; C.last_e0 = st.e0;
         C.n_qp += 1; C.n_ipm_iter += st.ipm_iters; C.n_factor += st.n_factor; C.n_solve += st.n_solve;
         C.total_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         return SQPHIP_OK;
@@ -503,6 +507,14 @@ extern "C" int sqphip_qp_stats(const sqphip_ctx *h, int32_t *ipm_iters, int32_t 
     if (!h) return SQPHIP_EINVAL;
     if (ipm_iters) *ipm_iters = h->c.last_ipm_iters;
     if (n_factor) *n_factor = h->c.last_n_factor;
+    return SQPHIP_OK;
+}
+
+extern "C" int sqphip_qp_termination(const sqphip_ctx *h, int32_t *rule, double *scaled_error)
+{
+    if (!h) return SQPHIP_EINVAL;
+    if (rule) *rule = h->c.last_rule;
+    if (scaled_error) *scaled_error = h->c.last_e0;
     return SQPHIP_OK;
 }
 
@@ -1069,6 +1081,39 @@ extern "C" int sqphip_sqp_qp_log(sqphip_ctx *h, int32_t inst, int32_t *rows, int
     });
 }
 
+extern "C" int sqphip_sqp_qp_log_term(sqphip_ctx *h, int32_t inst, double *scaled_error, int32_t *rule, int32_t cap, int32_t *n_rows)
+{
+    if (!h || !n_rows || cap < 0) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) -> int {
+        if (!C.d.sst || inst < 0 || inst >= C.d.B) return SQPHIP_EINVAL;
+        SqpState S;
+        SQPHIP_HIP_OK(hipMemcpyAsync(&S, C.d.sst + inst, sizeof(SqpState), hipMemcpyDeviceToHost, C.stream));
+        SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        const int have = S.qlog_n < SQPHIP_QLOG_CAP ? S.qlog_n : SQPHIP_QLOG_CAP, n = have < cap ? have : cap;
+        for (int k = 0; k < n; ++k) {
+            const int src = (S.qlog_n - n + k) % SQPHIP_QLOG_CAP;
+            if (scaled_error) scaled_error[k] = (double)S.qerr[src];
+            if (rule) rule[k] = (int32_t)S.qrule[src];
+        }
+        *n_rows = n;
+        return SQPHIP_OK;
+    });
+}
+
+extern "C" int sqphip_get_termination_counters(sqphip_ctx *h, int64_t *out)
+{
+    if (!h || !out) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) -> int {
+        for (int k = 0; k < 4; ++k) out[k] = 0;
+        if (!C.d.sst) return SQPHIP_OK;
+        std::vector<SqpState> S((size_t)C.d.B);
+        SQPHIP_HIP_OK(hipMemcpyAsync(S.data(), C.d.sst, sizeof(SqpState) * C.d.B, hipMemcpyDeviceToHost, C.stream));
+        SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        for (auto &s : S) for (int k = 0; k < 4; ++k) out[k] += s.term_rule[k];
+        return SQPHIP_OK;
+    });
+}
+
 extern "C" int sqphip_sqp_last_request(sqphip_ctx *h, int32_t inst, int32_t *mode, double *delta, double *mu_pen,
                                        double *x_k, double *c, double *b, double *jac_coo, double *hess_coo)
 {
@@ -1119,6 +1164,8 @@ extern "C" int sqphip_sqp_stream_begin(sqphip_ctx *h, int32_t n_scenarios)
         // sqphip_sqp_stream_run arms the slots (-2), so a plain sqp_reset / sqp_run between _begin and _stream_run
         // behaves as if no queue existed (dalloc zero-fills, and 0 is a valid scenario id)
         SQPHIP_HIP_OK(hipMemsetAsync(Q.slot_scen, 0xff, sizeof(int) * (size_t)d.B, C.stream));
+        // riter = -1: "no result filed by this context" (sqphip_sqp_stream_get; reset by _stream_run and _stream_assign)
+        SQPHIP_HIP_OK(hipMemsetAsync(Q.riter, 0xff, sizeof(int) * M, C.stream));
         SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
         make_lanes(C);
         return SQPHIP_OK;
@@ -1158,6 +1205,7 @@ extern "C" int sqphip_sqp_stream_run(sqphip_ctx *h)
     return guarded(h, [&](Ctx &C) {
         auto t0 = std::chrono::steady_clock::now();
         SQPHIP_HIP_OK(hipMemsetAsync(C.d.stream.next, 0, sizeof(int), C.stream));
+        SQPHIP_HIP_OK(hipMemsetAsync(C.d.stream.riter, 0xff, sizeof(int) * (size_t)C.d.stream.M, C.stream));   // results of an earlier pass are not this pass's
         sqp_stream_arm(C);
         C.stream_started = true;
         sqp_run(C, 0);
@@ -1189,6 +1237,7 @@ extern "C" int sqphip_sqp_stream_assign(sqphip_ctx *h, int32_t n, const int32_t 
         if (n > 0) SQPHIP_HIP_OK(hipMemcpyAsync(C.d.stream.qids, ids, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, C.stream));
         SQPHIP_HIP_OK(hipMemcpyAsync(C.d.stream.qend, &n, sizeof(int), hipMemcpyHostToDevice, C.stream));
         SQPHIP_HIP_OK(hipMemcpyAsync(C.d.stream.next, &zero, sizeof(int), hipMemcpyHostToDevice, C.stream));
+        SQPHIP_HIP_OK(hipMemsetAsync(C.d.stream.riter, 0xff, sizeof(int) * (size_t)C.d.stream.M, C.stream));   // nothing filed yet under the new assignment
         SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
         C.stream_started = false;
         return SQPHIP_OK;

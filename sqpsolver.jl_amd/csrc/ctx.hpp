@@ -32,6 +32,7 @@ struct IpmState {
     int prev_mode;                 // 1 + mode of this instance's last solved sub-problem (options.ipm_warm_start), 0 none
     int status, ipm_iters, n_factor, n_solve;   // n_solve: forward + backward solves with the factors (incl. refinement)
     int sel;                       // which of the two factorisations of the last sweep the solves use (mfront.hip, candidates)
+    int acc_rule;                  // how the last run of this sub-problem ended: 0 scaled error <= ipm_tol, 1 / 2 / 3 the acceptable-termination rules (b_ipm_prepare)
     double elastic;
 };
 
@@ -46,6 +47,9 @@ struct SqpState {
     long tot_ipm, tot_fac, tot_sol;
     long md_qp[4], md_ipm[4], md_fac[4];   // the same work split by sub-problem mode (0 QP, 1 FR, 2 SOC, 3 LP phase)
     int qlog_n, qlog[4 * SQPHIP_QLOG_CAP]; // the last sub-problems of this instance: mode, MOI status, iterations, factorisations
+    float qerr[SQPHIP_QLOG_CAP];           // ... their final scaled error (IpmState.e0) and the rule that ended them (IpmState.acc_rule)
+    signed char qrule[SQPHIP_QLOG_CAP];
+    long term_rule[4];                     // sub-problems ended by the tolerance / acceptable rule 1, 2, 3 since sqphip_sqp_reset
     int budget;          // outer iterations this instance may still start in the current sqp_run call
 };
 
@@ -172,6 +176,11 @@ struct Ctx {
     std::vector<std::unique_ptr<Ctx>> lanes;
     bool is_lane = false, owns_stream = true;
     long mf_factor_launches = 0, n_sweeps = 0;
+    // Transitions between sub-problems run every trans_period-th sweep of a RUN (ipm_sweep): run_sweep counts the sweeps
+    // of the current sqphip_sqp_run / _stream_run call, so the first sweep of every run is a transition sweep -- slots
+    // armed by the scenario queue draw their scenario there, whatever the lifetime counter n_sweeps says.
+    long run_sweep = 0;
+    int trans_period = 0;           // 0: by group size (3 from 64 instances, 2 from 32, else 1); SQPHIP_TRANS_PERIOD, read at creation
     Timers tm;
     std::vector<void *> allocs;
     std::string err;
@@ -179,6 +188,7 @@ struct Ctx {
     int *h_counters = nullptr;  // pinned
     std::vector<int> h_kpos;    // host copy of DV::kpos (row -> kept position or -1)
     bool acopf_attached = false;
+    bool mf_big_lds = false;        // the multifrontal kernels were granted 160 KB of dynamic LDS on this context's device (mf_device_setup)
     bool stream_started = false;    // scenario queue: the slots have been armed (sqphip_sqp_stream_run / _run_some)
     // RCCL communicator for the status gather (comm.hip); null: single rank
     void *comm = nullptr, *comm_buf = nullptr;
@@ -188,7 +198,8 @@ struct Ctx {
     // counters
     int64_t n_qp = 0, n_ipm_iter = 0, n_factor = 0, n_solve = 0;
     double total_seconds = 0;
-    int last_ipm_iters = 0, last_n_factor = 0;
+    int last_ipm_iters = 0, last_n_factor = 0, last_rule = -1;
+    double last_e0 = 0.0;
 
     template <class T> T *dalloc(size_t count)
     {
@@ -218,6 +229,7 @@ void launch_qp_gather(Ctx &C);       // COO -> CSC for instances with start set 
 // comm.hip
 void comm_release(Ctx &C);
 // mfront.hip
+void mf_device_setup(Ctx &C);
 void mf_factor(Ctx &C, int want, bool with_rhs);
 void mf_solve(Ctx &C, int want, bool skip_fwd);
 // acopf.hip

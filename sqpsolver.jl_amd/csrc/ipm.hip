@@ -386,7 +386,8 @@ static __device__ void b_ipm_prepare(const DV &d)
     // test demands (9241-bus shape; never fires on the IEEE-118 workload; oracle/qp_ipm.c, ipm_run, has the data)
     const int n_acc3 = e0 <= 1e4 * d.ipm_tol ? n_acc3_prev + 1 : 0;
     if (e0 <= d.ipm_tol || n_acc >= 8 || n_acc2 >= 15 || n_acc3 >= 25) {
-        if (threadIdx.x == 0) { st.rc = 0; d.phase[inst] = PH_DONE; }
+        // (which rule ended the run and at what scaled error is reported: sqphip_qp_termination, sqphip_sqp_qp_log_term)
+        if (threadIdx.x == 0) { st.rc = 0; st.e0 = e0; st.acc_rule = e0 <= d.ipm_tol ? 0 : (n_acc >= 8 ? 1 : (n_acc2 >= 15 ? 2 : 3)); d.phase[inst] = PH_DONE; }
         return;
     }
     if (threadIdx.x == 0) { st.n_acc = n_acc; st.n_acc2 = n_acc2; st.n_acc3 = n_acc3; }
@@ -1075,9 +1076,12 @@ void ipm_sweep(Ctx &C, bool sqp_level)
     // (gated out of everything meanwhile), and the sweeps in between start with k_ipm_rhs.  Which sweep an instance
     // moves on in changes nothing it computes.  Measured (driver's command, 512 x IEEE-118, groups of 128): P = 1 / 2 / 3 / 4
     // -> 7 443 / 7 682 / 7 769 / 7 763 QP/s with identical work counters; 64 scenarios (groups of 16): 2 020 / 2 023 / 2 002.
-    // Default: 3 for groups of 64 instances and more, 2 from 32 on, else 1; SQPHIP_TRANS_PERIOD overrides.
-    const int period = getenv("SQPHIP_TRANS_PERIOD") ? atoi(getenv("SQPHIP_TRANS_PERIOD")) : (d.B >= 64 ? 3 : (d.B >= 32 ? 2 : 1));
-    const bool trans = !sqp_level || period <= 1 || (C.n_sweeps % period) == 1 % period;
+    // Default: 3 for groups of 64 instances and more, 2 from 32 on, else 1; SQPHIP_TRANS_PERIOD overrides (read once, at creation).
+    // The position is counted per RUN (Ctx::run_sweep, reset by sqp_run_lane): the first sweep of every run is a transition
+    // sweep -- a run that starts with every slot idle (scenario queue) draws its scenarios there.
+    const int period = C.trans_period > 0 ? C.trans_period : (d.B >= 64 ? 3 : (d.B >= 32 ? 2 : 1));
+    const bool trans = !sqp_level || period <= 1 || (C.run_sweep % period) == 0;
+    C.run_sweep++;
     if (trans) {
         hipLaunchKernelGGL(k_qp_finish, gB, bT, 0, s, d);
         if (sqp_level) sqp_stage_kernels(C);

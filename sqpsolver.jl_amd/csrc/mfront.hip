@@ -24,6 +24,7 @@
 #include "ctx.hpp"
 #include "dev_util.hpp"
 #include <cstdlib>
+#include <mutex>
 
 namespace sqphip {
 
@@ -1618,6 +1619,25 @@ static int mf_generic_solves()
     return g;
 }
 
+// Kernels that ask for more than 64 KB of dynamic LDS need the attribute set on the device they run on: done for every
+// context at creation, on the context's device (a process may hold contexts on several devices; the attribute is per
+// device -- ADVICE r3), under a lock (contexts may be created from several host threads).
+void mf_device_setup(Ctx &C)
+{
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    bool ok = true;
+    auto big = [&](const void *f) { ok &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; };
+    big(reinterpret_cast<const void *>(k_mf_front<6, 4, true>)); big(reinterpret_cast<const void *>(k_mf_front<7, 4, true>));
+    big(reinterpret_cast<const void *>(k_mf_front<8, 4, true>)); big(reinterpret_cast<const void *>(k_mf_front<6, 8, true>));
+    big(reinterpret_cast<const void *>(k_mf_front<7, 8, true>)); big(reinterpret_cast<const void *>(k_mf_front<8, 8, true>));
+    big(reinterpret_cast<const void *>(k_mf_fwd2<true>)); big(reinterpret_cast<const void *>(k_mf_bwd2<true>));
+    big(reinterpret_cast<const void *>(k_mf_fwd2<false>)); big(reinterpret_cast<const void *>(k_mf_bwd2<false>));
+    big(reinterpret_cast<const void *>(k_mf_solve_top2));
+    (void)hipGetLastError();
+    C.mf_big_lds = ok;
+}
+
 void mf_factor(Ctx &C, int want, bool with_rhs)
 {
     const DV &d = C.d;
@@ -1646,17 +1666,7 @@ void mf_factor(Ctx &C, int want, bool with_rhs)
         // ... and eight instead of four for six to eight tile rows there: 7 323 -> 7 403 QP/s, same bits (SQPHIP_MF_NW8=0: four)
         const bool nw8 = !(getenv("SQPHIP_MF_NW8") && atoi(getenv("SQPHIP_MF_NW8")) == 0);
         const int nw4 = L.count <= 8 ? (getenv("SQPHIP_MF_NW4") ? atoi(getenv("SQPHIP_MF_NW4")) : 3) : 0;
-        static const bool big_attr = [] {
-            bool ok = true;
-            ok &= hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_front<6, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-            ok &= hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_front<7, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-            ok &= hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_front<8, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-            ok &= hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_front<6, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-            ok &= hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_front<7, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-            ok &= hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_front<8, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-            return ok;
-        }();
-        const bool big_img = big_attr && !(getenv("SQPHIP_MF_BIG_LDSIMG") && atoi(getenv("SQPHIP_MF_BIG_LDSIMG")) == 0);     // (read per call: tests flip it)
+        const bool big_img = C.mf_big_lds && !(getenv("SQPHIP_MF_BIG_LDSIMG") && atoi(getenv("SQPHIP_MF_BIG_LDSIMG")) == 0);     // (read per call: tests flip it)
         if (!stat || T > 8 || T < stat_min) {
             if (T <= 2) MF_GENERIC(1, 3, true);
             else if (T <= 4) MF_GENERIC(2, 5, true);
@@ -1701,11 +1711,7 @@ void mf_solve(Ctx &C, int want, bool skip_fwd)
     }
     // level launches: the LDS-staged kernels where every front of the level fits them (mfplan.hip: L.wimg >= 0)
     const bool lvl2 = !(getenv("SQPHIP_MF_LEVEL2") && atoi(getenv("SQPHIP_MF_LEVEL2")) == 0);      // (read per call: tests flip it)
-    static const hipError_t attr_f = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_fwd2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    static const hipError_t attr_b = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_bwd2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    static const hipError_t attr_f0 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_fwd2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    static const hipError_t attr_b0 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_bwd2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    SQPHIP_HIP_OK(attr_f); SQPHIP_HIP_OK(attr_b); SQPHIP_HIP_OK(attr_f0); SQPHIP_HIP_OK(attr_b0);
+    if (!C.mf_big_lds) throw std::string("sqphip: the solve kernels could not be granted 160 KB of dynamic LDS on this device (mf_device_setup)");
     if (!skip_fwd)
         for (const MfLaunch &L : C.mfp().fwd) {
             if (lvl2 && !generic && L.wimg >= 0) {
@@ -1716,9 +1722,6 @@ void mf_solve(Ctx &C, int want, bool skip_fwd)
         }
     if (d.mf.top_n > 0 && !generic) {
         const size_t lds = (size_t)C.mfp().top2_lds_bytes;
-        // more than 64 KB of dynamic LDS has to be asked for, once (thread-safe: the instance groups launch concurrently)
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mf_solve_top2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        SQPHIP_HIP_OK(attr);
         hipLaunchKernelGGL(k_mf_solve_top2, dim3(d.B), dim3(256), lds, s, d, want, skip_fwd ? 0 : 1);
     } else if (const MfLaunch &T = C.mfp().top; T.count > 0)
         hipLaunchKernelGGL(k_mf_solve_top, dim3(d.B), dim3(256), T.lds_bytes, s, d, T.begin, T.count, want, skip_fwd ? 0 : 1, generic,

@@ -133,6 +133,8 @@ static __device__ __forceinline__ void book_mode(SqpState &S, const IpmState &I)
     S.md_qp[k]++; S.md_ipm[k] += I.ipm_iters; S.md_fac[k] += I.n_factor;
     int *q = S.qlog + 4 * (S.qlog_n % SQPHIP_QLOG_CAP);
     q[0] = I.mode; q[1] = I.status; q[2] = I.ipm_iters; q[3] = I.n_factor;
+    S.qerr[S.qlog_n % SQPHIP_QLOG_CAP] = (float)I.e0; S.qrule[S.qlog_n % SQPHIP_QLOG_CAP] = (signed char)(I.rc == 0 ? I.acc_rule : -1);
+    if (I.rc == 0) S.term_rule[I.acc_rule & 3]++;
     S.qlog_n++;
 }
 
@@ -168,7 +170,7 @@ static __device__ __forceinline__ void reset_instance(const DV &d, int inst, boo
         z.step_acceptance = 1; z.fr = 0; z.iter = 1; z.ret = -5;
         if (keep_totals) {
             z.n_qp = S.n_qp; z.tot_ipm = S.tot_ipm; z.tot_fac = S.tot_fac; z.tot_sol = S.tot_sol; z.budget = S.budget;
-            for (int k = 0; k < 4; ++k) { z.md_qp[k] = S.md_qp[k]; z.md_ipm[k] = S.md_ipm[k]; z.md_fac[k] = S.md_fac[k]; }
+            for (int k = 0; k < 4; ++k) { z.md_qp[k] = S.md_qp[k]; z.md_ipm[k] = S.md_ipm[k]; z.md_fac[k] = S.md_fac[k]; z.term_rule[k] = S.term_rule[k]; }
         }
         S = z;
         I.start = 0; I.dw_last = 0.0; I.prev_mode = 0;
@@ -562,6 +564,7 @@ static void sqp_run_lane(Ctx &C, int max_outer)
     DV &d = C.d;
     hipStream_t s = C.stream;
     const dim3 gB(d.B), bT(TPB);
+    C.run_sweep = 0;                     // (the first sweep of a run always carries the transitions: ipm_sweep)
     hipLaunchKernelGGL(k_sqp_budget, dim3(1), dim3(64), 0, s, d, max_outer > 0 ? max_outer : 0x3fffffff);
     hipLaunchKernelGGL(k_sqp_begin, gB, bT, 0, s, d);
     // The "anyone left?" counter of sweep k is read while sweep k + 1 is already queued: the stream never runs dry

@@ -159,8 +159,10 @@ class Context:
                                         _d(p), _d(lam), _d(mu_u), _d(mu_l), _d(slack), C.byref(st)))
         it, nf = C.c_int32(), C.c_int32()
         self.L.sqphip_qp_stats(self.h, C.byref(it), C.byref(nf))
+        rule, err = C.c_int32(), C.c_double()
+        self.L.sqphip_qp_termination(self.h, C.byref(rule), C.byref(err))
         return dict(p=p, lam=lam, mult_x_U=mu_u, mult_x_L=mu_l, slack=slack, status=st.value,
-                    ipm_iters=it.value, n_factor=nf.value)
+                    ipm_iters=it.value, n_factor=nf.value, term_rule=rule.value, scaled_error=err.value)
 
     def compute_derivative_full(self, df, p, E, mu, mu_vec=None, feasibility_restoration=False, slack=None):
         """compute_derivative(sqp) of sqp.jl:190-213 over merit.jl:13-17 (vector penalty, restoration branch)."""
@@ -361,6 +363,19 @@ class Context:
         rows = np.zeros((64, 4), dtype=np.int32); n = C.c_int32()
         self._ck(self.L.sqphip_sqp_qp_log(self.h, inst, _i(rows), 64, C.byref(n)))
         return [tuple(int(v) for v in rows[k]) for k in range(n.value)]
+
+    def sqp_qp_log_term(self, inst):
+        """For the rows of sqp_qp_log: (final scaled optimality error, rule that ended the interior-point run: 0 tolerance,
+        1 / 2 / 3 acceptable-termination rules, -1 not converged)."""
+        err = np.zeros(64); rule = np.zeros(64, dtype=np.int32); n = C.c_int32()
+        self._ck(self.L.sqphip_sqp_qp_log_term(self.h, inst, _d(err), _i(rule), 64, C.byref(n)))
+        return [(float(err[k]), int(rule[k])) for k in range(n.value)]
+
+    def termination_counters(self):
+        """Sub-problems of the batched run since sqp_reset ended by (tolerance, rule 1, rule 2, rule 3)."""
+        out = (C.c_int64 * 4)()
+        self._ck(self.L.sqphip_get_termination_counters(self.h, out))
+        return tuple(int(v) for v in out)
 
     def sqp_last_request(self, inst):
         """The sub-problem request an instance of the batched run worked on last (arguments of QpHip / sqphip_qp_solve)."""

@@ -1441,6 +1441,57 @@ def test_scenario_queue_gives_the_batch_results(slots):
     q.close()
 
 
+def test_scenario_queue_second_pass_with_many_slots_solves_everything():
+    """with 32 or more slots per instance group the transitions between sub-problems run every second or
+    third sweep; the position used to be taken from the LIFETIME sweep counter, so a second sqphip_sqp_stream_run on a
+    context (every slot idle and armed) could start on a sweep without transitions, find "nobody left" and return OK with
+    nothing solved.  The position is counted per run now (the first sweep of a run always carries the transitions): 128
+    slots in one group (period 3), 140 scenarios, three passes -- each returns every scenario with the results of the
+    first pass, bit for bit -- and a budgeted pass (_run_some) behind an ordinary batched run on the same context."""
+    nb, ng, nl, seed = CASES["case14"]
+    base = acopf_synth(nb, ng, nl, seed)
+    M = 140
+    nets = [base] + [contingency(base, 1 + (s % 19), seed) for s in range(1, M)]
+    lays = [acopf_layout(nt) for nt in nets]
+    kw = dict(max_iter=40, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=0)
+    os.environ["SQPHIP_GROUPS"] = "1"                    # one group of 128 slots: transition period 3
+    try:
+        q = pkg.Context(lays[0].n, lays[0].m, lays[0].num_linear, lays[0].jrow, lays[0].jcol, lays[0].hrow, lays[0].hcol,
+                        lays[0].xL, lays[0].xU, lays[0].gL, lays[0].gU, pkg.default_options(**kw), batch=128)
+    finally:
+        del os.environ["SQPHIP_GROUPS"]
+    q.acopf_attach(base, lays[0])
+    q.stream_begin(M)
+    for s in range(M):
+        q.stream_set(s, nets[s], lays[s])
+    passes = []
+    for k in range(3):
+        q.stream_run()
+        res = [q.stream_get(s) for s in range(M)]
+        assert all(r["iter"] >= 1 for r in res), (k, [s for s, r in enumerate(res) if r["iter"] < 1][:8])
+        passes.append(res)
+        if k == 0:                                       # an odd number of sweeps between the passes, whatever the first took
+            q.sqp_reset(); q.sqp_run(1)
+    for k in (1, 2):
+        for s in range(M):
+            a, b = passes[0][s], passes[k][s]
+            assert (a["status"], a["iter"], a["obj_val"]) == (b["status"], b["iter"], b["obj_val"]) and np.array_equal(a["x"], b["x"]), (k, s)
+    # scenarios 1 .. 19 repeat every 19 ids: equal data, equal result
+    assert passes[0][1]["obj_val"] == passes[0][20]["obj_val"]
+    # a budgeted pass behind a plain batched run on the same context
+    q.sqp_reset(); q.sqp_run(2)
+    q.stream_assign(list(range(M)))
+    left, active, rounds = M, 1, 0
+    while (left > 0 or active > 0) and rounds < 200:
+        left, active = q.stream_run_some(5)
+        rounds += 1
+    res = [q.stream_get(s) for s in range(M)]
+    assert all(r["iter"] >= 1 for r in res)
+    for s in range(M):
+        assert (res[s]["status"], res[s]["iter"], res[s]["obj_val"]) == (passes[0][s]["status"], passes[0][s]["iter"], passes[0][s]["obj_val"]), s
+    q.close()
+
+
 def test_batch_of_eight_matches_oracle_instance_by_instance():
     """Batch 8 (XCD-aware tile map, eight concurrent stage workgroups): every instance against the oracle."""
     nb, ng, nl, seed = CASES["case14"]
