@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """Headline benchmark: QP sub-problems per second of the batched SQP-TR hot path on MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: the parent, which never touches a GPU,
+                                                            starts N rank processes itself and relays rank 0's line)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
            bench.py --gpus N --steps K --warmup W          (one rank per GPU; --gpus must equal WORLD_SIZE)
 
 One "step" = one SQP-TR outer iteration of every instance of the job: device ACOPF evaluation, the trust-region QP
 (or feasibility-restoration / second-order-correction) sub-problem solved by the on-device interior-point method,
 merit + ratio test.  Workload: BASELINE.json configs[3] -- 512 IEEE-118-shaped ACOPF contingency scenarios, ALL of
-them on one GPU at N = 1 and 512 / N per rank at N > 1 (strong scaling); Newton matrix of order 2813 condensed to 2069,
+them on one GPU at N = 1 and 512 / N per rank at N > 1 (strong scaling; --scaling weak: 512 per GPU, N x 512 in the job);
+Newton matrix of order 2813 condensed to 2069,
 factorised by the multifrontal path (options.kkt_mode = 0 picks it), fp64, synthetic data of that shape, SQP options
 of /root/reference/examples/acopf/opf.jl:76-79.  Inputs are resident in HBM before the timed region.  Ranks never
 exchange iterates; the timed region ends with one all-gather of (ret, iter, done) per instance over RCCL
@@ -46,6 +48,34 @@ def host_cores():
         return max(1, min(16, os.cpu_count() or 1))
 
 
+def self_launch(n):
+    """Start n rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as
+    torch.distributed.run sets them), let their stdout / stderr through, return the largest exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        for p in procs:
+            rc = max(rc, abs(p.wait()))
+    except KeyboardInterrupt:
+        for p in procs:
+            p.terminate()
+        rc = 130
+    if rc != 0:                    # a rank that died leaves the others waiting in a collective: end exactly the processes started here
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -58,7 +88,10 @@ def main():
     ap.add_argument("--topology", default=None, choices=["chain", "geo"],
                     help="synthetic network recipe: chain = SURVEY.md section 8d (default for case14 / case118), geo = lattice strip "
                          "with local generation (default for case1354 / case9241: the chain recipe gives no convergent NLP there)")
-    ap.add_argument("--batch", type=int, default=None, help="instances of the whole job (default 512 for case118)")
+    ap.add_argument("--batch", type=int, default=None, help="instances of the whole job (default 512 for case118); with --scaling weak: per GPU")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong (default, BASELINE configs[3]): the job's scenarios are split over the GPUs; weak: every GPU "
+                         "holds --batch scenarios (ids rank * batch ...), the job grows with N")
     ap.add_argument("--quick", action="store_true", help="development runs: timed steps only (implies --no-cpu-baseline --no-termination --no-dense-ldlt --no-screening)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-termination", action="store_true", help="skip the run-to-termination legs")
@@ -92,12 +125,23 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Typed without a launcher: this process -- which has made no GPU call and imported no GPU library -- starts one fresh
+        # rank process per GPU (the environment torch.distributed.run would give them), relays their output and leaves with
+        # their worst exit code.  Never an exec of a process that touched the GPU.
+        sys.exit(self_launch(args.gpus))
     if world != args.gpus:
         if rank == 0:
             print(f"[bench] --gpus {args.gpus} but WORLD_SIZE is {world}: launch N > 1 as\n"
+                  f"  python bench.py --gpus {args.gpus} ...   (starts the ranks itself), or\n"
                   f"  python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
                   f"--master-port 29500 bench.py --gpus {args.gpus} ...", file=sys.stderr)
         sys.exit(2)
+
+    if os.environ.get("SQPHIP_BENCH_RANK_ECHO"):      # test aid (tests/test_abi.py): what a rank process was started with; no GPU touched
+        print(json.dumps({"rank": rank, "world": world, "local_rank": local_rank, "master": os.environ.get("MASTER_ADDR"),
+                          "port": os.environ.get("MASTER_PORT")}), flush=True)
+        return
 
     import numpy as np
     import torch
@@ -122,7 +166,12 @@ def main():
 
     nb, ng, nl, seed = CASES[args.workload]
     total = args.batch or DEFAULT_BATCH[args.workload]
-    lo, hi = shard_range(total, world, rank)
+    if args.scaling == "weak":          # every GPU holds --batch scenarios: rank r solves the ids r * batch .. (r + 1) * batch - 1
+        per = total
+        total = per * world
+        lo, hi = rank * per, (rank + 1) * per
+    else:
+        lo, hi = shard_range(total, world, rank)
     B = hi - lo
     base = synth_case(args.workload, args.topology)
     topology = args.topology or ("chain" if nb <= 118 else "geo")
@@ -466,18 +515,27 @@ def main():
             cores = host_cores()
             n_s = min(total, {"case14": 512, "case118": 512, "case1354": 32, "case9241": 2}[args.workload])
             k_it = args.steps + args.warmup
-            oo = O.default_options(max_iter=k_it, literal_quirks=args.literal_quirks, num_threads=1, kkt_mode=2,
-                                   ipm_corrector=args.ipm_corrector, **sqp_kw)
             probs = [O.problem_acopf(*scenario(s)) for s in range(n_s)]
-            ta = time.perf_counter()
-            with ThreadPoolExecutor(max_workers=cores) as ex:          # ctypes releases the GIL inside ora_sqp_tr_solve
-                res = list(ex.map(lambda p: O.sqp_solve(p, oo), probs))
-            tb = time.perf_counter()
-            nq = sum(r["n_qp"] for r in res)
-            cpu = {"value": nq / (tb - ta), "unit": "QP subproblems/s", "cores": cores, "kind": "port",
-                   "sample": f"{args.workload} scenarios 0..{n_s - 1}, first {k_it} SQP-TR iterations each = {nq} sub-problems, "
-                             f"{sum(r['n_factor'] for r in res)} sparse LDL^T of order {N} (oracle/sparse_ldlt.c, its own "
-                             f"minimum-degree order), one scenario per thread on {cores} host threads, {tb - ta:.1f} s; CPU "
+
+            def cpu_run(iters):
+                oo = O.default_options(max_iter=iters, literal_quirks=args.literal_quirks, num_threads=1, kkt_mode=2,
+                                       ipm_corrector=args.ipm_corrector, **sqp_kw)
+                ta = time.perf_counter()
+                with ThreadPoolExecutor(max_workers=cores) as ex:          # ctypes releases the GIL inside ora_sqp_tr_solve
+                    res = list(ex.map(lambda p: O.sqp_solve(p, oo), probs))
+                return time.perf_counter() - ta, sum(r["n_qp"] for r in res), sum(r["n_factor"] for r in res)
+            # The timed GPU steps are outer iterations W + 1 .. W + K of every scenario (the warm-up iterations are the cheap
+            # ones: fewer interior-point iterations per sub-problem).  The oracle has no resumable state, so the same window is
+            # taken by difference: a run of W iterations and a run of W + K iterations, both from the start.
+            sec_all, nq_all, nf_all = cpu_run(k_it)
+            sec_w, nq_w, nf_w = cpu_run(args.warmup) if args.warmup > 0 else (0.0, 0, 0)
+            aligned = (nq_all - nq_w) / (sec_all - sec_w) if sec_all > sec_w and nq_all > nq_w else None
+            cpu = {"value": aligned if aligned is not None else nq_all / sec_all, "unit": "QP subproblems/s", "cores": cores, "kind": "port",
+                   "window": f"outer iterations {args.warmup + 1}..{k_it} (the timed steps), by difference of two runs from the start",
+                   "value_from_the_first_iteration": nq_all / sec_all,
+                   "sample": f"{args.workload} scenarios 0..{n_s - 1}: {nq_all - nq_w} sub-problems / {nf_all - nf_w} sparse LDL^T of order {N} "
+                             f"in the window ({nq_all} / {nf_all} from the first iteration; oracle/sparse_ldlt.c, its own minimum-degree "
+                             f"order), one scenario per thread on {cores} host threads, {sec_all:.1f} + {sec_w:.1f} s; CPU "
                              f"restatement (oracle/), not Julia/Ipopt"}
         except Exception as e:       # an optional leg must never cost the headline line
             print(f"[bench] optional record 'cpu' failed: {e!r}", file=sys.stderr)
@@ -496,7 +554,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / max(1, args.steps),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",

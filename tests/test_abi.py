@@ -256,14 +256,23 @@ def test_no_kernel_takes_its_arguments_through_scratch():
             assert v["VGPRs"] <= 128, (k, v)
 
 
-def test_bench_refuses_a_rank_count_it_was_not_launched_with():
-    """`python bench.py --gpus N` with N != WORLD_SIZE must not quietly measure one GPU and call it N:
-    exit code 2 and the torch.distributed.run command line, before anything touches a GPU."""
+def test_bench_starts_its_own_ranks_and_refuses_a_mismatched_launcher():
+    """`python bench.py --gpus N` typed without a launcher starts N rank processes itself (the parent touches no GPU) with
+    the environment torch.distributed.run would give them; under a launcher whose WORLD_SIZE differs it must not quietly
+    measure another rank count and call it N: exit code 2, before anything touches a GPU."""
+    import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--quick"],
+                       env=dict(env, SQPHIP_BENCH_RANK_ECHO="1"), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    rows = sorted((json.loads(ln) for ln in r.stdout.splitlines() if ln.strip()), key=lambda d: d["rank"])
+    assert [d["rank"] for d in rows] == [0, 1, 2] and all(d["world"] == 3 and d["local_rank"] == d["rank"] for d in rows)
+    assert all(d["master"] == "127.0.0.1" and d["port"] == rows[0]["port"] for d in rows)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1", RANK="0"),
+                       capture_output=True, text=True, timeout=120)
     assert r.returncode == 2 and "torch.distributed.run" in r.stderr and r.stdout.strip() == ""
 
 

@@ -247,6 +247,31 @@ def test_two_rank_rehearsal_gathers_the_single_rank_table(tmp_path):
     assert json.load(open(one)) == json.load(open(two))
 
 
+def test_bench_typed_with_two_gpus_starts_its_ranks_and_prints_one_line(tmp_path):
+    """`python3 bench.py --gpus 2 --backend gloo --one-device --quick` typed as is (no launcher, no RANK / WORLD_SIZE in the
+    environment): the parent starts the two rank processes itself and exactly one JSON line comes out, with n_gpus 2 --
+    strong scaling (4 + 4 of 8 scenarios, the single-rank table) and weak scaling (8 per rank, 16 in the job)."""
+    import subprocess, sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    common = ["--workload", "case14", "--batch", "8", "--steps", "3", "--warmup", "0", "--literal-quirks", "0", "--quick", "--no-kernel-timing"]
+    one = tmp_path / "one.json"; two = tmp_path / "two.json"
+    subprocess.run([_sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dump-status", str(one)] + common,
+                   check=True, cwd=root, env=env, capture_output=True, timeout=600)
+    r = subprocess.run([_sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--one-device",
+                        "--dump-status", str(two)] + common, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-800:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["scaling"] == "strong" and lines[0]["config"]["instances_per_gpu"] == 4
+    assert json.load(open(one)) == json.load(open(two))
+    r = subprocess.run([_sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--one-device",
+                        "--scaling", "weak"] + common, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-800:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["scaling"] == "weak"
+    assert lines[0]["config"]["instances_per_gpu"] == 8 and lines[0]["config"]["instances_total"] == 16
+
+
 # ------------------------------------------------------------------ K1: device ACOPF evaluator
 def _with_transformers(net, seed):
     """A third of the branches become transformers with off-nominal taps, a few of them phase shifters."""
