@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--kkt-mode", type=int, default=0, help="options.kkt_mode: 0 auto (sparse here), 1 dense MFMA, 2 sparse")
     ap.add_argument("--kkt-tile-order", type=int, default=None)
     ap.add_argument("--kkt-condense", type=int, default=None)
-    ap.add_argument("--ipm-corrector", type=int, default=1)
+    ap.add_argument("--ipm-corrector", type=int, default=0, help="0 (default): monotone barrier rule, Ipopt's default; 1: Mehrotra predictor-corrector")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event timing of the factor / solve kernels")
     ap.add_argument("--sqp-options", default="example", choices=["example", "defaults"],
                     help="example: tol_infeas 1e-6, tol_residual 1e-4, use_soc (examples/acopf/opf.jl:76-79, the headline); "

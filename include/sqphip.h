@@ -59,8 +59,12 @@ typedef struct {
                               * 5082-sub-problem survey of the IEEE-118 workload needed more than 83 iterations */
     int32_t ipm_phase1;      /* 1: confirm infeasibility verdicts with a phase-1 run (default 0) */
     int32_t device;          /* HIP device ordinal */
-    int32_t ipm_corrector;   /* 1 (default): Mehrotra predictor-corrector iterations until the first inertia
-                              * correction of a solve; 0: monotone Fiacco-McCormick rule throughout */
+    int32_t ipm_corrector;   /* 0 (default since round 4): monotone Fiacco-McCormick barrier rule throughout -- what Ipopt,
+                              * the sub-solver of every test and example of the reference, does by default (mu_strategy =
+                              * monotone; test/ext_solver.jl:2-6 and examples/acopf/opf.jl:59-64 leave it there): one solve
+                              * per factorisation; 1: Mehrotra predictor-corrector iterations until the first inertia
+                              * correction of a solve (4 % fewer factorisations on the IEEE-118 workload, a second solve per
+                              * iteration: 15 - 25 % slower end to end) */
     int32_t kkt_condense;    /* 1: rows with gL != gU (diagonal block -D of the Newton matrix) are eliminated before
                               * the factorisation: dense LDL^T of order n + #(gL == gU) instead of n + m */
     int32_t kkt_tile_order;  /* 1 (needs kkt_condense): the variables are ordered so that the leading tile columns of

@@ -24,6 +24,10 @@ int sqphip_mf_host_solve(int64_t n, int64_t m, int64_t nnzJ, const int64_t *jrow
  * its own plan arrays against the plain recursion of the same call; -1 when the plan has no such top (a front of more than
  * 128 rows or 84 columns, or SQPHIP_MF_TOP2=0).  Not thread safe (one global). */
 double sqphip_mf_host_top2_err(void);
+/* ... and of the host replay of the spine kernel's front assembly (k_mf_spine: gather entries from the arena, the block the
+ * previous front hands over through its row map, destination list) against the images the plain recursion assembled; -1
+ * when the plan has no spine (a front of more than eight tiles near the top, or SQPHIP_MF_SPINE=0). */
+double sqphip_mf_host_spine_err(void);
 /* Device twin of sqphip_mf_host_solve (kernel-level parity tests): the same Newton matrix, assembled, factorised and
  * solved by the multifrontal kernels in instance `inst` of a context that uses the sparse solver (kkt_mode 2, or 0
  * where it selects it).  sol_fused: right-hand side carried through the factorisation; sol_standalone: the

@@ -24,7 +24,7 @@ void ora_default_options(ora_options *o)
     o->ipm_max_iter = 200;
     o->ipm_phase1 = 0;
     o->num_threads = 1;
-    o->ipm_corrector = 1;
+    o->ipm_corrector = 0;   /* monotone rule: Ipopt's default mu_strategy (the reference leaves it there) */
     o->kkt_condense = 1;
     o->kkt_tile_order = 0;
     o->kkt_mode = 0;

@@ -60,9 +60,10 @@ typedef struct {
     int ipm_phase1;    /* 1: confirm an infeasibility verdict with a phase-1 run and escalate the penalty if it
                           disagrees; 0 (default): elastic mass left on a hard row means infeasible */
     int num_threads;   /* OpenMP threads for the dense LDL^T (cpu_baseline reports this) */
-    int ipm_corrector; /* 1 (default): Mehrotra predictor-corrector (adaptive barrier parameter + second-order term,
-                          two solves per factorisation) while the sub-problem behaves convex, monotone rule from the
-                          first inertia correction on; 0: monotone Fiacco-McCormick rule throughout */
+    int ipm_corrector; /* 0 (default since round 4): monotone Fiacco-McCormick rule throughout, Ipopt's default barrier strategy
+                          (mu_strategy = monotone; the reference's tests and examples leave it there); 1: Mehrotra
+                          predictor-corrector (adaptive barrier parameter + second-order term, two solves per factorisation)
+                          while the sub-problem behaves convex, monotone rule from the first inertia correction on */
     int kkt_condense;  /* 1: eliminate the rows with gL != gU (their block of the Newton matrix is the diagonal -D)
                           before factorising: dense LDL^T of order n + #equality rows instead of n + m */
     int kkt_tile_order; /* 0 (default): the oracle orders its factorisation by itself.  1 (tests of the product's dense

@@ -21,7 +21,7 @@ def run(s):
     net = base if s == 0 else contingency(base, s, seed)
     lay = acopf_layout(net)
     kw = dict(max_iter=MI, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=LQ)
-    r = O.sqp_solve(O.problem_acopf(net, lay), O.default_options(kkt_mode=2, num_threads=1, **kw))
+    r = O.sqp_solve(O.problem_acopf(net, lay), O.default_options(kkt_mode=2, num_threads=1, ipm_corrector=int(os.environ.get("EXP_CORRECTOR", "1")), **kw))
     rows = np.loadtxt(path, ndmin=2)
     os.remove(path)
     return s, r["status"], r["iter"], rows

@@ -7,4 +7,4 @@ from . import acopf_synth  # noqa: F401
 from . import _lib  # noqa: F401
 from . import host  # noqa: F401
 from .host import (Context, QpData, QpHip, default_options, SqpHipError, kkt_order,  # noqa: F401
-                   kkt_symbolic, mf_host_solve, mf_host_top2_err)
+                   kkt_symbolic, mf_host_solve, mf_host_top2_err, mf_host_spine_err)

@@ -11,7 +11,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 SO_PATH = os.path.join(_CSRC, "libsqphip.so")
 SOURCES = ["ldlt.hip", "kernel_api.hip", "ipm.hip", "acopf.hip", "sqp.hip", "api.hip", "order.hip", "symbolic.hip",
            "mfplan.hip", "mfront.hip", "comm.hip"]
-HEADERS = ["sqphip_internal.hpp", "ctx.hpp", "sparse.hpp", "dev_util.hpp", "acopf_dev.hpp", os.path.join("..", "..", "include", "sqphip.h"),
+HEADERS = ["sqphip_internal.hpp", "ctx.hpp", "sparse.hpp", "dev_util.hpp", "mf_dev.hpp", "acopf_dev.hpp", os.path.join("..", "..", "include", "sqphip.h"),
            os.path.join("..", "..", "include", "sqphip_test_hooks.h")]
 
 _lib = None
@@ -182,6 +182,8 @@ def lib():
                                                dp, dp, dp, dp, dp, ip, C.c_double, C.c_double, dp, dp, dp, ip]
             L.sqphip_mf_host_top2_err.argtypes = []
             L.sqphip_mf_host_top2_err.restype = C.c_double
+            L.sqphip_mf_host_spine_err.argtypes = []
+            L.sqphip_mf_host_spine_err.restype = C.c_double
             L.sqphip_mf_solve_test.argtypes = [vp, C.c_int32, dp, dp, dp, dp, dp, ip, C.c_double, C.c_double, dp, dp, dp, dp]
             L.sqphip_acopf_eval.argtypes = [vp, C.c_int32, dp, C.c_double, dp, dp, dp, dp, dp, dp]
             L.sqphip_sqp_reset.argtypes = [vp]
@@ -214,7 +216,7 @@ EXPORTS = [
     "sqphip_kt_residuals", "sqphip_norm_complementarity", "sqphip_compute_phi",
     "sqphip_compute_qmodel", "sqphip_compute_derivative", "sqphip_compute_derivative_full", "sqphip_compute_mu_rule_dev",
     "sqphip_acopf_armijo", "sqphip_tr_update",
-    "sqphip_kkt_order", "sqphip_kkt_symbolic", "sqphip_mf_host_solve", "sqphip_mf_host_top2_err", "sqphip_mf_solve_test", "sqphip_acopf_attach", "sqphip_acopf_attach_acr", "sqphip_acopf_attach_acwr", "sqphip_acopf_set_shunts", "sqphip_acopf_set_dclines", "sqphip_acopf_set_instance", "sqphip_acopf_eval", "sqphip_sqp_reset",
+    "sqphip_kkt_order", "sqphip_kkt_symbolic", "sqphip_mf_host_solve", "sqphip_mf_host_top2_err", "sqphip_mf_host_spine_err", "sqphip_mf_solve_test", "sqphip_acopf_attach", "sqphip_acopf_attach_acr", "sqphip_acopf_attach_acwr", "sqphip_acopf_set_shunts", "sqphip_acopf_set_dclines", "sqphip_acopf_set_instance", "sqphip_acopf_eval", "sqphip_sqp_reset",
     "sqphip_sqp_run", "sqphip_sqp_get", "sqphip_sqp_status", "sqphip_sqp_trace",
     "sqphip_comm_available", "sqphip_comm_unique_id", "sqphip_comm_init", "sqphip_gather_status", "sqphip_comm_destroy",
     "sqphip_get_counters", "sqphip_get_mode_counters", "sqphip_sqp_work", "sqphip_sqp_stream_begin", "sqphip_sqp_stream_set", "sqphip_sqp_stream_run", "sqphip_sqp_stream_get", "sqphip_sqp_stream_assign", "sqphip_sqp_stream_append", "sqphip_sqp_stream_release", "sqphip_sqp_stream_run_some", "sqphip_sqp_last_request", "sqphip_sqp_qp_log", "sqphip_reset_counters", "sqphip_set_timing", "sqphip_ldlt_factor_host",

@@ -98,6 +98,7 @@ DV group_view(const DV &d, int i0, int Bg, int g)
     v.rtype += o * m; v.rbase += o * m; v.hard += o * m;
     v.jcoo += o * d.nnzj_coo; v.hcoo += o * d.nnzh_coo; v.jv += o * d.nnzjc; v.hv += o * d.nnzhc;
     v.rhs += o * d.Npad; v.sol += o * d.Npad; v.wN += o * d.Npad;
+    if (v.flat) { v.fH += o * n; v.fJt += o * n; v.fJ += o * m; v.fX += o * m; }
     v.xv += o * d.Fpad; v.vv += o * d.Fpad; v.dinv += o * d.Fpad;
     v.ist += o; v.sst += o; v.phase += o;
     if (v.stream.slot_scen) v.stream.slot_scen += o;
@@ -172,7 +173,7 @@ extern "C" void sqphip_default_options(sqphip_options *o)
     o->init_mu = 1.0; o->max_mu = 1e10; o->tr_size = 10.0;
     o->rho = 0.8; o->eta = 0.4; o->tau = 0.9; o->min_alpha = 1e-6;
     o->max_iter = 3000; o->use_soc = 0; o->literal_quirks = 1;
-    o->ipm_tol = 1e-9; o->ipm_max_iter = 200; o->ipm_phase1 = 0; o->device = 0; o->ipm_corrector = 1; o->kkt_condense = 1; o->kkt_tile_order = 1;
+    o->ipm_tol = 1e-9; o->ipm_max_iter = 200; o->ipm_phase1 = 0; o->device = 0; o->ipm_corrector = 0; o->kkt_condense = 1; o->kkt_tile_order = 1;
     o->kkt_mode = 0; o->ipm_warm_start = 0;
 }
 
@@ -288,6 +289,11 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
                     M.top_next = (int)P.top_ext.size(); M.top_utotal = P.top_utotal; M.top_xtotal = P.top_xtotal;
                     M.top_buf0 = P.top_buf0; M.top_buf1 = P.top_buf1;
                 }
+                M.sp_n = P.spine_lds_bytes > 0 && P.spine_lds_bytes <= lds_max ? (int)P.sp_fr.size() : 0;
+                if (M.sp_n > 0) {
+                    M.sp_fr = C.upload(P.sp_fr); M.sp_ent = C.upload(P.sp_ent.empty() ? std::vector<MfGather>(1) : P.sp_ent);
+                    M.sp_src = C.upload(nz(P.sp_src)); M.sp_rel = C.upload(nz(P.sp_rel)); M.sp_T = P.spine_T; M.sp_stage = P.spine_stage;
+                }
                 M.nnzK = (int)P.nnzK;
                 M.vals = C.dalloc<double>((size_t)B * P.nnzK);
                 M.fronts = C.dalloc<double>((size_t)B * P.stride);
@@ -361,6 +367,17 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
         d.ipm_tol = opt->ipm_tol; d.ipm_max_iter = opt->ipm_max_iter; d.ipm_phase1 = opt->ipm_phase1; d.ipm_corrector = opt->ipm_corrector; d.ipm_warm = opt->ipm_warm_start;
         d.refine_tol = getenv("SQPHIP_REFINE_TOL") ? atof(getenv("SQPHIP_REFINE_TOL")) : 1e-11;
         d.vstage = (d.n + d.N <= 7000 && !getenv("SQPHIP_NO_VSTAGE")) ? d.n + d.N : 0;      // up to 56 KB of LDS per workgroup
+        // large instances (the vectors do not fit the LDS of one workgroup): the sparse products of the vector stages by flat
+        // kernels over the whole batch (ipm.hip, k_sp_products); SQPHIP_VEC_FLAT=1 / 0 forces / forbids it (tests, A / B runs)
+        d.flat = getenv("SQPHIP_VEC_FLAT") ? (atoi(getenv("SQPHIP_VEC_FLAT")) != 0) : (d.vstage == 0 && d.n + d.N > 7000);
+        // (measured, round 4: the stage kernel assembling the values of its instance -- eight destinations per thread, each a
+        //  chain item list -> items -> operands -- takes longer than the flat k_mf_values launch it saves: 7 528 against 7 706
+        //  QP/s at 512 x IEEE-118, 1 880 against 2 002 at 64, +2 % on IEEE-14; on request only)
+        d.vals_inline = d.sparse && !d.flat && getenv("SQPHIP_MF_VALS_INLINE") && atoi(getenv("SQPHIP_MF_VALS_INLINE")) == 1;
+        if (d.flat) {
+            d.vstage = 0;
+            d.fH = C.dalloc<double>(Bn); d.fJt = C.dalloc<double>(Bn); d.fJ = C.dalloc<double>(Bm); d.fX = C.dalloc<double>(Bm);
+        }
         d.tol_direction = opt->tol_direction; d.tol_residual = opt->tol_residual;
         d.tol_infeas = opt->tol_infeas; d.init_mu = opt->init_mu; d.tr_size = opt->tr_size;
         d.max_iter = opt->max_iter; d.use_soc = opt->use_soc; d.literal_quirks = opt->literal_quirks;
@@ -1023,7 +1040,7 @@ extern "C" int sqphip_get_counters(sqphip_ctx *h, sqphip_counters *c)
             long cb = 0;
             for (int q = 0; q < Y.ns; ++q) cb += (long)(Y.sn_nr[q] + 1) * Y.sn_nr[q] - (long)Y.sn_nr[q] * (Y.sn_nr[q] - 1) / 2;
             c->cb_doubles = cb;
-            c->factor_launches = (int64_t)C.mfp().fac.size();
+            c->factor_launches = (int64_t)(C.d.mf.sp_n > 0 ? C.mfp().fac_below + 1 : (int)C.mfp().fac.size());   // (+ k_mf_values)
             c->solve_launches = (int64_t)(C.mfp().fwd.size() + C.mfp().bwd.size() + (C.mfp().top.count > 0 ? 1 : 0));
             c->ldlt_flops = (double)nf * Y.flops;
         }

@@ -31,6 +31,7 @@ struct IpmState {
     // outcome
     int prev_mode;                 // 1 + mode of this instance's last solved sub-problem (options.ipm_warm_start), 0 none
     int status, ipm_iters, n_factor, n_solve;   // n_solve: forward + backward solves with the factors (incl. refinement)
+    int reload;                    // flat products (DV::flat): the working vector of the solves is to be loaded from 1 wN (refinement), 2 rhs (corrector)
     int sel;                       // which of the two factorisations of the last sweep the solves use (mfront.hip, candidates)
     int acc_rule;                  // how the last run of this sub-problem ended: 0 scaled error <= ipm_tol, 1 / 2 / 3 the acceptable-termination rules (b_ipm_prepare)
     double elastic;
@@ -77,6 +78,11 @@ struct MfDev {
     const MfTopFront *top_fr;
     const int *top_gptr, *top_gsrc, *top_rows, *top_ext;
     int top_n, top_next, top_utotal, top_xtotal, top_buf0, top_buf1;
+    // the spine of the factorisation for k_mf_spine (sparse.hpp MfSpineFront; sp_n == 0: level launches throughout)
+    const MfSpineFront *sp_fr;
+    const MfGather *sp_ent;
+    const int *sp_src, *sp_rel;
+    int sp_n, sp_T, sp_stage;             // fronts, tiles of the tallest, doubles of the staging area
     int nnzK;                             // destinations (structural entries of the lower triangle)
     double *vals;                         // [B][nnzK] assembled values of the destinations (k_mf_values)
 };
@@ -140,6 +146,9 @@ struct DV {
     int ipm_max_iter, ipm_phase1, ipm_corrector, ipm_warm;
     double refine_tol;                    // refinement step when the relative residual is above this (condensed form)
     int vstage;                           // doubles of dynamic LDS of the vector stages (n + N; 0: the vectors do not fit, ipm.hip)
+    int vals_inline;                      // 1: the stage kernel behind the Newton right-hand side assembles the matrix values too (mf_values_block)
+    int flat;                             // 1: the sparse products of the vector stages by flat kernels over the batch (large instances, ipm.hip)
+    double *fH, *fJt, *fJ, *fX;           // ... their results: H v and J' w [B][n], J v and J x of the eliminated rows [B][m]
     // ---- SQP level
     double *x, *lambda, *mxL, *mxU, *df, *E, *pstep, *psoc, *plam, *pmxL, *pmxU, *Esoc, *tmpx, *tmpE,
         *hlam;
@@ -180,6 +189,7 @@ struct Ctx {
     // of the current sqphip_sqp_run / _stream_run call, so the first sweep of every run is a transition sweep -- slots
     // armed by the scenario queue draw their scenario there, whatever the lifetime counter n_sweeps says.
     long run_sweep = 0;
+    bool want_resolve = true;       // monotone rule: this sweep carries the second solve slot (an instance asked for a refinement solve)
     int trans_period = 0;           // 0: by group size (3 from 64 instances, 2 from 32, else 1); SQPHIP_TRANS_PERIOD, read at creation
     Timers tm;
     std::vector<void *> allocs;
@@ -230,7 +240,7 @@ void launch_qp_gather(Ctx &C);       // COO -> CSC for instances with start set 
 void comm_release(Ctx &C);
 // mfront.hip
 void mf_device_setup(Ctx &C);
-void mf_factor(Ctx &C, int want, bool with_rhs);
+void mf_factor(Ctx &C, int want, bool with_rhs, bool values_done = false);
 void mf_solve(Ctx &C, int want, bool skip_fwd);
 // acopf.hip
 void launch_acopf_eval_point(Ctx &C, int inst, const double *x_dev, double sigma, const double *lam_dev,

@@ -17,6 +17,7 @@
 // shuffles + a 4-entry LDS exchange do the reductions.
 #include "ctx.hpp"
 #include "dev_util.hpp"
+#include "mf_dev.hpp"
 #include <cmath>
 
 #ifndef SQPHIP_VEC_FUSE
@@ -315,6 +316,9 @@ static __device__ void b_ipm_prepare(const DV &d)
     // (H p and J p are formed row by row inside the loops that consume them: SQPHIP_VEC_FUSE=0 restores the two passes
     //  through rd / rp with a barrier behind them -- same sums, same bits)
     const double *hvp = d.hv + (long)inst * d.nnzhc;
+    // (d.flat, large instances: H p, J' y and J p were formed by k_sp_products over the whole chip -- the same row / column
+    //  sums by the same routines, one thread per row of the batch instead of one workgroup per instance)
+    const double *fH = d.flat ? d.fH + on : nullptr, *fJt = d.flat ? d.fJt + on : nullptr, *fJ = d.flat ? d.fJ + om : nullptr;
 #if !SQPHIP_VEC_FUSE
     hess_mul(d, inst, hsc, pv, rd);
     VTR(18)
@@ -331,12 +335,12 @@ static __device__ void b_ipm_prepare(const DV &d)
     //  load is a second memory round trip, and these loops are round trips and little else)
     for (int j = threadIdx.x; j < d.n; j += TPB) {
 #if SQPHIP_VEC_FUSE
-        const double rdj = hess_row(d, hvp, hd, hsc, pv, j);
+        const double rdj = fH ? fH[j] : hess_row(d, hvp, hd, hsc, pv, j);
 #else
         const double rdj = rd[j];
 #endif
         const double cj = c[j], pj = p[j], lbj = lb[j], ubj = ub[j], zlj = zl[j], zuj = zu[j];
-        double r = rdj + cj - (d.vstage ? jact_col_masked(d, jv, yv, j) : jact_col(d, jv, rt, yv, j));
+        double r = rdj + cj - (fJt ? fJt[j] : (d.vstage ? jact_col_masked(d, jv, yv, j) : jact_col(d, jv, rt, yv, j)));
         const double g_l = pj - lbj, g_u = ubj - pj;
         double sg = 0.0;
         if (fin(lbj)) { r -= zlj; const double cc = zlj * g_l; csum += cc; cmax = fmax(cmax, cc); nc += 1; dl1 += zlj; sg += zlj / g_l; ce0 = fmax(ce0, compl_err(zlj, g_l, mu_in)); }
@@ -349,7 +353,7 @@ static __device__ void b_ipm_prepare(const DV &d)
         const double tpi = tp[i], tmi = tm[i], si = s[i], zp = zpv[i], zm = zmv[i], yi = y[i], loi = lo[i], hii = hi[i],
                      vli = vl[i], vui = vu[i];
 #if SQPHIP_VEC_FUSE
-        const double rpi = rti != ROW_FREE ? jac_row(d, jv, pv, i) : 0.0;
+        const double rpi = fJ ? fJ[i] : (rti != ROW_FREE ? jac_row(d, jv, pv, i) : 0.0);
 #else
         const double rpi = rp[i];
 #endif
@@ -517,11 +521,9 @@ __global__ __launch_bounds__(128) void k_kkt_assemble(DV d)
 
 // working vector of the triangular solves from a full-length right-hand side src = [g; b] (published to the
 // workgroup by the caller).  Full form: a copy.  Condensed form: g + J_I' (D_I + reg)^-1 b_I on top, b_E below.
-__device__ void load_solve_vector(const DV &d, int inst, const double *src, double *xv)
+__device__ __forceinline__ double solve_vector_at(const DV &d, const double *jv, const double *Dd, const int *rt, const double *src, int p)
 {
-    const double *jv = d.jv + (long)inst * d.nnzjc, *Dd = d.Dd + (long)inst * d.m;
-    const int *rt = d.rtype + (long)inst * d.m;
-    for (int p = threadIdx.x; p < d.Fpad; p += TPB) {
+    {
         const int u = d.uinv[p];
         double v = 0.0;                                           // identity padding
         if (u >= d.n) v = src[d.n + (d.condense ? d.krow[u - d.n] : u - d.n)];
@@ -539,8 +541,14 @@ __device__ void load_solve_vector(const DV &d, int inst, const double *src, doub
                 }
             }
         }
-        xv[p] = v;
+        return v;
     }
+}
+__device__ void load_solve_vector(const DV &d, int inst, const double *src, double *xv)
+{
+    const double *jv = d.jv + (long)inst * d.nnzjc, *Dd = d.Dd + (long)inst * d.m;
+    const int *rt = d.rtype + (long)inst * d.m;
+    for (int p = threadIdx.x; p < d.Fpad; p += TPB) xv[p] = solve_vector_at(d, jv, Dd, rt, src, p);
 }
 
 // Newton right-hand side for centring target tgt (minus the second-order terms when soc), its working copy xv
@@ -578,7 +586,7 @@ __device__ double build_rhs(const DV &d, int inst, double tgt, bool soc)
     }
     rn = block_reduce<OpMax>(rn);        // (its barriers also publish rhs to the whole workgroup)
     for (int i = threadIdx.x; i < d.Npad; i += TPB) sol[i] = 0.0;
-    load_solve_vector(d, inst, rhs, d.xv + (long)inst * d.Fpad);
+    if (!d.flat) load_solve_vector(d, inst, rhs, d.xv + (long)inst * d.Fpad);       // (flat: k_sp_load_xv behind this kernel)
     return rn;
 }
 
@@ -593,6 +601,9 @@ static __device__ void b_build_rhs(const DV &d)
     IpmState &st = d.ist[inst];
     const double rn = build_rhs(d, inst, st.mpc ? 0.0 : st.mu, false);
     if (threadIdx.x == 0) st.rn = fmax(1.0, rn);
+    // ... and the values of the structural entries of the Newton matrix this instance is about to factorise (both shifts of
+    // a speculating instance): they depend on what b_ipm_prepare left (D, Sigma) and on delta_w, all known here
+    if (d.vals_inline) mf_values_block(d, inst, TPB);
 }
 
 // after the factorisation: inertia from pivot signs -> PH_SOLVE, or a larger delta_w (stays PH_FACTOR).
@@ -638,7 +649,9 @@ __global__ __launch_bounds__(TPB, SQPHIP_VEC_WAVES_PER_EU) void k_inertia(DV d)
 // against the full sparse operator, decide.  Condensed form: one refinement step when the residual is above 1e-11
 // relative (the elimination puts 1/D-sized terms into the matrix; see oracle/qp_ipm.c, kkt_solve) -- the residual
 // becomes the next right-hand side, the sweep runs one more forward/backward solve and calls this kernel with last = 1.
-static __device__ void b_refine(const DV &d, int last, int want)
+// part: 3 = the whole routine (one workgroup per instance does everything), 1 = accumulation only, 2 = residual and decision
+// only (d.flat: the sparse products of each part are formed by flat kernels in front of it, ipm_sweep)
+static __device__ void b_refine(const DV &d, int last, int want, int part = 3)
 {
     const int inst = blockIdx.x;
     if (d.phase[inst] != want) return;
@@ -646,9 +659,12 @@ static __device__ void b_refine(const DV &d, int last, int want)
     INST_PTRS
     double *xv = d.xv + (long)inst * d.Fpad;
     const int refine_it = st.refine_it;      // read before the first barrier, written by thread 0 at the end
+    const double *fH = d.flat ? d.fH + on : nullptr, *fJt = d.flat ? d.fJt + on : nullptr, *fJ = d.flat ? d.fJ + om : nullptr,
+                 *fX = d.flat ? d.fX + om : nullptr;
     VTR(want == PH_RESOLVE ? 0 : 32)
     // LDS copies (d.vstage): xs = the solve's result in variable order, ss = the accumulated solution (both gathered from below)
     double *xs = d.vstage ? ipm_lds : nullptr, *ss = d.vstage ? ipm_lds + d.n : nullptr;
+    if (part & 1) {
     if (!d.condense) {
         for (int i = threadIdx.x; i < d.N; i += TPB) {
             const double v = sol[i] + xv[d.upos[i]];
@@ -672,7 +688,8 @@ static __device__ void b_refine(const DV &d, int last, int want)
             else if (rti == ROW_FREE) v = -ci;
             else {      // eliminated row: q_i = (J_i dp - b_i) / (D_i + reg)
                 double acc = 0.0;
-                if (xs) {
+                if (fX) acc = fX[i];
+                else if (xs) {
 #pragma unroll 4
                     for (int t = t0; t < t1; ++t) acc += jv[d.jrslot[t]] * xs[d.jrcol[t]];
                 } else for (int t = t0; t < t1; ++t) acc += jv[d.jrslot[t]] * xv[d.upos[d.jrcol[t]]];
@@ -683,6 +700,8 @@ static __device__ void b_refine(const DV &d, int last, int want)
             if (ss) ss[d.n + i] = rt[i] != ROW_FREE ? w : 0.0;                       // (masked: jact_col_masked)
         }
     }
+    }
+    if (part == 1) return;
     __syncthreads();
     VTR(want == PH_RESOLVE ? 1 : 33)
     const double hsc = st.hsc;
@@ -699,13 +718,13 @@ static __device__ void b_refine(const DV &d, int last, int want)
     const double dwv = st.dw;
     for (int j = threadIdx.x; j < d.n; j += TPB) {
 #if SQPHIP_VEC_FUSE
-        const double wnj = hess_row(d, hvp, hd, hsc, sv, j);
+        const double wnj = fH ? fH[j] : hess_row(d, hvp, hd, hsc, sv, j);
 #else
         const double wnj = wn[j];
 #endif
         const double sgj = sigp[j], rhj = rhs[j], svj = sv[j];
         const double kx = wnj + (sgj + dwv + IPM_REG_P) * svj +
-                          (ss ? jact_col_masked(d, jv, sv + d.n, j) : jact_col(d, jv, rt, sv + d.n, j));
+                          (fJt ? fJt[j] : (ss ? jact_col_masked(d, jv, sv + d.n, j) : jact_col(d, jv, rt, sv + d.n, j)));
         const double r = rhj - kx;
         wN[j] = r; en = fmax(en, fabs(r));
     }
@@ -713,7 +732,7 @@ static __device__ void b_refine(const DV &d, int last, int want)
         const int rti = rt[i];
         const double Ddi = Dd[i], rhi = rhs[d.n + i], soli = sol[d.n + i];
 #if SQPHIP_VEC_FUSE
-        const double wi = rti != ROW_FREE ? jac_row(d, jv, sv, i) : 0.0;
+        const double wi = fJ ? fJ[i] : (rti != ROW_FREE ? jac_row(d, jv, sv, i) : 0.0);
 #else
         const double wi = wN[d.n + i];
 #endif
@@ -727,14 +746,14 @@ static __device__ void b_refine(const DV &d, int last, int want)
     // second-order terms, the direction that is actually taken -- the corrector -- is refined (oracle: ipm_direction)
     const bool predictor = want == PH_SOLVE && st.mpc;
     const bool stop = last || predictor || refine_it >= 1 || !(en > d.refine_tol * st.rn);
-    if (!stop) load_solve_vector(d, inst, wN, xv);
+    if (!stop && !d.flat) load_solve_vector(d, inst, wN, xv);
     VTR(want == PH_RESOLVE ? 4 : 36)
     if (threadIdx.x == 0) {
         st.n_solve++;
         st.relres = en / st.rn;
         // predictor-corrector mode: the first solve was the predictor, k_mpc builds the corrector's system
         if (stop) d.phase[inst] = (want == PH_SOLVE && st.mpc) ? PH_MPC : PH_STEP;
-        else { st.refine_it++; d.phase[inst] = PH_RESOLVE; }  // the residual is the next right-hand side (second solve slot)
+        else { st.refine_it++; d.phase[inst] = PH_RESOLVE; st.reload = 1; }  // the residual is the next right-hand side (second solve slot; flat: k_sp_load_xv loads it)
     }
 }
 
@@ -847,7 +866,7 @@ static __device__ void b_mpc(const DV &d)
         st.mu = mu; st.tau = fmax(0.99, 1.0 - mu); st.use_soc = corr ? 1 : 0;
         if (!corr) st.mpc = 0;
         st.rn = fmax(1.0, rn); st.refine_it = 0;
-        d.phase[inst] = PH_RESOLVE;
+        d.phase[inst] = PH_RESOLVE; st.reload = 2;      // (flat: k_sp_load_xv loads the working vector from rhs)
     }
 }
 
@@ -1038,7 +1057,97 @@ __global__ __launch_bounds__(TPB, SQPHIP_VEC_WAVES_PER_EU) void k_ipm_tail(DV d,
     b_ipm_prepare(d);
 }
 
+// Monotone barrier rule (options.ipm_corrector = 0, the default since round 4: what Ipopt, the reference's sub-solver, does
+// by default -- mu_strategy = monotone): one solve per factorisation, so everything behind that solve -- residual check,
+// step, convergence test of the new iterate, the next Newton right-hand side -- is ONE kernel, and the second solve slot
+// of a sweep exists only for the rare refinement step (0.4 % of the iterations on 512 x IEEE-118): `want` = PH_SOLVE behind
+// the solve of the sweep, PH_RESOLVE behind a refinement solve.  25 launches per sweep instead of 36.
+__global__ __launch_bounds__(TPB, SQPHIP_VEC_WAVES_PER_EU) void k_ipm_post(DV d, int last, int want)
+{
+    b_refine(d, last, want);
+    __syncthreads();
+    b_ipm_step(d);
+    __syncthreads();
+    b_ipm_prepare(d);
+    __syncthreads();
+    b_build_rhs(d);
+}
+
 // ---------------------------------------------------------------------------------------------
+// Large instances (DV::flat; round 4).  One workgroup per instance is the wrong shape for the vector stages of a few large
+// instances (9241-bus shape: 7.8 - 10.2 ms per launch, 38 % of the GPU time at 256 instances, two thirds of it in the sparse
+// products: the gathers of one instance go through ONE compute unit's line rate).  The sparse products of a stage -- H v,
+// J' w, J v, the expansion of the eliminated rows, the working vector of the solves -- are formed by flat kernels over the
+// whole batch (one thread per row or column: thousands of workgroups instead of one per instance), written to buffers, and
+// the stage kernels, split at the points where a product depends on what the stage has just computed, read them.  The
+// same sums by the same routines in the same order: bit for bit the fused stages (tests force this path on IEEE-118).
+enum { SP_PREP = 0, SP_REFINE = 1, SP_XS = 2 };
+__global__ __launch_bounds__(256) void k_sp_products(DV d, int what, int want)
+{
+    const int inst = blockIdx.y;
+    if (d.phase[inst] != want) return;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= d.n + d.m) return;
+    const long on = (long)inst * d.n, om = (long)inst * d.m;
+    const double *jv = d.jv + (long)inst * d.nnzjc;
+    const int *rt = d.rtype + om;
+    if (what == SP_XS) {           // J_i x over the solve's result in variable order, for the eliminated rows (b_refine)
+        if (t < d.n || !d.condense) return;
+        const int i = t - d.n;
+        if (d.kpos[i] >= 0 || rt[i] == ROW_FREE) return;
+        const double *xv = d.xv + (long)inst * d.Fpad;
+        double acc = 0.0;
+        for (int k = d.jrowptr[i]; k < d.jrowptr[i + 1]; ++k) acc += jv[d.jrslot[k]] * xv[d.upos[d.jrcol[k]]];
+        d.fX[om + i] = acc;
+        return;
+    }
+    // SP_PREP: the iterate (p, y) in front of b_ipm_prepare; SP_REFINE: the accumulated solution in front of the residual
+    const double *v = what == SP_PREP ? d.p + on : d.sol + (long)inst * d.Npad;
+    const double *w = what == SP_PREP ? d.y + om : v + d.n;
+    if (t < d.n) {
+        d.fH[on + t] = hess_row(d, d.hv + (long)inst * d.nnzhc, d.hd + on, d.ist[inst].hsc, v, t);
+        d.fJt[on + t] = jact_col(d, jv, rt, w, t);
+    } else {
+        const int i = t - d.n;
+        d.fJ[om + i] = rt[i] != ROW_FREE ? jac_row(d, jv, v, i) : 0.0;
+    }
+}
+// working vector of the solves, one thread per position.  mode 0: the Newton right-hand side of every instance about to be
+// factorised (behind b_build_rhs); mode 1: instances that asked for it (IpmState.reload: 1 the refinement residual in wN,
+// 2 the corrector's right-hand side in rhs)
+__global__ __launch_bounds__(256) void k_sp_load_xv(DV d, int mode)
+{
+    const int inst = blockIdx.y;
+    const int rl = d.ist[inst].reload;
+    if (mode == 0 ? d.phase[inst] != PH_FACTOR : rl == 0) return;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= d.Fpad) return;
+    const double *src = (mode == 0 || rl == 2) ? d.rhs + (long)inst * d.Npad : d.wN + (long)inst * d.Npad;
+    d.xv[(long)inst * d.Fpad + p] = solve_vector_at(d, d.jv + (long)inst * d.nnzjc, d.Dd + (long)inst * d.m, d.rtype + (long)inst * d.m, src, p);
+}
+__global__ void k_sp_clear(DV d)
+{
+    for (int i = threadIdx.x; i < d.B; i += blockDim.x) d.ist[i].reload = 0;
+}
+// the stage kernels of a sweep, split where a product has to be formed in between
+__global__ __launch_bounds__(TPB, SQPHIP_VEC_WAVES_PER_EU) void k_ipm_head_a(DV d) { b_qp_gather(d); __syncthreads(); b_ipm_start(d); }
+__global__ __launch_bounds__(TPB, SQPHIP_VEC_WAVES_PER_EU) void k_ipm_head_b(DV d) { b_ipm_prepare(d); __syncthreads(); b_build_rhs(d); }
+__global__ __launch_bounds__(TPB, SQPHIP_VEC_WAVES_PER_EU) void k_ipm_refine_a(DV d, int last, int want) { b_refine(d, last, want, 1); }
+__global__ __launch_bounds__(TPB, SQPHIP_VEC_WAVES_PER_EU) void k_ipm_mid_b(DV d, int last)
+{
+    b_refine(d, last, PH_SOLVE, 2);
+    if (!d.ipm_corrector) return;
+    __syncthreads();
+    b_mpc(d);
+}
+__global__ __launch_bounds__(TPB, SQPHIP_VEC_WAVES_PER_EU) void k_ipm_tail_b(DV d, int last, int want)
+{
+    b_refine(d, last, want, 2);
+    __syncthreads();
+    b_ipm_step(d);
+}
+__global__ __launch_bounds__(TPB, SQPHIP_VEC_WAVES_PER_EU) void k_ipm_prepare(DV d) { b_ipm_prepare(d); }
+
 void launch_qp_gather(Ctx &C)
 {
     hipLaunchKernelGGL(k_qp_gather, dim3(C.d.B), dim3(TPB), 0, C.stream, C.d);
@@ -1082,16 +1191,28 @@ void ipm_sweep(Ctx &C, bool sqp_level)
     const int period = C.trans_period > 0 ? C.trans_period : (d.B >= 64 ? 3 : (d.B >= 32 ? 2 : 1));
     const bool trans = !sqp_level || period <= 1 || (C.run_sweep % period) == 0;
     C.run_sweep++;
+    const dim3 gP((d.n + d.m + 255) / 256, d.B), gX((d.Fpad + 255) / 256, d.B), b256(256);       // flat products (d.flat)
+    // monotone rule: the Newton right-hand side of an iteration is built by the kernel that ends the iteration before
+    // (k_ipm_post) or starts the sub-problem (k_ipm_head); the sparse factorisation leaves the working vector of a failed
+    // inertia trial as it was, so a sweep without transitions starts with the matrix values (the dense path consumes the
+    // vector in place and keeps k_ipm_rhs)
+    const bool mono = d.ipm_corrector == 0;
     if (trans) {
         hipLaunchKernelGGL(k_qp_finish, gB, bT, 0, s, d);
         if (sqp_level) sqp_stage_kernels(C);
-        hipLaunchKernelGGL(k_ipm_head, gB, bT, vlds, s, d);
-    } else hipLaunchKernelGGL(k_ipm_rhs, gB, bT, vlds, s, d);
+        if (!d.flat) hipLaunchKernelGGL(k_ipm_head, gB, bT, vlds, s, d);
+        else {
+            hipLaunchKernelGGL(k_ipm_head_a, gB, bT, vlds, s, d);
+            hipLaunchKernelGGL(k_sp_products, gP, b256, 0, s, d, (int)SP_PREP, (int)PH_PREP);
+            hipLaunchKernelGGL(k_ipm_head_b, gB, bT, vlds, s, d);
+        }
+    } else if (!(mono && d.sparse)) hipLaunchKernelGGL(k_ipm_rhs, gB, bT, vlds, s, d);
+    if (d.flat && (trans || !mono)) hipLaunchKernelGGL(k_sp_load_xv, gX, b256, 0, s, d, 0);
     if (!d.sparse) hipLaunchKernelGGL(k_kkt_assemble, dim3(d.Fpad, d.B), dim3(128), 0, s, d);
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (C.tm.enabled) { ev = C.tm.get(); hipEventRecord(ev.first, s); }
     // assembly + factorisation, with the forward elimination of xv fused in
-    if (d.sparse) { mf_factor(C, PH_FACTOR, true); C.tm.n_factor++; }
+    if (d.sparse) { mf_factor(C, PH_FACTOR, true, d.vals_inline != 0); C.tm.n_factor++; }
     else ldlt_factor(C.plan, d.K, d.dinv, d.phase, PH_FACTOR, &C.tm, d.xv, d.vv);
     if (C.tm.enabled) { hipEventRecord(ev.second, s); C.tm.pending_factor.push_back(ev); }
     auto lin_solve = [&](int want, bool skip_fwd) {
@@ -1116,17 +1237,56 @@ void ipm_sweep(Ctx &C, bool sqp_level)
     const int last = d.condense != 0 ? 0 : 1;          // full form: no refinement
     // (the solve timer brackets the two solve slots separately: the vector stage between them is not a solve kernel)
     if (C.tm.enabled) { hipEventRecord(ev.second, s); C.tm.pending_solve.push_back(ev); }
-    hipLaunchKernelGGL(k_ipm_mid, gB, bT, vlds, s, d, last);
+    auto refine_front = [&](int want) {      // flat: J x of the eliminated rows, the accumulation, the products of the accumulated solution
+        hipLaunchKernelGGL(k_sp_products, gP, b256, 0, s, d, (int)SP_XS, want);
+        hipLaunchKernelGGL(k_ipm_refine_a, gB, bT, vlds, s, d, last, want);
+        hipLaunchKernelGGL(k_sp_products, gP, b256, 0, s, d, (int)SP_REFINE, want);
+    };
+    auto reload = [&]() {
+        hipLaunchKernelGGL(k_sp_load_xv, gX, b256, 0, s, d, 1);
+        hipLaunchKernelGGL(k_sp_clear, dim3(1), dim3(256), 0, s, d);
+    };
+    if (mono) {
+        // behind the solve: residual check, step, convergence test, next right-hand side; then -- only when the host has
+        // seen an instance ask for it (C.want_resolve: the counter of the sweep before last) -- the refinement solve
+        auto post = [&](int want) {
+            if (!d.flat) { hipLaunchKernelGGL(k_ipm_post, gB, bT, vlds, s, d, last, want); return; }
+            refine_front(want);
+            hipLaunchKernelGGL(k_ipm_tail_b, gB, bT, vlds, s, d, last, want);
+            reload();
+            hipLaunchKernelGGL(k_sp_products, gP, b256, 0, s, d, (int)SP_PREP, (int)PH_PREP);
+            hipLaunchKernelGGL(k_ipm_head_b, gB, bT, vlds, s, d);
+            hipLaunchKernelGGL(k_sp_load_xv, gX, b256, 0, s, d, 0);
+        };
+        post(PH_SOLVE);
+        if (C.want_resolve) {
+            if (C.tm.enabled) { ev = C.tm.get(); hipEventRecord(ev.first, s); }
+            lin_solve(PH_RESOLVE, false);
+            if (C.tm.enabled) { hipEventRecord(ev.second, s); C.tm.pending_solve.push_back(ev); }
+            post(PH_RESOLVE);
+        }
+        return;
+    }
+    if (!d.flat) hipLaunchKernelGGL(k_ipm_mid, gB, bT, vlds, s, d, last);
+    else { refine_front(PH_SOLVE); hipLaunchKernelGGL(k_ipm_mid_b, gB, bT, vlds, s, d, last); reload(); }
     if (C.tm.enabled) { ev = C.tm.get(); hipEventRecord(ev.first, s); }
     lin_solve(PH_RESOLVE, false);
     if (C.tm.enabled) { hipEventRecord(ev.second, s); C.tm.pending_solve.push_back(ev); }
-    hipLaunchKernelGGL(k_ipm_tail, gB, bT, vlds, s, d, last);
+    if (!d.flat) hipLaunchKernelGGL(k_ipm_tail, gB, bT, vlds, s, d, last);
+    else {
+        refine_front(PH_RESOLVE);
+        hipLaunchKernelGGL(k_ipm_tail_b, gB, bT, vlds, s, d, last, (int)PH_RESOLVE);
+        reload();
+        hipLaunchKernelGGL(k_sp_products, gP, b256, 0, s, d, (int)SP_PREP, (int)PH_PREP);
+        hipLaunchKernelGGL(k_ipm_prepare, gB, bT, vlds, s, d);
+    }
 }
 
 // Runs every instance whose IpmState.start flag is set until each has a final MOI status
 // (drop-in sqphip_qp_solve path: no SQP-level kernels).
 void ipm_run_all(Ctx &C)
 {
+    C.want_resolve = true;               // (the drop-in seat: every sweep carries the refinement slot)
     for (long sweep = 0; sweep < 100000000L; ++sweep) {
         ipm_sweep(C, false);
         // counters[0] = instances iterating, [1] = start requests (phase 1 / escalation restarts)

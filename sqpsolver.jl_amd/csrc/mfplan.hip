@@ -89,6 +89,36 @@ MfPlan mf_build_plan(int n, int m, const std::vector<int> &kpos, int mk, const s
         for (int e = P.asm_ptr[s]; e < P.asm_ptr[s + 1]; ++e) P.dest_rc[e] = (P.dest_loc[e] % ld) | ((P.dest_loc[e] / ld) << 16);
     }
     if (P.stride >= (1L << 31)) { fprintf(stderr, "sqphip: mf_build_plan: front arena too large for 32-bit offsets\n"); abort(); }
+    // The narrow top of the assembly tree (solves: k_mf_solve_top2; factorisation: k_mf_spine): from the first level on above
+    // which no level holds more than two fronts (or up to four wave-sized ones) -- decided here, before the gather lists,
+    // because the lists of a top front take its children in the order [children below the top, ascending | children inside
+    // the top, ascending]: the last child inside the top is then the last term of every sum it contributes to, which lets
+    // the spine kernel add it straight from its accumulator registers behind the terms that come from the arena, in the
+    // order every other kernel (level launches, host reference) uses too.
+    const bool big_solve = !(getenv("SQPHIP_MF_BIG_SOLVE") && atoi(getenv("SQPHIP_MF_BIG_SOLVE")) == 0);   // experiment switch
+    P.top_level = S.nlevels;
+    if (big_solve && !(getenv("SQPHIP_MF_TOP") && atoi(getenv("SQPHIP_MF_TOP")) == 0)) {
+        // ... a level of up to four fronts joins the top as well when all of them are wave-sized (<= 64 rows): the four
+        // waves of the instance's workgroup take one each, exactly what a level launch would do, one launch less per pass
+        auto joins = [&](int lev) {
+            const int cnt = S.level_ptr[lev + 1] - S.level_ptr[lev];
+            if (cnt <= 2) return true;
+            if (cnt > 4 || getenv("SQPHIP_MF_TOP_NARROW")) return false;
+            for (int q = S.level_ptr[lev]; q < S.level_ptr[lev + 1]; ++q)
+                if (S.sn_nc[S.level_sn[q]] + S.sn_nr[S.level_sn[q]] > 64) return false;
+            return true;
+        };
+        int l = S.nlevels;
+        while (l > 0 && joins(l - 1)) --l;
+        if (S.nlevels - l >= 2) P.top_level = l;
+    }
+    P.spine_level = P.top_level; P.narrow_level = P.top_level;
+    // children of s in summation order
+    auto children_of = [&](int s) {
+        std::vector<int> ch(S.child.begin() + S.child_ptr[s], S.child.begin() + S.child_ptr[s + 1]);
+        std::stable_sort(ch.begin(), ch.end(), [&](int a, int b) { return (S.sn_level[a] >= P.spine_level) < (S.sn_level[b] >= P.spine_level); });
+        return ch;
+    };
     // extend-add gather lists
     P.ea_ptr.assign(S.ns + 1, 0);
     P.ea_src_ptr.push_back(0);
@@ -97,8 +127,8 @@ MfPlan mf_build_plan(int n, int m, const std::vector<int> &kpos, int mk, const s
         for (int s = 0; s < S.ns; ++s) {
             const int fs = S.sn_nc[s] + S.sn_nr[s];
             con.clear();
-            for (int q = S.child_ptr[s]; q < S.child_ptr[s + 1]; ++q) {
-                const int c = S.child[q], cnc = S.sn_nc[c], cnr = S.sn_nr[c], cld = cnc + cnr + 1;
+            for (int c : children_of(s)) {
+                const int cnc = S.sn_nc[c], cnr = S.sn_nr[c], cld = cnc + cnr + 1;
                 const int *rel = S.rel.data() + S.sn_rowptr[c];
                 for (int jj = 0; jj < cnr; ++jj)
                     for (int ii = jj; ii <= cnr; ++ii)
@@ -163,6 +193,7 @@ MfPlan mf_build_plan(int n, int m, const std::vector<int> &kpos, int mk, const s
         const bool merge = cnt <= 8 && tmax <= 8 && !getenv("SQPHIP_MF_NO_LEVEL_MERGE");
         for (int c = 0; c < 10; ++c) {
             MfLaunch L{(int)P.sched.size(), 0, 0, 0, c, 0};
+            L.level = l;
             for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; ++q) {
                 const int s = S.level_sn[q];
                 if (merge ? c != tmax - 1 : cls(s) != c) continue;
@@ -177,27 +208,7 @@ MfPlan mf_build_plan(int n, int m, const std::vector<int> &kpos, int mk, const s
         }
     }
     // solves: one launch per level; a workgroup of four waves takes one front of more than 64 rows or four smaller ones
-    const bool big_solve = !(getenv("SQPHIP_MF_BIG_SOLVE") && atoi(getenv("SQPHIP_MF_BIG_SOLVE")) == 0);   // experiment switch
-    // The top of the assembly tree is narrow (IEEE-118: one or two fronts per level over the last eight of thirteen
-    // levels): a launch per level there is a launch per front.  From the first level on above which no level holds
-    // more than two fronts, ONE workgroup per instance walks the remaining fronts in order (k_mf_solve_top: forward
-    // pass up, backward pass down, a workgroup barrier between fronts) -- same arithmetic, 2 x levels fewer launches.
-    P.top_level = S.nlevels;
-    if (big_solve && !(getenv("SQPHIP_MF_TOP") && atoi(getenv("SQPHIP_MF_TOP")) == 0)) {
-        // ... a level of up to four fronts joins the top as well when all of them are wave-sized (<= 64 rows): the four
-        // waves of the instance's workgroup take one each, exactly what a level launch would do, one launch less per pass
-        auto joins = [&](int lev) {
-            const int cnt = S.level_ptr[lev + 1] - S.level_ptr[lev];
-            if (cnt <= 2) return true;
-            if (cnt > 4 || getenv("SQPHIP_MF_TOP_NARROW")) return false;
-            for (int q = S.level_ptr[lev]; q < S.level_ptr[lev + 1]; ++q)
-                if (S.sn_nc[S.level_sn[q]] + S.sn_nr[S.level_sn[q]] > 64) return false;
-            return true;
-        };
-        int l = S.nlevels;
-        while (l > 0 && joins(l - 1)) --l;
-        if (S.nlevels - l >= 2) P.top_level = l;
-    }
+    // (the top of the tree -- P.top_level, decided above -- is one launch per pass: k_mf_solve_top2 / k_mf_solve_top)
     auto build_solve_launches = [&]() {
     P.sol_items.clear(); P.fwd.clear(); P.bwd.clear(); P.top = MfLaunch{0, 0, 256, 0, 0, 0};
     int top_maxfs = 64, top_lcap = 0;
@@ -325,6 +336,81 @@ MfPlan mf_build_plan(int n, int m, const std::vector<int> &kpos, int mk, const s
     for (size_t t = 0; t < P.ea_rc.size(); ++t) P.ea_ent[t] = {P.ea_rc[t], P.ea_src_ptr[t], P.ea_src_ptr[t + 1], P.ea_src[P.ea_src_ptr[t]]};
     P.ev_ent.resize(P.ev_idx.size());
     for (size_t t = 0; t < P.ev_idx.size(); ++t) P.ev_ent[t] = {P.ev_idx[t], P.ev_src_ptr[t], P.ev_src_ptr[t + 1], P.ev_src[P.ev_src_ptr[t]]};
+    // ---- the spine of the factorisation (k_mf_spine): the fronts of the levels >= spine_level by one workgroup per instance
+    for (const MfLaunch &L : P.fac) if (L.level < P.spine_level) P.fac_below++;
+    {
+        // (measured, round 4: the kernel reproduces the level launches bit for bit and keeps the blocks it hands over off the
+        //  memory bus, but a front costs it what it costs a level launch -- 230 us for the 17 fronts of IEEE-118 against ~170 us
+        //  of level launches, which run the two branches of the tree side by side -- and its 120 KB of LDS keeps every other
+        //  kernel off its CU: 7 251 against 7 704 QP/s at 512 resident scenarios, 1 946 against 2 014 at 64.  Off unless asked for.)
+        bool ok = P.spine_level < S.nlevels && getenv("SQPHIP_MF_SPINE") && atoi(getenv("SQPHIP_MF_SPINE")) == 1;
+        std::vector<int> sp;                             // spine fronts, ascending
+        for (int s = 0; ok && s < S.ns; ++s)
+            if (S.sn_level[s] >= P.spine_level) {
+                if (tiles(s) > 8) ok = false;
+                sp.push_back(s);
+                P.spine_T = std::max(P.spine_T, tiles(s));
+            }
+        for (size_t k = 0; ok && k < sp.size(); ++k) {
+            const int s = sp[k], nc = S.sn_nc[s], nr = S.sn_nr[s], fs = nc + nr;
+            MfSpineFront F{s, nc, nr, S.sn_first[s], (int)P.off[s], tiles(s), P.asm_ptr[s], P.asm_ptr[s + 1], 0, 0, 0, 0, 0, 0, 0, 0};
+            // the child that hands its block over in registers: the front right before this one in the spine, if it is a child
+            const int reg_child = (k > 0 && S.sn_parent[sp[k - 1]] == s) ? sp[k - 1] : -1;
+            std::vector<std::tuple<int, int, int>> con;      // (column, row, source offset): the extend-add from the arena
+            const std::vector<int> ch = children_of(s);
+            if (reg_child >= 0 && ch.back() != reg_child) { fprintf(stderr, "sqphip: mf_build_plan: the spine child is not the last child\n"); abort(); }
+            for (int c : ch) {
+                if (c == reg_child) continue;
+                const int cnc = S.sn_nc[c], cnr = S.sn_nr[c], cld = cnc + cnr + 1;
+                const int *rel = S.rel.data() + S.sn_rowptr[c];
+                for (int jj = 0; jj < cnr; ++jj)
+                    for (int ii = jj; ii <= cnr; ++ii)
+                        con.emplace_back(rel[jj], ii < cnr ? rel[ii] : fs, (int)(P.off[c] + (long)(cnc + jj) * cld + cnc + ii));
+            }
+            std::stable_sort(con.begin(), con.end(), [](const std::tuple<int, int, int> &a, const std::tuple<int, int, int> &b) {
+                return std::tie(std::get<0>(a), std::get<1>(a)) < std::tie(std::get<0>(b), std::get<1>(b)); });
+            F.ea_begin = (int)P.sp_ent.size();
+            bool open = false;
+            for (size_t r = 0; r < con.size(); ++r) {
+                const bool fresh = r == 0 || std::get<0>(con[r]) != std::get<0>(con[r - 1]) || std::get<1>(con[r]) != std::get<1>(con[r - 1]);
+                if (fresh) {
+                    if (open) P.sp_ent.back().src_end = (int)P.sp_src.size();
+                    P.sp_ent.push_back({std::get<1>(con[r]) | (std::get<0>(con[r]) << 16), (int)P.sp_src.size(), 0, std::get<2>(con[r])});
+                    open = true;
+                }
+                P.sp_src.push_back(std::get<2>(con[r]));
+            }
+            if (open) P.sp_ent.back().src_end = (int)P.sp_src.size();
+            F.ea_end = (int)P.sp_ent.size();
+            // hand-off to the next front?
+            if (k + 1 < sp.size() && S.sn_parent[s] == sp[k + 1]) {
+                const int p = sp[k + 1], pfs = S.sn_nc[p] + S.sn_nr[p];
+                F.handoff = 1; F.rel = (int)P.sp_rel.size();
+                for (int t = 0; t < nr; ++t) P.sp_rel.push_back(S.rel[S.sn_rowptr[s] + t]);
+                P.sp_rel.push_back(pfs);
+                P.spine_stage = std::max(P.spine_stage, (nr + 1) * nr);
+            }
+            P.sp_fr.push_back(F);
+        }
+        if (ok && !P.sp_fr.empty()) {
+            // LDS: the static front kernels' layout for the tallest front with eight waves (mfront.hip, mf_front_lds_doubles) + the row map
+            const int R = 16 * P.spine_T;
+            P.spine_stage = (P.spine_stage + 1) / 2 * 2;
+            P.spine_lds_bytes = 8L * ((long)R * R + 256 + 40 + R + 64 * 8 + P.spine_stage + 136);
+            if (P.spine_lds_bytes > 160 * 1024 - 1024) ok = false;
+        }
+        if (!ok || P.sp_fr.empty()) { P.sp_fr.clear(); P.sp_ent.clear(); P.sp_src.clear(); P.sp_rel.clear(); P.spine_lds_bytes = 0; P.spine_level = S.nlevels; P.fac_below = (int)P.fac.size(); }
+        if (getenv("SQPHIP_SYM_DUMP"))
+            for (const MfSpineFront &F : P.sp_fr) {
+                int hist[5] = {0, 0, 0, 0, 0};
+                for (int t = F.ea_begin; t < F.ea_end; ++t) hist[std::min(4, P.sp_ent[t].src_end - P.sp_ent[t].src_begin)]++;
+                fprintf(stderr, "  spine front %d: %d x %d, T %d, %d structural entries, %d receiving entries from the arena (1 / 2 / 3 / 4+ sources: %d / %d / %d / %d), handoff %d\n",
+                        F.s, F.nc, F.nr, F.T, F.asm_end - F.asm_begin, F.ea_end - F.ea_begin, hist[1], hist[2], hist[3], hist[4], F.handoff);
+            }
+        if (getenv("SQPHIP_SYM_DUMP"))
+            fprintf(stderr, "spine (factorisation): %d fronts from level %d, tallest %d tiles, %zu arena gather entries, LDS %ld bytes\n",
+                    (int)P.sp_fr.size(), P.spine_level, P.spine_T, P.sp_ent.size(), P.spine_lds_bytes);
+    }
     return P;
 }
 
@@ -342,6 +428,7 @@ static inline double item_value(const MfItem &it, const MfValues &V)
 }
 
 static double g_top2_err = -1.0;          // last replay of the streamed top solve on the host: relative error, -1: not applicable
+static double g_spine_err = -1.0;         // last replay of the spine kernel's assembly on the host: relative error, -1: not applicable
 
 void mf_host_factor_solve(const MfPlan &P, const MfValues &V, const double *rhs, double *sol, double *dinv)
 {
@@ -357,13 +444,53 @@ void mf_host_factor_solve(const MfPlan &P, const MfValues &V, const double *rhs,
             A[P.dest_loc[e]] = a;
         }
         for (int j = 0; j < nc; ++j) A[j * ld + fs] = x[f0 + j];
-        for (int q = S.child_ptr[s]; q < S.child_ptr[s + 1]; ++q) {
+        for (int q = S.child_ptr[s]; q < S.child_ptr[s + 1]; ++q) {      // (a sum; the kernels fix its order through the gather lists)
             const int c = S.child[q], cnc = S.sn_nc[c], cnr = S.sn_nr[c], cfs = cnc + cnr, cld = cfs + 1;
             const double *C = F.data() + P.off[c];
             const int *rel = S.rel.data() + S.sn_rowptr[c];
             for (int jj = 0; jj < cnr; ++jj)
                 for (int ii = jj; ii <= cnr; ++ii)
                     A[rel[jj] * ld + (ii < cnr ? rel[ii] : fs)] += C[(cnc + jj) * cld + cnc + ii];
+        }
+        // the assembly of the spine kernel (k_mf_spine) replayed from ITS plan arrays -- gather entries whose sources lie in the
+        // arena, the row map of the block the previous front hands over, the destination list -- against the image assembled
+        // above: validates those arrays without a GPU (CPU tests read the error through sqphip_mf_host_spine_err)
+        if (!P.sp_fr.empty()) {
+            if (s == P.sp_fr[0].s) g_spine_err = 0.0;
+            for (size_t k = 0; k < P.sp_fr.size(); ++k) {
+                const MfSpineFront &R = P.sp_fr[k];
+                if (R.s != s) continue;
+                const int Rn = 16 * R.T;
+                std::vector<double> img((size_t)Rn * Rn, 0.0);
+                for (int t = R.ea_begin; t < R.ea_end; ++t) {
+                    const MfGather &g = P.sp_ent[t];
+                    double a = F[g.src0];
+                    for (int q = g.src_begin + 1; q < g.src_end; ++q) a += F[P.sp_src[q]];
+                    img[(g.where >> 16) * Rn + (g.where & 0xffff)] += a;
+                }
+                if (k > 0 && P.sp_fr[k - 1].handoff) {
+                    const MfSpineFront &Cc = P.sp_fr[k - 1];
+                    const int cld = Cc.nc + Cc.nr + 1;
+                    const double *Cb = F.data() + Cc.off;
+                    const int *rel = P.sp_rel.data() + Cc.rel;
+                    for (int c = 0; c < Cc.nr; ++c)
+                        for (int r = c; r <= Cc.nr; ++r) img[rel[c] * Rn + rel[r]] += Cb[(Cc.nc + c) * cld + Cc.nc + r];
+                }
+                for (int e = R.asm_begin; e < R.asm_end; ++e) {
+                    double a = 0.0;
+                    for (int q = P.item_ptr[e]; q < P.item_ptr[e + 1]; ++q) a += item_value(P.items[q], V);
+                    double &dst = img[(P.dest_rc[e] >> 16) * Rn + (P.dest_rc[e] & 0xffff)];
+                    dst = a + dst;
+                }
+                for (int j = 0; j < nc; ++j) img[j * Rn + fs] = x[f0 + j] + img[j * Rn + fs];
+                double err = 0.0, scale = 0.0;
+                for (int c = 0; c < fs; ++c)
+                    for (int r = c; r <= fs; ++r) {
+                        err = std::max(err, std::fabs(img[c * Rn + r] - A[c * ld + r]));
+                        scale = std::max(scale, std::fabs(A[c * ld + r]));
+                    }
+                g_spine_err = std::max(g_spine_err, err / std::max(scale, 1e-300));
+            }
         }
         for (int k = 0; k < nc; ++k) {
             const double d = A[k * ld + k], di = 1.0 / d;
@@ -444,6 +571,7 @@ void mf_host_factor_solve(const MfPlan &P, const MfValues &V, const double *rhs,
 }  // namespace sqphip
 
 extern "C" double sqphip_mf_host_top2_err(void) { return sqphip::g_top2_err; }
+extern "C" double sqphip_mf_host_spine_err(void) { return sqphip::g_spine_err; }
 
 // C-ABI test hook (host only, no GPU): plan + host reference of the numeric phase for the NLP structure given as in
 // sqphip_create; values in the library's internal layouts (see include/sqphip.h).

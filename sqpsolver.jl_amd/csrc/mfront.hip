@@ -23,42 +23,11 @@
 // 8 nnz(L) written, the contribution blocks written once and read once.
 #include "ctx.hpp"
 #include "dev_util.hpp"
+#include "mf_dev.hpp"
 #include <cstdlib>
 #include <mutex>
 
 namespace sqphip {
-
-// Two candidates per sweep: 0 = the factorisation with the shift st.dw, 1 = the one with the next shift of the schedule
-// (dev_util.hpp next_shift), computed in the same launches for the instances mf_speculates() names; k_inertia picks
-// (IpmState.sel) and the solves follow.  The factor kernels run over 2 B "instances": blockIdx.y >= B is candidate 1.
-__device__ __forceinline__ double *mf_arena(const DV &d, int inst, int cand) { return (cand ? d.mf.fronts1 : d.mf.fronts) + (long)inst * d.mf.stride; }
-__device__ __forceinline__ double *mf_vals(const DV &d, int inst, int cand) { return (cand ? d.mf.vals1 : d.mf.vals) + (long)inst * d.mf.nnzK; }
-__device__ __forceinline__ double *mf_dinv(const DV &d, int inst, int cand) { return (cand ? d.dinv1 : d.dinv) + (long)inst * d.Fpad; }
-__device__ __forceinline__ double *mf_vv(const DV &d, int inst, int cand) { return (cand ? d.vv1 : d.vv) + (long)inst * d.Fpad; }
-// instance and candidate of a factor-side workgroup; false: nothing to do
-__device__ __forceinline__ bool mf_candidate(const DV &d, int want, int &inst, int &cand)
-{
-    inst = blockIdx.y; cand = 0;
-    if (inst >= d.B) { inst -= d.B; cand = 1; }
-    if (d.phase[inst] != want) return false;
-    return cand == 0 || mf_speculates(d, d.ist[inst]);
-}
-
-#define MF_REG_P 1e-8      // = IPM_REG_P / IPM_REG_D of ipm.hip
-#define MF_REG_D 1e-8
-
-__device__ __forceinline__ double mf_item_value(const MfItem &it, const double *hv, const double *jv, const double *Dd,
-                                                const double *sigp, const double *hd, const int *rt, double hsc,
-                                                double dw)
-{
-    switch (it.type) {
-    case MF_ITEM_H: return hsc * hv[it.a];
-    case MF_ITEM_JKEPT: return rt[it.row] != ROW_FREE ? jv[it.a] : 0.0;
-    case MF_ITEM_PAIR: return rt[it.row] != ROW_FREE ? jv[it.a] * jv[it.b] / (Dd[it.row] + MF_REG_D) : 0.0;
-    case MF_ITEM_VDIAG: return hd[it.a] + sigp[it.a] + dw + MF_REG_P;
-    default: return rt[it.row] != ROW_FREE ? -(Dd[it.row] + MF_REG_D) : -1.0;
-    }
-}
 
 // phase stamps of the factor kernel (instance 0 only; scripts/gpu_mf_trace.py builds with -DSQPHIP_MF_TRACE)
 #ifdef SQPHIP_MF_TRACE
@@ -73,12 +42,15 @@ __device__ long long g_mf_trace3[1 << 12][16];
 // ... and in the streamed top-of-tree solve: per step [compute wave: start, done, past the barrier | -, loader wave 1: likewise]
 #define MF_TR2S(a, b) if (inst == 0 && lane == 0 && j < 64 && wave < 2) g_mf_trace3[(do_fwd ? 64 : 0) + j][wave == 0 ? (a) : (b)] = (long long)clock64();
 #define MF_TR2W(c) if (trj >= 0 && lane == 0) g_mf_trace3[trj][c] = (long long)clock64();
+// ... and in the spine kernel (thread 0 of instance 0, first candidate): rows 128 + k, 100 MHz wall clock
+#define MF_TRSP(c) if (inst == 0 && cand == 0 && tid == 0 && k < 64) g_mf_trace3[128 + k][c] = (long long)wall_clock64();
 #else
 #define MF_TR(i)
 #define MF_TRW(i)
 #define MF_TRS(i)
 #define MF_TR2S(a, b)
 #define MF_TR2W(c)
+#define MF_TRSP(c)
 #endif
 
 // Thread layout inside a front: RL row lanes x (NT / RL) column groups; RL = 16 / 32 / 64 by front height so that a
@@ -473,40 +445,58 @@ __host__ __device__ constexpr int mf_front_lds_doubles(int T, int NW, bool ldsim
     return u + 256 + 40 + R + 64 * NW;
 }
 
-// everything wave W of NW does for one front of T tile rows: tiles into registers, the unrolled elimination, results
+// What wave W of NW does for one front of T tile rows, in three pieces over the same accumulator registers (the static
+// front kernel runs them back to back; the spine kernel puts the hand-over to the parent front between the last two):
+// tiles into registers, the unrolled elimination, results.
+template <int T, int NW, int W> struct MfTileSet {
+    static constexpr int NROWS = W < T ? (T - W + NW - 1) / NW : 0;
+    // tiles of my rows: row slot s <-> tile row ti = W + s NW, tiles tj = 0..ti at acc[off(s) + tj]
+    static constexpr int NTILES = NROWS > 0 ? NROWS * (2 * W + (NROWS - 1) * NW + 2) / 2 : 1;
+};
+
+// (the tiles travel between the pieces as a struct: a reference-to-array parameter of a vector type does not parse)
+template <int T, int NW, int W> struct MfAcc { d4 v[MfTileSet<T, NW, W>::NTILES]; };
+
 template <int T, int NW, int W, bool LDSIMG>
-__device__ __forceinline__ void mf_front_wave(const double *F, int LD, double *G, int ld, int fs, int nc, int with_rhs,
-                                              double *lds, double *dinv, double *vv, int lane, int trs)
+__device__ __forceinline__ void mf_front_load(MfAcc<T, NW, W> &A, const double *F, int LD, int fs, int lane)
 {
+    auto &acc = A.v;
+    constexpr int NROWS = MfTileSet<T, NW, W>::NROWS;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    int o = 0;
+#pragma unroll
+    for (int s = 0; s < NROWS; ++s) {
+        const int ti = W + s * NW;
+#pragma unroll
+        for (int tj = 0; tj <= ti; ++tj)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int col = 16 * tj + l4 + 4 * rr, row = 16 * ti + l15;
+                const bool in = LDSIMG || (row <= fs && col < fs);
+                acc[o + tj][rr] = in ? F[col * LD + row] : 0.0;
+            }
+        o += ti + 1;
+    }
+}
+
+// (LDSBAR: the barriers of the elimination wait for LDS traffic only -- the spine kernel holds global loads of the NEXT
+//  front in flight across the elimination, and a __syncthreads() would wait for them)
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+template <bool LDSBAR> __device__ __forceinline__ void mf_elim_barrier() { if constexpr (LDSBAR) lds_barrier(); else __syncthreads(); }
+
+template <int T, int NW, int W, bool LDSIMG, bool LDSBAR = false>
+__device__ __forceinline__ void mf_front_elim(MfAcc<T, NW, W> &A, int nc, double *lds, int lane, int trs)
+{
+    auto &acc = A.v;
     constexpr int R = 16 * T;
     constexpr int U = (LDSIMG ? R * R : 0) > 16 * R ? R * R : 16 * R;
-    MF_TRW(0)
-    constexpr int NROWS = W < T ? (T - W + NW - 1) / NW : 0;
+    constexpr int NROWS = MfTileSet<T, NW, W>::NROWS;
     double *Lp = lds, *dtile = lds + U, *rec = dtile + 256, *dl = rec + 40, *dsc = dl + R + 64 * W;
     const int l15 = lane & 15, l4 = lane >> 4;
     const MfLaneSel LS = mf_lane_sel(l4);
-    // tiles of my rows: row slot s <-> tile row ti = W + s NW, tiles tj = 0..ti at acc[off(s) + tj]
-    constexpr int NTILES = NROWS > 0 ? NROWS * (2 * W + (NROWS - 1) * NW + 2) / 2 : 1;
-    d4 acc[NTILES];
-    {
-        int o = 0;
-#pragma unroll
-        for (int s = 0; s < NROWS; ++s) {
-            const int ti = W + s * NW;
-#pragma unroll
-            for (int tj = 0; tj <= ti; ++tj)
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int col = 16 * tj + l4 + 4 * rr, row = 16 * ti + l15;
-                    const bool in = LDSIMG || (row <= fs && col < fs);
-                    acc[o + tj][rr] = in ? F[col * LD + row] : 0.0;
-                }
-            o += ti + 1;
-        }
-    }
-    MF_TRW(1)
-    __syncthreads();                      // the image is dead from here on: its LDS carries the rows of L
-    MF_TRW(2)
 #pragma unroll
     for (int tk = 0; tk < T; ++tk) {
         if (16 * tk >= nc) break;
@@ -547,7 +537,7 @@ __device__ __forceinline__ void mf_front_wave(const double *F, int LD, double *G
             acc[od] = dt;
         }
         if (tk == 0) { MF_TRW(3) }
-        __syncthreads();
+        mf_elim_barrier<LDSBAR>();
         if (tk == 0) { MF_TRW(4) }
         // B. my tiles below the diagonal tile: sixteen columns of every row; the rows of L go to LDS, X = L D stays here
         {
@@ -576,7 +566,7 @@ __device__ __forceinline__ void mf_front_wave(const double *F, int LD, double *G
             }
         }
         if (tk == 0) { MF_TRW(5) }
-        __syncthreads();
+        mf_elim_barrier<LDSBAR>();
         if (tk == 0) { MF_TRW(6) }
         // C. rank-16 update of my tiles to the right
         {
@@ -598,45 +588,72 @@ __device__ __forceinline__ void mf_front_wave(const double *F, int LD, double *G
             }
         }
     }
-    MF_TRW(7)
-    __syncthreads();
-    MF_TRW(8)
-    // results: L (scaled), D^-1 L^-1 b, the contribution block with its right-hand-side row
-    {
-        int o = 0;
+}
+
+// results: L (scaled), D^-1 L^-1 b, and -- cb_out -- the contribution block with its right-hand-side row (the spine kernel
+// hands the block to the parent front in registers instead: mf_front_scatter)
+// CB / ldcb: where the contribution block goes -- entry (row, col) of the front to CB[col * ldcb + row]: the front's own
+// storage in the arena (CB = G, ldcb = ld), or the spine kernel's LDS staging area in block coordinates
+template <int T, int NW, int W, bool LDSIMG>
+__device__ __forceinline__ void mf_front_store(const MfAcc<T, NW, W> &A, double *G, int ld, int fs, int nc,
+                                               int with_rhs, double *CB, int ldcb, const double *lds, double *dinv, double *vv, int lane)
+{
+    const auto &acc = A.v;
+    constexpr int R = 16 * T;
+    constexpr int U = (LDSIMG ? R * R : 0) > 16 * R ? R * R : 16 * R;
+    constexpr int NROWS = MfTileSet<T, NW, W>::NROWS;
+    const double *dl = lds + U + 256 + 40;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    int o = 0;
 #pragma unroll
-        for (int s = 0; s < NROWS; ++s) {
-            const int ti = W + s * NW;
+    for (int s = 0; s < NROWS; ++s) {
+        const int ti = W + s * NW;
 #pragma unroll
-            for (int tj = 0; tj <= ti; ++tj) {
-                // tiles strictly below the diagonal tiles whose rows all lie inside the front and whose columns are all
-                // eliminated (L) or all kept (contribution block) need no test per lane: most tiles of a large front
-                const bool inside = ti > tj && 16 * ti + 15 < fs;
-                if (inside && 16 * tj + 15 < nc) {
+        for (int tj = 0; tj <= ti; ++tj) {
+            // tiles strictly below the diagonal tiles whose rows all lie inside the front and whose columns are all
+            // eliminated (L) or all kept (contribution block) need no test per lane: most tiles of a large front
+            const bool inside = ti > tj && 16 * ti + 15 < fs;
+            if (inside && 16 * tj + 15 < nc) {
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        const int col = 16 * tj + l4 + 4 * rr;
-                        G[(long)col * ld + 16 * ti + l15] = acc[o + tj][rr] * dl[col];
-                    }
-                } else if (inside && 16 * tj >= nc) {
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int col = 16 * tj + l4 + 4 * rr;
+                    G[(long)col * ld + 16 * ti + l15] = acc[o + tj][rr] * dl[col];
+                }
+            } else if (inside && 16 * tj >= nc) {
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) G[(long)(16 * tj + l4 + 4 * rr) * ld + 16 * ti + l15] = acc[o + tj][rr];
-                } else {
+                for (int rr = 0; rr < 4; ++rr) CB[(long)(16 * tj + l4 + 4 * rr) * ldcb + 16 * ti + l15] = acc[o + tj][rr];
+            } else {
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        const int col = 16 * tj + l4 + 4 * rr, row = 16 * ti + l15;
-                        const double v = acc[o + tj][rr];
-                        if (col < nc) {
-                            if (row > col && row < fs) G[(long)col * ld + row] = v * dl[col];
-                            else if (row == fs && with_rhs) vv[col] = v * dl[col];
-                        } else if (col < fs && row >= col && row <= fs) G[(long)col * ld + row] = v;
-                    }
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int col = 16 * tj + l4 + 4 * rr, row = 16 * ti + l15;
+                    const double v = acc[o + tj][rr];
+                    if (col < nc) {
+                        if (row > col && row < fs) G[(long)col * ld + row] = v * dl[col];
+                        else if (row == fs && with_rhs) vv[col] = v * dl[col];
+                    } else if (col < fs && row >= col && row <= fs) CB[(long)col * ldcb + row] = v;
                 }
             }
-            o += ti + 1;
         }
+        o += ti + 1;
     }
     if (W == 0) for (int k = lane; k < nc; k += 64) dinv[k] = dl[k];
+}
+
+template <int T, int NW, int W, bool LDSIMG, bool LDSBAR = false>
+__device__ __forceinline__ void mf_front_wave(const double *F, int LD, double *G, int ld, int fs, int nc, int with_rhs,
+                                              double *lds, double *dinv, double *vv, int lane, int trs, double *CB, int ldcb)
+{
+    MF_TRW(0)
+    MfAcc<T, NW, W> acc;
+    mf_front_load<T, NW, W, LDSIMG>(acc, F, LD, fs, lane);
+    MF_TRW(1)
+    mf_elim_barrier<LDSBAR>();            // the image is dead from here on: its LDS carries the rows of L
+    MF_TRW(2)
+    mf_front_elim<T, NW, W, LDSIMG, LDSBAR>(acc, nc, lds, lane, trs);
+    MF_TRW(7)
+    mf_elim_barrier<LDSBAR>();
+    MF_TRW(8)
+    mf_front_store<T, NW, W, LDSIMG>(acc, G, ld, fs, nc, with_rhs, CB, ldcb, lds, dinv, vv, lane);
     MF_TRW(10)
 }
 
@@ -644,7 +661,7 @@ template <int T, int NW, int W, bool LDSIMG>
 __device__ __forceinline__ void mf_front_dispatch(int wave, const double *F, int LD, double *G, int ld, int fs, int nc,
                                                   int with_rhs, double *lds, double *dinv, double *vv, int lane, int trs)
 {
-    if (wave == W) mf_front_wave<T, NW, W, LDSIMG>(F, LD, G, ld, fs, nc, with_rhs, lds, dinv, vv, lane, trs);
+    if (wave == W) mf_front_wave<T, NW, W, LDSIMG>(F, LD, G, ld, fs, nc, with_rhs, lds, dinv, vv, lane, trs, G, ld);
     else if constexpr (W + 1 < NW) mf_front_dispatch<T, NW, W + 1, LDSIMG>(wave, F, LD, G, ld, fs, nc, with_rhs, lds, dinv, vv, lane, trs);
 }
 
@@ -730,6 +747,176 @@ __global__ __launch_bounds__(64 * NW) void k_mf_front(DV d, int sbegin, int want
                                         mf_vv(d, inst, cand) + f0, tid & 63, inst == 0 ? s : -1);
     MF_TR(4)
     MF_TR(5)
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The spine of the factorisation in ONE launch (k_mf_spine; plan: mfplan.hip, MfSpineFront; round 4).
+//
+// The levels of the assembly tree from spine_level up hold one or two fronts per instance each (IEEE-118: levels 3 .. 12, 17
+// fronts, 620 of the 2 069 columns): as level launches they were twelve kernel boundaries per sweep, each front a chain of
+// descriptor -> values / gather entries -> gathered sources -> image before its elimination could start, and every
+// contribution block a trip through the arena.  Here one workgroup of eight waves per instance walks these fronts in order
+// (children first) with the front image in LDS:
+//   * the elimination is that of the static front kernel (mf_front_wave: same tiles, same arithmetic, same bits as
+//     k_mf_front<T, 8, true>);
+//   * the contribution block of a front whose parent is the NEXT front of the spine never leaves the chip: out of the
+//     accumulator registers into an LDS staging area, from there into the parent's image behind the terms the parent
+//     gathers from the arena -- the order the gather lists of every other kernel use too (mfplan.hip, children_of);
+//   * what the next front needs from global memory -- its assembled values with their destinations, the receiving entries
+//     of its extend-add from the arena -- is REQUESTED before the current front is eliminated and held in registers across
+//     the elimination, whose barriers wait for LDS traffic only; the gathered sources are requested when the elimination
+//     ends;
+//   * L, 1 / D and D^-1 L^-1 b go to the arena exactly where the solve kernels expect them.
+constexpr int MF_SP_NW = 8, MF_SP_NT = 64 * MF_SP_NW, MF_SP_PV = 3, MF_SP_PE = 6;
+struct MfSpinePre { int vrc[MF_SP_PV]; double vval[MF_SP_PV]; int ew[MF_SP_PE], eb[MF_SP_PE], ee[MF_SP_PE], es[MF_SP_PE]; double ea[MF_SP_PE]; double brhs; };
+
+template <int T, int W>
+__device__ __forceinline__ void mf_spine_dispatch_w(int wave, double *lds, double *G, int ld, int fs, int nc, int with_rhs, double *dinv,
+                                                    double *vv, int lane, double *CB, int ldcb)
+{
+    if (wave == W) mf_front_wave<T, MF_SP_NW, W, true, true>(lds, 16 * T, G, ld, fs, nc, with_rhs, lds, dinv, vv, lane, -1, CB, ldcb);
+    else if constexpr (W + 1 < MF_SP_NW) mf_spine_dispatch_w<T, W + 1>(wave, lds, G, ld, fs, nc, with_rhs, dinv, vv, lane, CB, ldcb);
+}
+template <int T>
+__device__ __forceinline__ void mf_spine_dispatch_t(int Tf, int wave, double *lds, double *G, int ld, int fs, int nc, int with_rhs, double *dinv,
+                                                    double *vv, int lane, double *CB, int ldcb)
+{
+    if (Tf == T) mf_spine_dispatch_w<T, 0>(wave, lds, G, ld, fs, nc, with_rhs, dinv, vv, lane, CB, ldcb);
+    else if constexpr (T < 8) mf_spine_dispatch_t<T + 1>(Tf, wave, lds, G, ld, fs, nc, with_rhs, dinv, vv, lane, CB, ldcb);
+}
+
+// LDS (doubles): [static front kernels' layout for the tallest front, eight waves][staging area of a block that is handed to the
+// parent: (nr + 1) x nr, block coordinates][two row maps of 136 ints]
+__global__ __launch_bounds__(MF_SP_NT) void k_mf_spine(DV d, int want, int with_rhs)
+{
+    constexpr int NT = MF_SP_NT, PV = MF_SP_PV, PE = MF_SP_PE;
+    int inst, cand;
+    if (!mf_candidate(d, want, inst, cand)) return;
+    const MfDev &M = d.mf;
+    extern __shared__ double mf_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *arena = mf_arena(d, inst, cand);
+    const double *vals = mf_vals(d, inst, cand);
+    const double *xv = d.xv + (long)inst * d.Fpad;
+    double *dinv = mf_dinv(d, inst, cand), *vv = mf_vv(d, inst, cand);
+    double *stage = mf_lds + mf_front_lds_doubles(M.sp_T, MF_SP_NW, true);
+    int *relmap = reinterpret_cast<int *>(stage + M.sp_stage);                                          // two maps of 136 ints
+    const int n = M.sp_n;
+    // a front record into scalar registers (every lane reads the same words)
+    auto rec = [&](int k) {
+        MfSpineFront R;
+        const int *g = reinterpret_cast<const int *>(M.sp_fr + k);
+        int *w = reinterpret_cast<int *>(&R);
+#pragma unroll
+        for (int q = 0; q < 12; ++q) w[q] = __builtin_amdgcn_readfirstlane(g[q]);
+        R.pad0 = R.pad1 = R.pad2 = R.pad3 = 0;
+        return R;
+    };
+    // request what front R needs from global memory, first round: destinations + values, receiving entries, right-hand side
+    auto issue1 = [&](const MfSpineFront &R, MfSpinePre &P) {
+#pragma unroll
+        for (int k = 0; k < PV; ++k) {
+            const int e = R.asm_begin + tid + k * NT;
+            P.vrc[k] = -1; P.vval[k] = 0.0;
+            if (e < R.asm_end) { P.vrc[k] = M.dest_rc[e]; P.vval[k] = vals[e]; }
+        }
+#pragma unroll
+        for (int k = 0; k < PE; ++k) {
+            const int t = R.ea_begin + tid + k * NT;
+            P.ew[k] = -1; P.eb[k] = 0; P.ee[k] = 0; P.es[k] = 0; P.ea[k] = 0.0;
+            if (t < R.ea_end) { const MfGather g = M.sp_ent[t]; P.ew[k] = g.where; P.eb[k] = g.src_begin; P.ee[k] = g.src_end; P.es[k] = g.src0; }
+        }
+        P.brhs = (with_rhs && tid < R.nc) ? xv[R.first + tid] : 0.0;
+    };
+    // ... second round: the first gathered source of every receiving entry (most have exactly one)
+    auto issue2 = [&](MfSpinePre &P) {
+#pragma unroll
+        for (int k = 0; k < PE; ++k) if (P.ew[k] >= 0) P.ea[k] = arena[P.es[k]];
+    };
+    // image of front R: zero, then the extend-add from the arena (sums in list order: a = src0 + src1 + ...; image = 0 + a)
+    auto begin_image = [&](const MfSpineFront &R, const MfSpinePre &P, int slot) {
+        const int Rn = 16 * R.T;
+        for (int e = tid; e < Rn * Rn; e += NT) mf_lds[e] = 0.0;
+        if (R.handoff && tid <= R.nr) relmap[136 * slot + tid] = M.sp_rel[R.rel + tid];
+        lds_barrier();
+#pragma unroll
+        for (int k = 0; k < PE; ++k)
+            if (P.ew[k] >= 0) {
+                double a = P.ea[k];
+                for (int q = P.eb[k] + 1; q < P.ee[k]; ++q) a += arena[M.sp_src[q]];
+                mf_lds[(P.ew[k] >> 16) * Rn + (P.ew[k] & 0xffff)] += a;
+            }
+        for (int t = R.ea_begin + tid + PE * NT; t < R.ea_end; t += NT) {
+            const MfGather g = M.sp_ent[t];
+            double a = arena[g.src0];
+            for (int q = g.src_begin + 1; q < g.src_end; ++q) a += arena[M.sp_src[q]];
+            mf_lds[(g.where >> 16) * Rn + (g.where & 0xffff)] += a;
+        }
+        lds_barrier();
+    };
+    // ... finished: the structural entries of the Newton matrix and the right-hand side on top of the children's sums
+    auto finish_image = [&](const MfSpineFront &R, const MfSpinePre &P) {
+        const int Rn = 16 * R.T, fs = R.nc + R.nr;
+#pragma unroll
+        for (int k = 0; k < PV; ++k)
+            if (P.vrc[k] >= 0) { double *q = mf_lds + (P.vrc[k] >> 16) * Rn + (P.vrc[k] & 0xffff); *q = P.vval[k] + *q; }
+        for (int e = R.asm_begin + tid + PV * NT; e < R.asm_end; e += NT) {
+            const int rc = M.dest_rc[e];
+            double *q = mf_lds + (rc >> 16) * Rn + (rc & 0xffff);
+            *q = vals[e] + *q;
+        }
+        if (with_rhs) {
+            if (tid < R.nc) { double *q = mf_lds + tid * Rn + fs; *q = P.brhs + *q; }
+            for (int j = tid + NT; j < R.nc; j += NT) { double *q = mf_lds + j * Rn + fs; *q = xv[R.first + j] + *q; }
+        }
+        lds_barrier();
+    };
+    MfSpineFront R = rec(0);
+    MfSpinePre P;
+    issue1(R, P);
+    issue2(P);
+    begin_image(R, P, 0);
+    for (int k = 0; k < n; ++k) {
+        MF_TRSP(0)
+        finish_image(R, P);
+        MF_TRSP(1)
+        const bool more = k + 1 < n;
+        MfSpineFront Rn = R;
+        if (more) { Rn = rec(k + 1); issue1(Rn, P); }          // (held in registers across the elimination: its barriers wait for LDS only)
+        MF_TRSP(2)
+        const int nc = R.nc, nr = R.nr, fs = nc + nr, ld = fs + 1;
+        double *G = arena + R.off;
+        // the contribution block: to the arena, or -- its parent is the next front -- to the staging area in block coordinates
+        double *CB = R.handoff ? stage - (long)nc * (nr + 1) - nc : G;
+        // (the lane index is made opaque per front: with it loop-invariant the compiler hoists the per-lane LDS addresses of all
+        //  64 specialisations -- eight front heights x eight waves -- out of this loop and keeps hundreds of them alive: 256
+        //  registers and 470 bytes of scratch per lane)
+        int lane_k = lane;
+        asm volatile("" : "+v"(lane_k));
+        mf_spine_dispatch_t<1>(R.T, wave, mf_lds, G, ld, fs, nc, with_rhs, dinv + R.first, vv + R.first, lane_k, CB, R.handoff ? nr + 1 : ld);
+        MF_TRSP(3)
+        if (!more) break;
+        issue2(P);
+        // a block that went to the arena is read back by a later front of this workgroup (other waves): have it arrive
+        if (!R.handoff) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();                         // every wave is done with 1 / D and the rows of L in LDS; the staged block is complete
+        MF_TRSP(4)
+        begin_image(Rn, P, (k + 1) & 1);
+        MF_TRSP(5)
+        if (R.handoff) {
+            // the staged block on top of the parent's sums from the arena: entry (r, c) -> (rel[r], rel[c]); rel[nr] = the
+            // parent's right-hand-side row.  Every entry has its own destination.
+            const int *rel = relmap + 136 * (k & 1);
+            const int LDn = 16 * Rn.T;
+            for (int e = tid; e < nr * (nr + 1); e += NT) {
+                const int c = e / (nr + 1), r = e - c * (nr + 1);
+                if (r >= c) mf_lds[rel[c] * LDn + rel[r]] += stage[e];
+            }
+            lds_barrier();
+        }
+        MF_TRSP(6)
+        R = Rn;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1102,10 +1289,7 @@ __global__ __launch_bounds__(64 * NWV) void k_mf_solve_inst(DV d, int want, int 
 // 1 / D, right-hand side and gather lists into the second LDS buffer.  Updates between top fronts, the solution of the
 // ancestors and D^-1 L^-1 b stay in LDS; global memory sees only the results (stores nobody waits for).  One
 // workgroup barrier per front, and it waits for LDS traffic only.
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
+// (lds_barrier(): defined with the front kernels above)
 
 // What a loader wave holds of a front between requesting it and writing it to LDS: its share of the image of L (rows
 // below the diagonal of the nc columns: columns lw, lw + NLW, ...; rows lane and lane + 64), and one of the small
@@ -1634,21 +1818,27 @@ void mf_device_setup(Ctx &C)
     big(reinterpret_cast<const void *>(k_mf_fwd2<true>)); big(reinterpret_cast<const void *>(k_mf_bwd2<true>));
     big(reinterpret_cast<const void *>(k_mf_fwd2<false>)); big(reinterpret_cast<const void *>(k_mf_bwd2<false>));
     big(reinterpret_cast<const void *>(k_mf_solve_top2));
+    big(reinterpret_cast<const void *>(k_mf_spine));
     (void)hipGetLastError();
     C.mf_big_lds = ok;
 }
 
-void mf_factor(Ctx &C, int want, bool with_rhs)
+void mf_factor(Ctx &C, int want, bool with_rhs, bool values_done)
 {
     const DV &d = C.d;
     hipStream_t s = C.stream;
     static const bool v1 = getenv("SQPHIP_MF_V1") != nullptr;      // cross-check: the plain rank-1 kernel for every front
     const int wr = (int)with_rhs;
     const int nb = d.mf.fronts1 ? 2 * d.B : d.B;         // with the second candidate the factor side runs over 2 B "instances"
-    if (!v1) hipLaunchKernelGGL(k_mf_values, dim3((d.mf.nnzK + 255) / 256, nb), dim3(256), 0, s, d, want);
+    // (values_done: the stage kernel that built the right-hand sides has assembled the values too: mf_values_block)
+    if (!v1 && !values_done) hipLaunchKernelGGL(k_mf_values, dim3((d.mf.nnzK + 255) / 256, nb), dim3(256), 0, s, d, want);
     // static front kernels (k_mf_front<T, NW, LDSIMG>) unless SQPHIP_MF_STATIC=0 asks for the generic ones (cross-check)
     const bool stat = !(getenv("SQPHIP_MF_STATIC") && atoi(getenv("SQPHIP_MF_STATIC")) == 0);     // (read per call: tests flip it)
+    // the levels below the spine as level launches, the spine (mfplan.hip: spine_level) by one workgroup per instance
+    const bool spine = !v1 && d.mf.sp_n > 0 && C.mf_big_lds;
+    int li = 0;
     for (const MfLaunch &L : C.mfp().fac) {
+        if (spine && li++ >= C.mfp().fac_below) break;
         const dim3 grid(L.count, nb);
         const int T = L.tiles, R = 16 * T;
         if (v1 || T > 13) { hipLaunchKernelGGL((k_mf_factor<256, true>), grid, dim3(256), 0, s, d, L.begin, want, wr); continue; }
@@ -1659,7 +1849,9 @@ void mf_factor(Ctx &C, int want, bool with_rhs)
         // size) where thousands of small fronts are in flight.  Measured (QP/s, static from T = 1 / from T = 4 / never):
         // 512 x IEEE-118 5565 / 5507 / 5259, 64 x IEEE-118 1372 / - / 1315, 9241 shape 20.6 / 24.3 / 23.4, IEEE-14 50.9 k /
         // 55.4 k / 53.9 k.  SQPHIP_MF_STATIC_MIN moves the threshold (tests run it at 1 to cover every instantiation).
-        const int stat_min = getenv("SQPHIP_MF_STATIC_MIN") ? atoi(getenv("SQPHIP_MF_STATIC_MIN")) : 4;
+        // (round 4: on a narrow level -- a handful of fronts, i.e. the levels the spine kernel takes over -- the static
+        //  kernels run every front: the level-launch build, SQPHIP_MF_SPINE=0, then gives the bits of the spine kernel)
+        const int stat_min = getenv("SQPHIP_MF_STATIC_MIN") ? atoi(getenv("SQPHIP_MF_STATIC_MIN")) : (L.count <= 8 && L.level >= C.mfp().narrow_level ? 1 : 4);
         // four waves instead of two for fronts of four (bit 0) / five (bit 1) tile rows on the levels near the top of the
         // tree (a handful of fronts: latency, not occupancy, is what counts there): 512 x IEEE-118 7 100 -> 7 154 / 7 297 / 7 326
         // QP/s with bit 0 / bit 1 / both, same bits (SQPHIP_MF_NW4=0: two waves everywhere)
@@ -1691,7 +1883,8 @@ void mf_factor(Ctx &C, int want, bool with_rhs)
 #undef MF_GENERIC
 #undef MF_STATIC
     }
-    C.mf_factor_launches += (long)C.mfp().fac.size();
+    if (spine) hipLaunchKernelGGL(k_mf_spine, dim3(1, nb), dim3(MF_SP_NT), (size_t)C.mfp().spine_lds_bytes, s, d, want, wr);
+    C.mf_factor_launches += spine ? (long)C.mfp().fac_below + 1 : (long)C.mfp().fac.size();
 }
 
 // x (d.xv) <- K^-1 x through the factors; skip_fwd: d.vv already holds D^-1 L^-1 b (fused into mf_factor)

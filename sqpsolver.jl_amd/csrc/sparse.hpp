@@ -93,7 +93,7 @@ struct MfGather { int where, src_begin, src_end, src0; };
 // of the launch (sizes the LDS image), lds_bytes = dynamic LDS.
 // Solve launches also carry what the LDS-staged kernels (k_mf_fwd2 / k_mf_bwd2) need: wimg = doubles of a wave's image
 // buffer (-1: a front of the level does not fit them), lds2 = their dynamic LDS.
-struct MfLaunch { int begin, count, threads, lds_bytes, cls, tiles; int wimg = -1, lds2 = 0, hasbig = 1; };
+struct MfLaunch { int begin, count, threads, lds_bytes, cls, tiles; int wimg = -1, lds2 = 0, hasbig = 1; int level = 0; };
 
 // One front of the narrow top of the assembly tree as the streaming solve kernel (k_mf_solve_top2, mfront.hip) sees it:
 // where its factor lives in the arena, the leading dimension of its LDS image (odd: the transposed reads of the
@@ -101,6 +101,16 @@ struct MfLaunch { int begin, count, threads, lds_bytes, cls, tiles; int wimg = -
 // where its update vector goes (uoff, into the LDS vector of updates), its gather lists (pointers relative to the
 // front, sources = indices into that vector) and the LDS indices of its rows (rloc).  lbuf = doubles of its LDS buffer.
 struct MfTopFront { int s, nc, nr, first, off, ll, xloc, uoff, gptr, gsrc0, nsrc, rloc, lbuf, pad0, pad1, pad2; };
+
+// One front of the spine of the factorisation (k_mf_spine, mfront.hip): the fronts of the levels >= spine_level, ascending
+// (children first), eliminated one after the other by ONE workgroup per instance with the front image in LDS.  What
+// the kernel needs per front in one 64-byte record: geometry, its tiles T (16-row tiles of the front with its
+// right-hand-side row), its ranges in the destination list (dest_rc / vals: unchanged) and in the spine's own gather list
+// sp_ent / sp_src -- the extend-add WITHOUT the contributions of the child that hands its block over in registers --,
+// handoff = 1: the NEXT front of the spine is this front's parent and receives the contribution block straight from
+// the accumulator registers (no trip through the arena), through the row map sp_rel[rel .. rel + nr] (local row of the
+// block -> local index in the parent; entry nr = the parent's right-hand-side row).
+struct MfSpineFront { int s, nc, nr, first, off, T, asm_begin, asm_end, ea_begin, ea_end, handoff, rel, pad0, pad1, pad2, pad3; };
 
 struct MfPlan {
     SparseSym S;
@@ -133,6 +143,15 @@ struct MfPlan {
     int top_xtotal = 0, top_utotal = 0, top_buf0 = 0, top_buf1 = 0;
     long top2_lds_bytes = 0;
     long nnzK = 0;                               // structural entries of the lower triangle (destinations)
+    // the spine of the factorisation (k_mf_spine): spine_level == S.nlevels: not applicable (a front beyond 8 tiles) or off
+    int spine_level = 0, spine_T = 0;             // first level of the spine; tiles of its tallest front (sizes the LDS image)
+    int narrow_level = 0;                         // first level of the narrow top of the tree, whether or not the top / spine kernels apply
+    std::vector<MfSpineFront> sp_fr;
+    std::vector<MfGather> sp_ent;                 // receiving entries of the spine fronts' extend-add from the ARENA
+    std::vector<int> sp_src, sp_rel;
+    long spine_lds_bytes = 0;
+    int spine_stage = 0;                          // doubles of the LDS staging area: the largest (nr + 1) x nr among the blocks handed over
+    int fac_below = 0;                            // launches of `fac` that lie below the spine (the rest are the level launches of the spine's fronts)
 };
 
 // kpos / krow as in DV; jcolptr.. = CSC of J, jrowptr/jrcol/jrslot its CSR view, hcolptr/hrowval full symmetric CSC

@@ -474,20 +474,23 @@ __global__ void k_sqp_count(DV d, int *host_slot)
 {
     // counters[2] = instances that still have work in this run, [3] = pending sub-problem starts; host_slot: the same
     // two words in pinned host memory (written from here: one launch per sweep less than a device-to-host copy behind it)
-    int nb = 0, ns = 0;
+    // host_slot[1] (round 4): instances waiting for a refinement solve (PH_RESOLVE) -- with the monotone rule the second solve
+    // slot of a sweep is launched only when the host has seen one (ipm_sweep, Ctx::want_resolve)
+    int nb = 0, ns = 0, nr = 0;
     for (int i = threadIdx.x; i < d.B; i += blockDim.x) {
         const SqpState &S = d.sst[i];
         if (!S.done && (S.budget > 0 || S.stage != ST_TOP)) ++nb;
         if (d.ist[i].start) ++ns;
+        if (d.phase[i] == PH_RESOLVE) ++nr;
     }
-    __shared__ int a[64], b[64];
-    a[threadIdx.x] = nb; b[threadIdx.x] = ns;
+    __shared__ int a[64], b[64], c[64];
+    a[threadIdx.x] = nb; b[threadIdx.x] = ns; c[threadIdx.x] = nr;
     __syncthreads();
     if (threadIdx.x == 0) {
-        int s0 = 0, s1 = 0;
-        for (int k = 0; k < (int)blockDim.x; ++k) { s0 += a[k]; s1 += b[k]; }
+        int s0 = 0, s1 = 0, s2 = 0;
+        for (int k = 0; k < (int)blockDim.x; ++k) { s0 += a[k]; s1 += b[k]; s2 += c[k]; }
         d.counters[2] = s0; d.counters[3] = s1;
-        if (host_slot) { host_slot[0] = s0; host_slot[1] = s1; __threadfence_system(); }
+        if (host_slot) { host_slot[0] = s0; host_slot[1] = s2; __threadfence_system(); }
     }
 }
 
@@ -565,6 +568,7 @@ static void sqp_run_lane(Ctx &C, int max_outer)
     hipStream_t s = C.stream;
     const dim3 gB(d.B), bT(TPB);
     C.run_sweep = 0;                     // (the first sweep of a run always carries the transitions: ipm_sweep)
+    C.want_resolve = true;               // (... and the refinement slot, until the first counter has come back)
     hipLaunchKernelGGL(k_sqp_budget, dim3(1), dim3(64), 0, s, d, max_outer > 0 ? max_outer : 0x3fffffff);
     hipLaunchKernelGGL(k_sqp_begin, gB, bT, 0, s, d);
     // The "anyone left?" counter of sweep k is read while sweep k + 1 is already queued: the stream never runs dry
@@ -577,6 +581,7 @@ static void sqp_run_lane(Ctx &C, int max_outer)
         SQPHIP_HIP_OK(hipEventSynchronize(ev[k & 1]));
         SQPHIP_HIP_OK(hipGetLastError());   // a failed launch anywhere in the sweep surfaces here
         const int left = C.h_counters[2 + 2 * (k & 1)];
+        C.want_resolve = C.h_counters[3 + 2 * (k & 1)] > 0;      // (refinement solves pending after sweep k: the next sweep queued carries the slot)
         if (sweep_log) fprintf(stderr, "%d%c", left, (k % 32) == 31 ? '\n' : ' ');
         return left;
     };

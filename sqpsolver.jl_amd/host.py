@@ -114,6 +114,12 @@ def mf_host_top2_err() -> float:
     return float(_lib.lib().sqphip_mf_host_top2_err())
 
 
+def mf_host_spine_err() -> float:
+    """After `mf_host_solve`: relative error of the host replay of the spine kernel's front assembly (k_mf_spine) from its own
+    plan arrays against the images of the plain recursion (-1: the plan has no spine)."""
+    return float(_lib.lib().sqphip_mf_host_spine_err())
+
+
 class Context:
     """Owns a sqphip_ctx (one NLP structure, `batch` instances)."""
 

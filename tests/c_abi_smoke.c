@@ -37,7 +37,7 @@ int main(int argc, char **argv)
     CHECK(o.tol_direction == 1e-8 && o.tol_residual == 1e-8 && o.tol_infeas == 1e-8);    /* parameters.jl:17-19 */
     CHECK(o.init_mu == 1.0 && o.max_mu == 1e10 && o.tr_size == 10.0 && o.rho == 0.8 && o.eta == 0.4 && o.tau == 0.9);
     CHECK(o.min_alpha == 1e-6 && o.max_iter == 3000 && o.use_soc == 0 && o.literal_quirks == 1);
-    CHECK(o.ipm_tol == 1e-9 && o.ipm_max_iter == 200 && o.ipm_phase1 == 0 && o.device == 0 && o.ipm_corrector == 1);
+    CHECK(o.ipm_tol == 1e-9 && o.ipm_max_iter == 200 && o.ipm_phase1 == 0 && o.device == 0 && o.ipm_corrector == 0);
     CHECK(o.kkt_condense == 1 && o.kkt_tile_order == 1 && o.kkt_mode == 0 && o.ipm_warm_start == 0);
 
     /* ratio test / radius update, sqp_trust_region.jl:529-538, :574-577 */

@@ -1430,6 +1430,80 @@ def test_speculative_second_shift_changes_nothing_but_the_schedule(monkeypatch):
     assert got["1"][3] <= got["2"][3] < got["0"][3]
 
 
+def test_flat_sparse_products_give_the_fused_stage_bits(monkeypatch):
+    """Large instances (the 1354- and 9241-bus shapes) run the sparse products of the vector stages -- H v, J' w, J v, the
+    expansion of the eliminated rows, the working vector of the solves -- as flat kernels over the whole batch, the stage
+    kernels split around them (ipm.hip, k_sp_products; DV::flat).  The same sums by the same routines: forced on IEEE-118
+    and IEEE-14 shapes (SQPHIP_VEC_FLAT=1) against the fused stages, with and without their LDS staging -- the same iterates
+    bit for bit, the same per-sub-problem logs and work counters; reference sign (non-convex sub-problems: inertia
+    corrections, refinement steps, restoration) and textbook sign, condensed and full form of the Newton matrix."""
+    for case, quirks, B, iters, extra in (("case118", 1, 3, 7, {}), ("case14", 0, 4, 30, {}), ("case14", 1, 3, 10, {"kkt_condense": 0})):
+        nb, ng, nl, seed = CASES[case]
+        base = acopf_synth(nb, ng, nl, seed)
+        nets = [base] + [contingency(base, 3 + 4 * s, seed) for s in range(1, B)]
+        lays = [acopf_layout(nt) for nt in nets]
+        kw = dict(max_iter=iters, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=quirks, **extra)
+        got = {}
+        for mode in ("flat", "fused", "fused-nolds"):
+            monkeypatch.setenv("SQPHIP_VEC_FLAT", "1" if mode == "flat" else "0")
+            if mode == "fused-nolds": monkeypatch.setenv("SQPHIP_NO_VSTAGE", "1")
+            else: monkeypatch.delenv("SQPHIP_NO_VSTAGE", raising=False)
+            ctx = _run_batch(nets, lays, kw, kkt_mode=2)
+            c = ctx.counters()
+            got[mode] = ([ctx.sqp_get(b)["x"] for b in range(B)], [ctx.sqp_qp_log(b) for b in range(B)],
+                         [(ctx.sqp_get(b)["status"], ctx.sqp_get(b)["iter"]) for b in range(B)], (c["n_qp"], c["n_ipm_iter"], c["n_factor"], c["n_solve"]))
+            ctx.close()
+        monkeypatch.delenv("SQPHIP_NO_VSTAGE", raising=False)
+        for mode in ("fused", "fused-nolds"):
+            assert all(np.array_equal(a, b) for a, b in zip(got["flat"][0], got[mode][0])), (case, mode)
+            assert got["flat"][1] == got[mode][1] and got["flat"][2] == got[mode][2] and got["flat"][3] == got[mode][3], (case, mode)
+
+
+def test_matrix_values_by_the_stage_kernel_give_the_flat_kernel_bits(monkeypatch):
+    """The values of the structural entries of the Newton matrix are assembled by the stage kernel that has just built the
+    instance's right-hand side (mf_values_block, round 4) instead of a flat launch of its own on the critical path of every
+    sweep (k_mf_values, SQPHIP_MF_VALS_INLINE=0): same sums, same order, both candidate shifts -- the same iterates bit for
+    bit, the same logs and counters (three IEEE-118 scenarios with the speculative second shift on)."""
+    nb, ng, nl, seed = CASES["case118"]
+    base = acopf_synth(nb, ng, nl, seed)
+    nets = [base, contingency(base, 7, seed), contingency(base, 3, seed)]
+    lays = [acopf_layout(nt) for nt in nets]
+    kw = dict(max_iter=7, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=1)
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SQPHIP_MF_VALS_INLINE", mode)
+        ctx = _run_batch(nets, lays, kw)
+        c = ctx.counters()
+        got[mode] = ([ctx.sqp_get(b)["x"] for b in range(3)], [ctx.sqp_qp_log(b) for b in range(3)], (c["n_qp"], c["n_ipm_iter"], c["n_factor"], c["n_solve"]))
+        ctx.close()
+    assert all(np.array_equal(a, b) for a, b in zip(got["1"][0], got["0"][0]))
+    assert got["1"][1] == got["0"][1] and got["1"][2] == got["0"][2]
+
+
+def test_spine_kernel_gives_the_level_launch_bits(monkeypatch):
+    """k_mf_spine (round 4): the fronts of the narrow top of the assembly tree -- IEEE-118: levels 3 .. 12, 17 fronts -- are
+    eliminated by one workgroup per instance in ONE launch, the front image in LDS, a contribution block whose parent is the
+    next front handed over on chip.  Same tiles, same arithmetic, same summation order as the level launches
+    (SQPHIP_MF_SPINE=0, read when the plan is built): the same iterates bit for bit, the same per-sub-problem logs and
+    work counters, twelve factor launches per sweep fewer."""
+    nb, ng, nl, seed = CASES["case118"]
+    base = acopf_synth(nb, ng, nl, seed)
+    nets = [base, contingency(base, 7, seed), contingency(base, 3, seed), contingency(base, 100, seed)]
+    lays = [acopf_layout(nt) for nt in nets]
+    kw = dict(max_iter=7, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=1)
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SQPHIP_MF_SPINE", mode)
+        ctx = _run_batch(nets, lays, kw)
+        c = ctx.counters()
+        got[mode] = ([ctx.sqp_get(b)["x"] for b in range(4)], [ctx.sqp_qp_log(b) for b in range(4)],
+                     (c["n_qp"], c["n_ipm_iter"], c["n_factor"]), c["factor_launches"])
+        ctx.close()
+    assert all(np.array_equal(a, b) for a, b in zip(got["1"][0], got["0"][0]))
+    assert got["1"][1] == got["0"][1] and got["1"][2] == got["0"][2]
+    assert got["1"][3] < got["0"][3]
+
+
 @pytest.mark.parametrize("slots", [4, 64])
 def test_scenario_queue_gives_the_batch_results(slots):
     """More scenarios than slots (sqphip_sqp_stream_*): 12 IEEE-14-shaped contingency scenarios through 4 slots (three

@@ -45,9 +45,10 @@ def _random_values(lay, seed, free_frac=0.0):
 
 @pytest.mark.parametrize("case,cond,free", [("case14", 1, 0.0), ("case14", 0, 0.2), ("case118", 1, 0.0), ("case118", 1, 0.3),
                                             ("case118", 0, 0.0)])
-def test_multifrontal_plan_reproduces_a_dense_solve(case, cond, free):
+def test_multifrontal_plan_reproduces_a_dense_solve(case, cond, free, monkeypatch):
     """Plan = ordering + supernodes + assembly lists + extend-add maps.  Its host reference (front-by-front partial
     LDL^T with the right-hand side carried along) must solve the Newton system like numpy does, with the right inertia."""
+    monkeypatch.setenv("SQPHIP_MF_SPINE", "1")      # the spine kernel's plan is built on request only (mfplan.hip)
     _, lay = _layout(case)
     Jv, Hv, Dd, sigp, hd, rt = _random_values(lay, 3, free)
     K, kept = _dense_newton(lay, cond, Jv, Hv, Dd, sigp, hd, rt, 0.7, 1e-3)
@@ -61,6 +62,11 @@ def test_multifrontal_plan_reproduces_a_dense_solve(case, cond, free):
     # forms end in fronts beyond the kernel's 84 columns / 128 rows: 96 x 0 for IEEE-14, 162 columns for IEEE-118)
     err = pkg.mf_host_top2_err()
     assert (err == -1.0 and cond == 0) or 0.0 <= err <= 1e-12, err
+    # ... and the front assembly of the spine kernel (k_mf_spine) from ITS arrays: gather entries whose sources lie in the
+    # arena, the block a front hands to its parent through the row map, the destination list -- against the images the plain
+    # recursion assembled; IEEE-14 has no narrow top, the full forms end in fronts of more than eight tiles
+    serr = pkg.mf_host_spine_err()
+    assert (serr == -1.0 and (cond == 0 or case == "case14")) or 0.0 <= serr <= 1e-13, serr
     assert npos == lay.n == int((np.linalg.eigvalsh(K) > 0).sum())
     assert np.all(np.isfinite(dinv)) and int((dinv > 0).sum()) == lay.n
 
