@@ -1,0 +1,7 @@
+#!/bin/bash
+for rep in 1 2; do
+for b in 512 64; do
+for sp in 0 1; do
+  v=$(SQPHIP_POST_SPLIT=$sp timeout -k 10 120 python bench.py --steps 20 --warmup 5 --quick --batch $b 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print(round(d['value'],1), d['config']['sweeps'])")
+  echo "batch $b post_split $sp: $v"
+done; done; done

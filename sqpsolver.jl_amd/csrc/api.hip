@@ -132,7 +132,7 @@ void make_lanes(Ctx &C)
         L->is_lane = true;
         L->opt = C.opt; L->n = C.n; L->m = C.m; L->acopf_attached = C.acopf_attached;
         L->mfp_ = C.mfp_;
-        L->trans_period = C.trans_period; L->mf_big_lds = C.mf_big_lds;
+        L->trans_period = C.trans_period; L->mf_big_lds = C.mf_big_lds; L->post_split = C.post_split;
         L->d = group_view(C.d, lo, hi - lo, g);
         // the first group runs on the owner's stream (idle during sqphip_sqp_run): HIP maps streams onto four hardware
         // queues by default, and a fifth stream would share one -- measured: 3131 QP/s with five streams against 5216
@@ -393,6 +393,7 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
         SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
         if (const char *e = getenv("SQPHIP_TRANS_PERIOD")) C.trans_period = atoi(e);      // experiment switch, read once per context
         if (d.sparse) mf_device_setup(C);
+        C.post_split = getenv("SQPHIP_POST_SPLIT") && atoi(getenv("SQPHIP_POST_SPLIT")) == 1;
         make_lanes(C);
         return SQPHIP_OK;
     });

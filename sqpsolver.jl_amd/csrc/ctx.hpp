@@ -189,6 +189,7 @@ struct Ctx {
     // of the current sqphip_sqp_run / _stream_run call, so the first sweep of every run is a transition sweep -- slots
     // armed by the scenario queue draw their scenario there, whatever the lifetime counter n_sweeps says.
     long run_sweep = 0;
+    bool post_split = false;        // experiment (SQPHIP_POST_SPLIT): the right-hand side of the next iteration by its own launch behind k_ipm_post
     bool want_resolve = true;       // monotone rule: this sweep carries the second solve slot (an instance asked for a refinement solve)
     int trans_period = 0;           // 0: by group size (3 from 64 instances, 2 from 32, else 1); SQPHIP_TRANS_PERIOD, read at creation
     Timers tm;
@@ -241,7 +242,8 @@ void comm_release(Ctx &C);
 // mfront.hip
 void mf_device_setup(Ctx &C);
 void mf_factor(Ctx &C, int want, bool with_rhs, bool values_done = false);
-void mf_solve(Ctx &C, int want, bool skip_fwd);
+void mf_solve(Ctx &C, int want, bool skip_fwd, bool inertia = false);   // inertia: the streamed top kernel tests the inertia of PH_FACTOR instances first
+bool mf_solve_tests_inertia(const Ctx &C);     // ... which it can when the plan has a streamed top (k_mf_solve_top2)
 // acopf.hip
 void launch_acopf_eval_point(Ctx &C, int inst, const double *x_dev, double sigma, const double *lam_dev,
                              double *f_dev, double *grad_dev, double *g_dev, double *jcoo_dev,

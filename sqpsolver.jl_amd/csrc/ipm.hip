@@ -618,31 +618,10 @@ __global__ __launch_bounds__(TPB, SQPHIP_VEC_WAVES_PER_EU) void k_inertia(DV d)
     const bool spec = mf_speculates(d, st);
     const double *dinv = d.dinv + (long)inst * d.Fpad, *dinv1 = spec ? d.dinv1 + (long)inst * d.Fpad : nullptr;
     double np = 0, bad = 0, np1 = 0, bad1 = 0;
-    for (int i = threadIdx.x; i < d.Fpad; i += TPB) {
-        if (d.uinv[i] < 0) continue;             // identity padding
-        const double v = dinv[i];
-        if (!fin(v) || v == 0.0) bad += 1; else if (v > 0) np += 1;
-        if (spec) {
-            const double w = dinv1[i];
-            if (!fin(w) || w == 0.0) bad1 += 1; else if (w > 0) np1 += 1;
-        }
-    }
+    inertia_count(d, dinv, dinv1, TPB, np, bad, np1, bad1);
     np = block_reduce<OpSum>(np); bad = block_reduce<OpSum>(bad);
     if (spec) { np1 = block_reduce<OpSum>(np1); bad1 = block_reduce<OpSum>(bad1); }
-    const bool ok[2] = { (np == (double)d.n) && bad == 0, spec && (np1 == (double)d.n) && bad1 == 0 };
-    if (threadIdx.x != 0) return;
-    for (int cand = 0; cand < (spec ? 2 : 1); ++cand) {
-        st.n_factor++;                           // the factorisation with the shift st.dw
-        if (ok[cand]) {
-            if (st.dw > 0.0) st.dw_last = st.dw;
-            st.refine_it = 0; st.sel = cand;
-            d.phase[inst] = PH_SOLVE;
-            return;
-        }
-        st.fac_attempt++;
-        st.dw = next_shift(st.dw, st.dw_last);   // (candidate 1 was factorised with exactly this shift)
-        if (st.dw > 1e40 || st.fac_attempt >= 60) { st.rc = 2; d.phase[inst] = PH_DONE; return; }
-    }
+    if (threadIdx.x == 0) inertia_decide(d, inst, st, spec, np, bad, np1, bad1);
 }
 
 // after a triangular solve: accumulate (expanding the eliminated rows in the condensed form), form the residual
@@ -1062,13 +1041,15 @@ __global__ __launch_bounds__(TPB, SQPHIP_VEC_WAVES_PER_EU) void k_ipm_tail(DV d,
 // step, convergence test of the new iterate, the next Newton right-hand side -- is ONE kernel, and the second solve slot
 // of a sweep exists only for the rare refinement step (0.4 % of the iterations on 512 x IEEE-118): `want` = PH_SOLVE behind
 // the solve of the sweep, PH_RESOLVE behind a refinement solve.  25 launches per sweep instead of 36.
-__global__ __launch_bounds__(TPB, SQPHIP_VEC_WAVES_PER_EU) void k_ipm_post(DV d, int last, int want)
+template <int WANT, bool RHS>
+__global__ __launch_bounds__(TPB, SQPHIP_VEC_WAVES_PER_EU) void k_ipm_post(DV d, int last)
 {
-    b_refine(d, last, want);
+    b_refine(d, last, WANT);
     __syncthreads();
     b_ipm_step(d);
     __syncthreads();
     b_ipm_prepare(d);
+    if (!RHS) return;          // (the right-hand side by k_ipm_rhs behind this kernel: experiment switch SQPHIP_POST_SPLIT)
     __syncthreads();
     b_build_rhs(d);
 }
@@ -1188,7 +1169,9 @@ void ipm_sweep(Ctx &C, bool sqp_level)
     // Default: 3 for groups of 64 instances and more, 2 from 32 on, else 1; SQPHIP_TRANS_PERIOD overrides (read once, at creation).
     // The position is counted per RUN (Ctx::run_sweep, reset by sqp_run_lane): the first sweep of every run is a transition
     // sweep -- a run that starts with every slot idle (scenario queue) draws its scenarios there.
-    const int period = C.trans_period > 0 ? C.trans_period : (d.B >= 64 ? 3 : (d.B >= 32 ? 2 : 1));
+    // (round 4, monotone rule -- shorter sweeps, the transitions weigh more: every fourth sweep from groups of eight on;
+    //  512 x IEEE-118 P = 3 / 4 / 5 -> 8 836 / 8 878 / 8 894 QP/s, 64 scenarios P = 1 / 2 / 4 / 5 -> 2 458 / 2 555 / 2 584 / 2 567)
+    const int period = C.trans_period > 0 ? C.trans_period : (d.ipm_corrector == 0 ? (d.B >= 8 ? 4 : 1) : (d.B >= 64 ? 3 : (d.B >= 32 ? 2 : 1)));
     const bool trans = !sqp_level || period <= 1 || (C.run_sweep % period) == 0;
     C.run_sweep++;
     const dim3 gP((d.n + d.m + 255) / 256, d.B), gX((d.Fpad + 255) / 256, d.B), b256(256);       // flat products (d.flat)
@@ -1215,11 +1198,12 @@ void ipm_sweep(Ctx &C, bool sqp_level)
     if (d.sparse) { mf_factor(C, PH_FACTOR, true, d.vals_inline != 0); C.tm.n_factor++; }
     else ldlt_factor(C.plan, d.K, d.dinv, d.phase, PH_FACTOR, &C.tm, d.xv, d.vv);
     if (C.tm.enabled) { hipEventRecord(ev.second, s); C.tm.pending_factor.push_back(ev); }
+    const bool top_inertia = d.sparse && mf_solve_tests_inertia(C);      // the streamed solve kernel tests the inertia itself
     auto lin_solve = [&](int want, bool skip_fwd) {
-        if (d.sparse) mf_solve(C, want, skip_fwd);
+        if (d.sparse) mf_solve(C, want, skip_fwd, top_inertia && want == PH_SOLVE);
         else ldlt_solve(C.plan, d.K, d.dinv, d.xv, d.vv, d.phase, want, skip_fwd);
     };
-    hipLaunchKernelGGL(k_inertia, gB, bT, 0, s, d);
+    if (!top_inertia) hipLaunchKernelGGL(k_inertia, gB, bT, 0, s, d);
     if (C.tm.enabled) { ev = C.tm.get(); hipEventRecord(ev.first, s); }
     // backward half of the solve (the forward half happened inside the factorisation), then the residual against
     // the sparse operator.  No iterative refinement: one step of it (the policy until late in round 1, two more
@@ -1250,7 +1234,15 @@ void ipm_sweep(Ctx &C, bool sqp_level)
         // behind the solve: residual check, step, convergence test, next right-hand side; then -- only when the host has
         // seen an instance ask for it (C.want_resolve: the counter of the sweep before last) -- the refinement solve
         auto post = [&](int want) {
-            if (!d.flat) { hipLaunchKernelGGL(k_ipm_post, gB, bT, vlds, s, d, last, want); return; }
+            if (!d.flat) {
+                if (C.post_split) {
+                    if (want == PH_SOLVE) hipLaunchKernelGGL((k_ipm_post<PH_SOLVE, false>), gB, bT, vlds, s, d, last);
+                    else hipLaunchKernelGGL((k_ipm_post<PH_RESOLVE, false>), gB, bT, vlds, s, d, last);
+                    hipLaunchKernelGGL(k_ipm_rhs, gB, bT, vlds, s, d);
+                } else if (want == PH_SOLVE) hipLaunchKernelGGL((k_ipm_post<PH_SOLVE, true>), gB, bT, vlds, s, d, last);
+                else hipLaunchKernelGGL((k_ipm_post<PH_RESOLVE, true>), gB, bT, vlds, s, d, last);
+                return;
+            }
             refine_front(want);
             hipLaunchKernelGGL(k_ipm_tail_b, gB, bT, vlds, s, d, last, want);
             reload();
@@ -1259,7 +1251,10 @@ void ipm_sweep(Ctx &C, bool sqp_level)
             hipLaunchKernelGGL(k_sp_load_xv, gX, b256, 0, s, d, 0);
         };
         post(PH_SOLVE);
-        if (C.want_resolve) {
+        // (the refinement slot at most every fourth sweep of a run: with 128 instances in a group one of them asks for it in a
+        //  third of all sweeps, and the slot costs every instance of the group a forward and a backward pass of gated kernels;
+        //  the few that wait are 0.4 % of the iterations)
+        if (C.want_resolve && (!sqp_level || d.B < 8 || (C.run_sweep & 3) == 0)) {
             if (C.tm.enabled) { ev = C.tm.get(); hipEventRecord(ev.first, s); }
             lin_solve(PH_RESOLVE, false);
             if (C.tm.enabled) { hipEventRecord(ev.second, s); C.tm.pending_solve.push_back(ev); }

@@ -66,4 +66,41 @@ static __device__ __forceinline__ void mf_values_block(const DV &d, int inst, in
     }
 }
 
+// Inertia of a factorisation from its pivot signs (n positive), shared by k_inertia (ipm.hip: one workgroup of the vector
+// kernels per instance) and the streamed solve kernel, which does the test of its instance in its own prologue
+// (k_mf_solve_top2, mfront.hip: a launch less per sweep).  The counts are small integers: any summation order gives the
+// same doubles.
+static __device__ __forceinline__ void inertia_count(const DV &d, const double *dinv, const double *dinv1, int nthreads,
+                                                     double &np, double &bad, double &np1, double &bad1)
+{
+    for (int i = threadIdx.x; i < d.Fpad; i += nthreads) {
+        if (d.uinv[i] < 0) continue;             // identity padding
+        const double v = dinv[i];
+        if (!isfinite(v) || v == 0.0) bad += 1; else if (v > 0) np += 1;
+        if (dinv1) {
+            const double w = dinv1[i];
+            if (!isfinite(w) || w == 0.0) bad1 += 1; else if (w > 0) np1 += 1;
+        }
+    }
+}
+// ... and the decision (one thread): PH_SOLVE, or a larger delta_w (stays PH_FACTOR).  Sparse path: the sweep has
+// factorised the shift st.dw AND -- for the instances mf_speculates() names -- the next shift of the schedule; the
+// bookkeeping is that of a run that factorises one shift per sweep (same counters, same decisions as the oracle).
+static __device__ __forceinline__ void inertia_decide(const DV &d, int inst, IpmState &st, bool spec, double np, double bad, double np1, double bad1)
+{
+    const bool ok[2] = { (np == (double)d.n) && bad == 0, spec && (np1 == (double)d.n) && bad1 == 0 };
+    for (int cand = 0; cand < (spec ? 2 : 1); ++cand) {
+        st.n_factor++;                           // the factorisation with the shift st.dw
+        if (ok[cand]) {
+            if (st.dw > 0.0) st.dw_last = st.dw;
+            st.refine_it = 0; st.sel = cand;
+            d.phase[inst] = PH_SOLVE;
+            return;
+        }
+        st.fac_attempt++;
+        st.dw = next_shift(st.dw, st.dw_last);   // (candidate 1 was factorised with exactly this shift)
+        if (st.dw > 1e40 || st.fac_attempt >= 60) { st.rc = 2; d.phase[inst] = PH_DONE; return; }
+    }
+}
+
 }  // namespace sqphip

@@ -1582,9 +1582,30 @@ __device__ __forceinline__ void mf_top_bwd(const MfTopFront &F, const double *Bf
     if constexpr (TWO) if (i1 < nc) { xtop[F.xloc + i1] = t1; xg[F.first + i1] = t1; }
 }
 
-__global__ __launch_bounds__(256) void k_mf_solve_top2(DV d, int want, int do_fwd)
+__global__ __launch_bounds__(256) void k_mf_solve_top2(DV d, int want, int do_fwd, int inertia)
 {
     const int inst = blockIdx.x;
+    if (inertia && d.phase[inst] == PH_FACTOR) {
+        // the inertia test of this instance's factorisation (round 4: k_inertia's job, a launch less per sweep): pivot signs
+        // counted by the four waves, decision by thread 0, published to the workgroup by the barrier
+        IpmState &st = d.ist[inst];
+        const bool spec = mf_speculates(d, st);
+        double c[4] = {0.0, 0.0, 0.0, 0.0};
+        inertia_count(d, d.dinv + (long)inst * d.Fpad, spec ? d.dinv1 + (long)inst * d.Fpad : nullptr, 256, c[0], c[1], c[2], c[3]);
+        extern __shared__ double mf_lds[];
+        double (*ish)[4] = reinterpret_cast<double (*)[4]>(mf_lds);      // (sixteen doubles of the dynamic LDS, free until the solve starts)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) c[q] += __shfl_xor(c[q], o);
+            if ((threadIdx.x & 63) == 0) ish[q][threadIdx.x >> 6] = c[q];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            inertia_decide(d, inst, st, spec, (ish[0][0] + ish[0][1]) + (ish[0][2] + ish[0][3]), (ish[1][0] + ish[1][1]) + (ish[1][2] + ish[1][3]),
+                           (ish[2][0] + ish[2][1]) + (ish[2][2] + ish[2][3]), (ish[3][0] + ish[3][1]) + (ish[3][2] + ish[3][3]));
+        __syncthreads();
+    }
     if (d.phase[inst] != want) return;
     const MfDev &M = d.mf;
     extern __shared__ double mf_lds[];
@@ -1887,8 +1908,14 @@ void mf_factor(Ctx &C, int want, bool with_rhs, bool values_done)
     C.mf_factor_launches += spine ? (long)C.mfp().fac_below + 1 : (long)C.mfp().fac.size();
 }
 
+bool mf_solve_tests_inertia(const Ctx &C)
+{
+    static const bool off = getenv("SQPHIP_MF_INERTIA_KERNEL") != nullptr;      // experiment switch: keep k_inertia
+    return !off && C.d.sparse && C.d.mf.top_n > 0 && !mf_generic_solves() && !(C.d.B >= (getenv("SQPHIP_MF_INST_SOLVE_MIN") ? atoi(getenv("SQPHIP_MF_INST_SOLVE_MIN")) : (1 << 30)));
+}
+
 // x (d.xv) <- K^-1 x through the factors; skip_fwd: d.vv already holds D^-1 L^-1 b (fused into mf_factor)
-void mf_solve(Ctx &C, int want, bool skip_fwd)
+void mf_solve(Ctx &C, int want, bool skip_fwd, bool inertia)
 {
     const DV &d = C.d;
     hipStream_t s = C.stream;
@@ -1915,7 +1942,7 @@ void mf_solve(Ctx &C, int want, bool skip_fwd)
         }
     if (d.mf.top_n > 0 && !generic) {
         const size_t lds = (size_t)C.mfp().top2_lds_bytes;
-        hipLaunchKernelGGL(k_mf_solve_top2, dim3(d.B), dim3(256), lds, s, d, want, skip_fwd ? 0 : 1);
+        hipLaunchKernelGGL(k_mf_solve_top2, dim3(d.B), dim3(256), lds, s, d, want, skip_fwd ? 0 : 1, inertia ? 1 : 0);
     } else if (const MfLaunch &T = C.mfp().top; T.count > 0)
         hipLaunchKernelGGL(k_mf_solve_top, dim3(d.B), dim3(256), T.lds_bytes, s, d, T.begin, T.count, want, skip_fwd ? 0 : 1, generic,
                            T.tiles, T.cls, T.lds_bytes / 8 - T.cls);
