@@ -400,6 +400,59 @@ def main():
                     "launches": int(tr_launch), "avg_launch_ms": 1e3 * tr_sec / tr_launch if tr_launch else None,
                     "share_of_wall": tr_sec / (t1 - t0) if t1 > t0 else None,
                     "onbox_mfma_probe_tflops": probe}
+    # ---- per-kernel records (rank 0, sparse path): three more outer iterations with an event pair around every launch group
+    # of a sweep by kernel class (sqphip_set_timing(ctx, 2) -- outside the timed region: about twenty event records per
+    # sweep).  achieved = ALGORITHMIC bytes of what the class touches x the units it processed / its time on the stream
+    # (averaged over the instance groups, which overlap), against the HBM peak; DESIGN.md section 6 has the byte counts.
+    kernels = None
+    if rank == 0 and c1["sparse"] and not args.no_kernel_timing:
+        try:
+            kt0, cc0 = ctx.kernel_times(), ctx.counters()
+            ctx.set_timing(2)
+            ctx.sqp_run(3)
+            torch.cuda.synchronize()
+            ctx.set_timing(False)
+            kt1, cc1 = ctx.kernel_times(), ctx.counters()
+            dfac, dsol, dit = (cc1[k] - cc0[k] for k in ("n_factor", "n_solve", "n_ipm_iter"))
+            ng_ = max(1, int(cc1["n_groups"]))
+            nK, nL, nKt, nLt, ct = (int(cc1[k]) for k in ("nnz_k", "nnz_l", "nnz_k_top", "nnz_l_top", "cols_top"))
+            nj, nh = len(lay0.jrow), 2 * len(lay0.hrow)
+            dres = max(0, dsol - dit)                      # refinement / corrector solves: forward + backward
+            per_unit = {
+                "values": ("k_mf_values", "instance-factorisation", dfac, 20.0 * nK, "12 B read (value + index) + 8 B written per structural entry"),
+                "fronts_low": ("k_mf_factor2<*> / k_mf_front<*> below the narrow top of the tree", "instance-factorisation", dfac,
+                               8.0 * (nL - nLt) + 8.0 * (nK - nKt), "8 B per entry of L written + 8 B per assembled value read"),
+                "fronts_top": ("k_mf_front<*> of the narrow top (17 fronts of IEEE-118)", "instance-factorisation", dfac,
+                               8.0 * nLt + 8.0 * nKt, "8 B per entry of L written + 8 B per assembled value read"),
+                "solve_top": ("k_mf_solve_top2 (with the inertia test)", "instance-solve", dit + dres,
+                              (dit * (8.0 * nLt + 16.0 * ct) + dres * (16.0 * nLt + 16.0 * ct)) / max(1, dit + dres),
+                              "backward pass: 8 B per entry of L of the top + 16 B per column; forward + backward: twice the L"),
+                "solve_levels": ("k_mf_fwd2 / k_mf_bwd2", "instance-solve", dit + dres,
+                                 (dit * (8.0 * (nL - nLt) + 16.0 * (N - ct)) + dres * (16.0 * (nL - nLt) + 16.0 * (N - ct))) / max(1, dit + dres),
+                                 "as solve_top, the fronts below the top"),
+                "post": ("k_ipm_post (residual check, step, convergence test, next right-hand side)", "instance-iteration", dit,
+                         8.0 * (36 * lay0.n + 52 * lay0.m) + 12.0 * (2 * nh + 6 * nj),
+                         "36 vector passes over n + 52 over m (8 B each) + 2 Hessian and 6 Jacobian products (12 B per entry)"),
+            }
+            kernels = {}
+            for cls, (name, unit, units, bpu, what) in per_unit.items():
+                sec, grp = kt1[cls][0] - kt0[cls][0], kt1[cls][1] - kt0[cls][1]
+                if sec <= 0 or grp <= 0:
+                    continue
+                ach = units * bpu / (sec / ng_) / 1e9
+                kernels[cls] = {"kernel": name, "unit": unit, "units": int(units), "algorithmic_bytes_per_unit": bpu, "bytes": what,
+                                "launch_groups": int(grp), "avg_us_per_launch_group": 1e6 * sec / grp,
+                                "achieved": ach, "peak": HBM_PEAK_GBS, "frac": ach / HBM_PEAK_GBS, "bound": "hbm"}
+            tr = kt1["transitions"][0] - kt0["transitions"][0]
+            if tr > 0:
+                kernels["transitions"] = {"kernel": "k_qp_finish + k_sqp_stage + k_ipm_head", "launch_groups": int(kt1["transitions"][1] - kt0["transitions"][1]),
+                                          "avg_us_per_launch_group": 1e6 * tr / max(1, kt1["transitions"][1] - kt0["transitions"][1])}
+            tot = sum(kt1[k][0] - kt0[k][0] for k in kt1)
+            for cls in kernels:
+                kernels[cls]["share_of_timed_kernel_seconds"] = (kt1[cls][0] - kt0[cls][0]) / tot if tot > 0 else None
+        except Exception as e:
+            print(f"[bench] optional record 'kernels' failed: {e!r}", file=sys.stderr)
+            kernels = {"error": repr(e)}
     ctx.close()
 
     # ---- rank 0, single-GPU only: the dense MFMA LDL^T on its own, the run-to-termination legs, the CPU baseline
@@ -582,6 +635,7 @@ def main():
                                "sub-problems are non-convex and most scenarios never meet the termination test; see "
                                "`termination` for both sign conventions run to the end"},
             "roofline": roofline,
+            "kernels": kernels,
             "dense_ldlt": dense,
             "termination": termination,
             "screening": screening,

@@ -353,6 +353,8 @@ typedef struct {
                               * factorisation, corrector, refinement steps) */
     int64_t n_groups;        /* instance groups of sqphip_sqp_run, each on its own HIP stream and host thread (1: none).
                               * n_sweeps and the kernel seconds are summed over the groups */
+    int64_t nnz_l_top, nnz_k_top, cols_top;   /* the narrow top of the assembly tree (the fronts k_mf_solve_top2 streams): entries
+                              * of L, structural entries of the matrix, columns -- the algorithmic bytes of the per-kernel records */
 } sqphip_counters;
 int sqphip_get_counters(sqphip_ctx *ctx, sqphip_counters *c);
 /* The work of the batched run since sqphip_sqp_reset, split by sub-problem mode: out[3 k + 0..2] = sub-problems solved,
@@ -378,8 +380,16 @@ int sqphip_get_termination_counters(sqphip_ctx *ctx, int64_t *out4);
 int sqphip_sqp_last_request(sqphip_ctx *ctx, int32_t inst, int32_t *mode, double *delta, double *mu_pen, double *x_k,
                             double *c, double *b, double *jac_coo, double *hess_coo);
 int sqphip_reset_counters(sqphip_ctx *ctx);
-/* HIP-event timing of the factor / trailing-update / solve kernels (off by default) */
+/* HIP-event timing of the factor / trailing-update / solve kernels (off by default); enabled = 2 additionally brackets every
+ * launch group of a sweep by kernel class (about twenty more event records per sweep: meant for a short measurement leg) */
 int sqphip_set_timing(sqphip_ctx *ctx, int32_t enabled);
+/* ... the class timers (sparse path): seconds[c] of kernel time and groups[c] = launch groups timed, summed over the instance
+ * groups, since sqphip_reset_counters; classes c = 0 values of the matrix entries (k_mf_values), 1 front kernels below the
+ * narrow top of the assembly tree, 2 front kernels of the top (level launches, or k_mf_spine), 3 the top of the tree in
+ * the solves (k_mf_solve_top2, with the inertia test), 4 level launches of the solves (k_mf_fwd2 / k_mf_bwd2), 5 the stage
+ * kernel behind the solve (k_ipm_post: residual check, step, convergence test, next right-hand side), 6 transitions between
+ * sub-problems (k_qp_finish, k_sqp_stage, k_ipm_head).  cap = length of both arrays (7 classes). */
+int sqphip_get_kernel_times(sqphip_ctx *ctx, double *seconds, int64_t *groups, int32_t cap);
 
 /* Test hooks and micro-benchmarks (host reference of the multifrontal plan, kernel-level twins, dense LDL^T probes) are
  * exported by the library but are not part of the drop-in boundary: include/sqphip_test_hooks.h. */

@@ -114,6 +114,7 @@ def lib():
         L.ora_problem_x0.restype = dp
         L.ora_problem_x0.argtypes = [C.c_void_p]
         L.ora_problem_destroy.argtypes = [C.c_void_p]
+        L.ora_problem_drop_hessian.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -225,6 +226,13 @@ class Problem:
         return dict(n=self.n, m=self.m, num_linear=int(c.num_linear),
                     jrow=g(c.jrow, nj), jcol=g(c.jcol, nj), hrow=g(c.hrow, nh), hcol=g(c.hcol, nh),
                     xL=g(c.xL, self.n), xU=g(c.xU, self.n), gL=g(c.gL, self.m), gU=g(c.gU, self.m))
+
+
+def drop_hessian(prob: Problem) -> Problem:
+    """The same problem without second derivatives (the reference's `eval_h === nothing` path, sqp.jl:92): every
+    sub-problem gets a linear objective (subproblem_JuMP.jl:137-140)."""
+    lib().ora_problem_drop_hessian(prob.h)
+    return prob
 
 
 def problem_toy():

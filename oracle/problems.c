@@ -48,6 +48,10 @@ static ora_problem *mk(int64_t n, int64_t m, int64_t nlin, int64_t nnzj, const i
     return P;
 }
 const ora_nlp *ora_problem_nlp(const ora_problem *p) { return &p->nlp; }
+/* the problem without second derivatives: what the reference sees when the evaluator offers no :Hess feature
+ * (MOI_wrapper.jl:1092-1103,1178: eval_h === nothing, hessian_type "none"; sqp.jl:92 then never fills the Hessian and
+ * subproblem_JuMP.jl:137-140 gives every sub-problem a linear objective: sequential linear programming) */
+void ora_problem_drop_hessian(ora_problem *p) { p->nlp.nnzh = 0; p->nlp.eval_h = NULL; }
 const double *ora_problem_x0(const ora_problem *p) { return p->x0; }
 void ora_problem_destroy(ora_problem *P)
 {

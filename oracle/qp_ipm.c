@@ -74,6 +74,8 @@ struct ora_qp {
     /* stats */
     int ipm_iters, n_factor;
     double last_elastic;
+    int last_rule;          /* how the last interior-point run ended: 0 error <= tol, 1 / 2 / 3 acceptable-termination rules, -1 not converged */
+    double last_e0;         /* ... and its scaled optimality error there */
 };
 
 static double *dalloc(int64_t k) { return (double *)calloc((size_t)(k > 0 ? k : 1), sizeof(double)); }
@@ -185,6 +187,13 @@ void ora_qp_destroy(ora_qp *q)
     for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) free(ptrs[i]);
     ora_sldl_free(q->sl);
     free(q);
+}
+
+/* how the last interior-point run of the last sub-problem ended (the device twin: sqphip_qp_termination) */
+void ora_qp_termination(const ora_qp *q, int *rule, double *scaled_error)
+{
+    if (rule) *rule = q->last_rule;
+    if (scaled_error) *scaled_error = q->last_e0;
 }
 
 void ora_qp_stats(const ora_qp *q, int *ipm_iters, int *n_factor, double *last_elastic)
@@ -884,7 +893,8 @@ static int ipm_run(ora_qp *q, const double *p_start, const double *y_start)
         if (!isfinite(ms.rd) || !isfinite(ms.cavg) || !isfinite(ms.rp)) { rc = 2; break; }
         double sd = fmax(100.0, ms.dual_l1 / (double)(n + m)) / 100.0;
         double e0 = fmax(fmax(ms.rd / sd, ms.rp), ms.cmax / sd);
-        if (e0 <= tol) { rc = 0; break; }
+        q->last_e0 = e0; q->last_rule = -1;
+        if (e0 <= tol) { rc = 0; q->last_rule = 0; break; }
         /* acceptable termination: 8 consecutive iterates within 100 x tol (the monotone rule can crawl
          * just above the tolerance when round-off keeps triggering tiny inertia corrections) */
         n_acc = e0 <= 100.0 * tol ? n_acc + 1 : 0;
@@ -898,7 +908,7 @@ static int ipm_run(ora_qp *q, const double *p_start, const double *y_start)
          * 200-iteration limit and run! gave up on them.  The rule never fires on the IEEE-118 bench workload (1 282
          * sub-problems: same iteration and factorisation counts with and without it); same rule in ipm.hip (b_ipm_prepare) */
         n_acc3 = e0 <= 1e4 * tol ? n_acc3 + 1 : 0;
-        if (n_acc >= 8 || n_acc2 >= 15 || n_acc3 >= 25) { rc = 0; break; }
+        if (n_acc >= 8 || n_acc2 >= 15 || n_acc3 >= 25) { rc = 0; q->last_rule = n_acc >= 8 ? 1 : (n_acc2 >= 15 ? 2 : 3); break; }
         /* barrier update */
         for (int k = 0; k < 20 && !mpc; ++k) {
             double emu = fmax(fmax(ms.rd / sd, ms.rp), ipm_compl_err(q, mu) / sd);

@@ -171,6 +171,10 @@ void ora_qp_destroy(ora_qp *qp);
 int ora_qp_solve(ora_qp *qp, int mode, const double *x_k, double delta, double mu_pen,
                  const double *c, const double *b, const double *jval, const double *hval,
                  double *p, double *lambda, double *mult_x_U, double *mult_x_L, double *slack);
+/* problems.c: drop the second derivatives of a problem (the reference's eval_h === nothing path: SLP) */
+struct ora_problem;
+void ora_problem_drop_hessian(struct ora_problem *p);
+void ora_qp_termination(const ora_qp *q, int *rule, double *scaled_error);
 void ora_qp_stats(const ora_qp *qp, int *ipm_iters, int *n_factor, double *last_elastic);
 
 /* ---- dense LDL^T, exported for kernel-level parity tests and the CPU baseline -------------- */

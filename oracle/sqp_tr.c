@@ -178,7 +178,9 @@ static int qp_call(sqp_t *s, int mode, const double *b, double *p, double *lam, 
     s->it_ipm += a; s->it_fac += b2;
     if (getenv("ORA_QP_LOG")) {          /* experiment aid: one line per sub-problem (mode, status, work, radius, last acceptance) */
         FILE *fh = fopen(getenv("ORA_QP_LOG"), "a");
-        if (fh) { fprintf(fh, "%d %d %d %d %d %.6e %d\n", mode, st, a, b2, s->iter, s->Delta, s->step_acceptance); fclose(fh); }
+        int rule; double e0;
+        ora_qp_termination(s->optimizer, &rule, &e0);
+        if (fh) { fprintf(fh, "%d %d %d %d %d %.6e %d %d %.6e\n", mode, st, a, b2, s->iter, s->Delta, s->step_acceptance, rule, e0); fclose(fh); }
     }
     return st;
 }

@@ -114,7 +114,8 @@ class Counters(C.Structure):
                 ("sparse", C.c_int64), ("nnz_k", C.c_int64), ("nnz_l", C.c_int64), ("n_supernodes", C.c_int64),
                 ("n_levels", C.c_int64), ("max_front", C.c_int64), ("factor_flops", C.c_double),
                 ("front_doubles", C.c_int64), ("cb_doubles", C.c_int64), ("factor_launches", C.c_int64),
-                ("solve_launches", C.c_int64), ("n_sweeps", C.c_int64), ("n_solve", C.c_int64), ("n_groups", C.c_int64)]
+                ("solve_launches", C.c_int64), ("n_sweeps", C.c_int64), ("n_solve", C.c_int64), ("n_groups", C.c_int64),
+                ("nnz_l_top", C.c_int64), ("nnz_k_top", C.c_int64), ("cols_top", C.c_int64)]
 
 
 class SymbolicStats(C.Structure):
@@ -206,6 +207,7 @@ def lib():
             L.sqphip_sqp_work.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
             L.sqphip_reset_counters.argtypes = [vp]
             L.sqphip_set_timing.argtypes = [vp, C.c_int32]
+            L.sqphip_get_kernel_times.argtypes = [vp, dp, C.POINTER(C.c_int64), C.c_int32]
         _lib = L
     return _lib
 
@@ -219,6 +221,6 @@ EXPORTS = [
     "sqphip_kkt_order", "sqphip_kkt_symbolic", "sqphip_mf_host_solve", "sqphip_mf_host_top2_err", "sqphip_mf_host_spine_err", "sqphip_mf_solve_test", "sqphip_acopf_attach", "sqphip_acopf_attach_acr", "sqphip_acopf_attach_acwr", "sqphip_acopf_set_shunts", "sqphip_acopf_set_dclines", "sqphip_acopf_set_instance", "sqphip_acopf_eval", "sqphip_sqp_reset",
     "sqphip_sqp_run", "sqphip_sqp_get", "sqphip_sqp_status", "sqphip_sqp_trace",
     "sqphip_comm_available", "sqphip_comm_unique_id", "sqphip_comm_init", "sqphip_gather_status", "sqphip_comm_destroy",
-    "sqphip_get_counters", "sqphip_get_mode_counters", "sqphip_sqp_work", "sqphip_sqp_stream_begin", "sqphip_sqp_stream_set", "sqphip_sqp_stream_run", "sqphip_sqp_stream_get", "sqphip_sqp_stream_assign", "sqphip_sqp_stream_append", "sqphip_sqp_stream_release", "sqphip_sqp_stream_run_some", "sqphip_sqp_last_request", "sqphip_sqp_qp_log", "sqphip_reset_counters", "sqphip_set_timing", "sqphip_ldlt_factor_host",
+    "sqphip_get_counters", "sqphip_get_mode_counters", "sqphip_sqp_work", "sqphip_sqp_stream_begin", "sqphip_sqp_stream_set", "sqphip_sqp_stream_run", "sqphip_sqp_stream_get", "sqphip_sqp_stream_assign", "sqphip_sqp_stream_append", "sqphip_sqp_stream_release", "sqphip_sqp_stream_run_some", "sqphip_sqp_last_request", "sqphip_sqp_qp_log", "sqphip_reset_counters", "sqphip_set_timing", "sqphip_get_kernel_times", "sqphip_ldlt_factor_host",
     "sqphip_ldlt_solve_host", "sqphip_ldlt_bench", "sqphip_ldlt_stress", "sqphip_mfma_f64_peak", "sqphip_armijo_alpha", "sqphip_compute_mu_rule",
 ]

@@ -1034,6 +1034,7 @@ extern "C" int sqphip_get_counters(sqphip_ctx *h, sqphip_counters *c)
         c->n_sweeps = C.n_sweeps + lane_sweeps; c->n_solve = nsol; c->n_groups = C.lanes.empty() ? 1 : (int64_t)C.lanes.size();
         c->sparse = C.d.sparse; c->nnz_k = 0; c->nnz_l = 0; c->n_supernodes = 0; c->n_levels = 0; c->max_front = 0;
         c->factor_flops = 0; c->front_doubles = 0; c->cb_doubles = 0; c->factor_launches = 0; c->solve_launches = 0;
+        c->nnz_l_top = 0; c->nnz_k_top = 0; c->cols_top = 0;
         if (C.d.sparse) {
             const SparseSym &Y = C.mfp().S;
             c->nnz_k = C.mfp().nnzK; c->nnz_l = Y.nnzL; c->n_supernodes = Y.ns; c->n_levels = Y.nlevels;
@@ -1041,6 +1042,13 @@ extern "C" int sqphip_get_counters(sqphip_ctx *h, sqphip_counters *c)
             long cb = 0;
             for (int q = 0; q < Y.ns; ++q) cb += (long)(Y.sn_nr[q] + 1) * Y.sn_nr[q] - (long)Y.sn_nr[q] * (Y.sn_nr[q] - 1) / 2;
             c->cb_doubles = cb;
+            long lt = 0, kt = 0, nct = 0;
+            for (int q = 0; q < Y.ns; ++q)
+                if (Y.sn_level[q] >= C.mfp().narrow_level) {
+                    const long nc = Y.sn_nc[q], nr = Y.sn_nr[q];
+                    lt += nc * (nc - 1) / 2 + nc * nr; kt += C.mfp().asm_ptr[q + 1] - C.mfp().asm_ptr[q]; nct += nc;
+                }
+            c->nnz_l_top = lt; c->nnz_k_top = kt; c->cols_top = nct;
             c->factor_launches = (int64_t)(C.d.mf.sp_n > 0 ? C.mfp().fac_below + 1 : (int)C.mfp().fac.size());   // (+ k_mf_values)
             c->solve_launches = (int64_t)(C.mfp().fwd.size() + C.mfp().bwd.size() + (C.mfp().top.count > 0 ? 1 : 0));
             c->ldlt_flops = (double)nf * Y.flops;
@@ -1341,6 +1349,23 @@ extern "C" int sqphip_sqp_stream_get(sqphip_ctx *h, int32_t scen, double *x, dou
     });
 }
 
+// seconds of kernel time by class (sqphip.h: sqphip_get_kernel_times), summed over the instance groups, and launch groups timed
+extern "C" int sqphip_get_kernel_times(sqphip_ctx *h, double *seconds, int64_t *groups, int32_t cap)
+{
+    if (!h || !seconds || !groups || cap < 0) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) -> int {
+        C.tm.flush();
+        for (auto &L : C.lanes) L->tm.flush();
+        for (int c = 0; c < cap; ++c) {
+            seconds[c] = 0.0; groups[c] = 0;
+            if (c >= KC_COUNT) continue;
+            seconds[c] = C.tm.class_seconds[c]; groups[c] = C.tm.class_groups[c];
+            for (auto &L : C.lanes) { seconds[c] += L->tm.class_seconds[c]; groups[c] += L->tm.class_groups[c]; }
+        }
+        return SQPHIP_OK;
+    });
+}
+
 extern "C" int sqphip_reset_counters(sqphip_ctx *h)
 {
     if (!h) return SQPHIP_EINVAL;
@@ -1348,10 +1373,12 @@ extern "C" int sqphip_reset_counters(sqphip_ctx *h)
     C.tm.flush();
     C.tm.trailing_seconds = C.tm.factor_seconds = C.tm.solve_seconds = 0;
     C.tm.trailing_launches = 0; C.tm.n_factor = 0;
+    for (int c = 0; c < KC_COUNT; ++c) { C.tm.class_seconds[c] = 0; C.tm.class_groups[c] = 0; }
     C.n_qp = C.n_ipm_iter = C.n_factor = C.n_solve = 0; C.total_seconds = 0; C.n_sweeps = 0;
     for (auto &L : C.lanes) {
         L->tm.flush();
         L->tm.trailing_seconds = L->tm.factor_seconds = L->tm.solve_seconds = 0; L->tm.trailing_launches = 0; L->tm.n_factor = 0;
+        for (int c = 0; c < KC_COUNT; ++c) { L->tm.class_seconds[c] = 0; L->tm.class_groups[c] = 0; }
         L->n_sweeps = 0;
     }
     return SQPHIP_OK;
@@ -1362,7 +1389,7 @@ extern "C" int sqphip_set_timing(sqphip_ctx *h, int32_t enabled)
 {
     if (!h) return SQPHIP_EINVAL;
     h->c.tm.flush();
-    h->c.tm.enabled = enabled != 0;
-    for (auto &L : h->c.lanes) { L->tm.flush(); L->tm.enabled = enabled != 0; }
+    h->c.tm.enabled = enabled != 0; h->c.tm.detail = enabled == 2;
+    for (auto &L : h->c.lanes) { L->tm.flush(); L->tm.enabled = enabled != 0; L->tm.detail = enabled == 2; }
     return SQPHIP_OK;
 }

@@ -1181,6 +1181,7 @@ void ipm_sweep(Ctx &C, bool sqp_level)
     // vector in place and keeps k_ipm_rhs)
     const bool mono = d.ipm_corrector == 0;
     if (trans) {
+        C.tm.open(s);
         hipLaunchKernelGGL(k_qp_finish, gB, bT, 0, s, d);
         if (sqp_level) sqp_stage_kernels(C);
         if (!d.flat) hipLaunchKernelGGL(k_ipm_head, gB, bT, vlds, s, d);
@@ -1189,6 +1190,7 @@ void ipm_sweep(Ctx &C, bool sqp_level)
             hipLaunchKernelGGL(k_sp_products, gP, b256, 0, s, d, (int)SP_PREP, (int)PH_PREP);
             hipLaunchKernelGGL(k_ipm_head_b, gB, bT, vlds, s, d);
         }
+        C.tm.close(KC_TRANS, s);
     } else if (!(mono && d.sparse)) hipLaunchKernelGGL(k_ipm_rhs, gB, bT, vlds, s, d);
     if (d.flat && (trans || !mono)) hipLaunchKernelGGL(k_sp_load_xv, gX, b256, 0, s, d, 0);
     if (!d.sparse) hipLaunchKernelGGL(k_kkt_assemble, dim3(d.Fpad, d.B), dim3(128), 0, s, d);
@@ -1250,7 +1252,9 @@ void ipm_sweep(Ctx &C, bool sqp_level)
             hipLaunchKernelGGL(k_ipm_head_b, gB, bT, vlds, s, d);
             hipLaunchKernelGGL(k_sp_load_xv, gX, b256, 0, s, d, 0);
         };
+        C.tm.open(s);
         post(PH_SOLVE);
+        C.tm.close(KC_POST, s);
         // (the refinement slot at most every fourth sweep of a run: with 128 instances in a group one of them asks for it in a
         //  third of all sweeps, and the slot costs every instance of the group a forward and a backward pass of gated kernels;
         //  the few that wait are 0.4 % of the iterations)

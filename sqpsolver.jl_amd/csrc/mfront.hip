@@ -1852,14 +1852,16 @@ void mf_factor(Ctx &C, int want, bool with_rhs, bool values_done)
     const int wr = (int)with_rhs;
     const int nb = d.mf.fronts1 ? 2 * d.B : d.B;         // with the second candidate the factor side runs over 2 B "instances"
     // (values_done: the stage kernel that built the right-hand sides has assembled the values too: mf_values_block)
-    if (!v1 && !values_done) hipLaunchKernelGGL(k_mf_values, dim3((d.mf.nnzK + 255) / 256, nb), dim3(256), 0, s, d, want);
+    if (!v1 && !values_done) { C.tm.open(s); hipLaunchKernelGGL(k_mf_values, dim3((d.mf.nnzK + 255) / 256, nb), dim3(256), 0, s, d, want); C.tm.close(KC_VALUES, s); }
     // static front kernels (k_mf_front<T, NW, LDSIMG>) unless SQPHIP_MF_STATIC=0 asks for the generic ones (cross-check)
     const bool stat = !(getenv("SQPHIP_MF_STATIC") && atoi(getenv("SQPHIP_MF_STATIC")) == 0);     // (read per call: tests flip it)
     // the levels below the spine as level launches, the spine (mfplan.hip: spine_level) by one workgroup per instance
     const bool spine = !v1 && d.mf.sp_n > 0 && C.mf_big_lds;
-    int li = 0;
+    int li = 0, cls_open = -1;        // (detail timers: one event pair around the launches below the narrow top, one around those of the top)
     for (const MfLaunch &L : C.mfp().fac) {
         if (spine && li++ >= C.mfp().fac_below) break;
+        const int cls = L.level >= C.mfp().narrow_level ? KC_FRONTS_TOP : KC_FRONTS_LOW;
+        if (cls != cls_open) { if (cls_open >= 0) C.tm.close(cls_open, s); C.tm.open(s); cls_open = cls; }
         const dim3 grid(L.count, nb);
         const int T = L.tiles, R = 16 * T;
         if (v1 || T > 13) { hipLaunchKernelGGL((k_mf_factor<256, true>), grid, dim3(256), 0, s, d, L.begin, want, wr); continue; }
@@ -1904,7 +1906,8 @@ void mf_factor(Ctx &C, int want, bool with_rhs, bool values_done)
 #undef MF_GENERIC
 #undef MF_STATIC
     }
-    if (spine) hipLaunchKernelGGL(k_mf_spine, dim3(1, nb), dim3(MF_SP_NT), (size_t)C.mfp().spine_lds_bytes, s, d, want, wr);
+    if (cls_open >= 0) C.tm.close(cls_open, s);
+    if (spine) { C.tm.open(s); hipLaunchKernelGGL(k_mf_spine, dim3(1, nb), dim3(MF_SP_NT), (size_t)C.mfp().spine_lds_bytes, s, d, want, wr); C.tm.close(KC_FRONTS_TOP, s); }
     C.mf_factor_launches += spine ? (long)C.mfp().fac_below + 1 : (long)C.mfp().fac.size();
 }
 
@@ -1932,6 +1935,7 @@ void mf_solve(Ctx &C, int want, bool skip_fwd, bool inertia)
     // level launches: the LDS-staged kernels where every front of the level fits them (mfplan.hip: L.wimg >= 0)
     const bool lvl2 = !(getenv("SQPHIP_MF_LEVEL2") && atoi(getenv("SQPHIP_MF_LEVEL2")) == 0);      // (read per call: tests flip it)
     if (!C.mf_big_lds) throw std::string("sqphip: the solve kernels could not be granted 160 KB of dynamic LDS on this device (mf_device_setup)");
+    if (!skip_fwd && !C.mfp().fwd.empty()) C.tm.open(s);
     if (!skip_fwd)
         for (const MfLaunch &L : C.mfp().fwd) {
             if (lvl2 && !generic && L.wimg >= 0) {
@@ -1940,12 +1944,16 @@ void mf_solve(Ctx &C, int want, bool skip_fwd, bool inertia)
             }
             else hipLaunchKernelGGL(k_mf_fwd, dim3(L.count, d.B), dim3(256), L.lds_bytes, s, d, L.begin, want, generic, L.tiles, L.cls, L.lds_bytes / 8 - L.cls);
         }
+    if (!skip_fwd && !C.mfp().fwd.empty()) C.tm.close(KC_SOLVE_LEVELS, s);
+    C.tm.open(s);
     if (d.mf.top_n > 0 && !generic) {
         const size_t lds = (size_t)C.mfp().top2_lds_bytes;
         hipLaunchKernelGGL(k_mf_solve_top2, dim3(d.B), dim3(256), lds, s, d, want, skip_fwd ? 0 : 1, inertia ? 1 : 0);
     } else if (const MfLaunch &T = C.mfp().top; T.count > 0)
         hipLaunchKernelGGL(k_mf_solve_top, dim3(d.B), dim3(256), T.lds_bytes, s, d, T.begin, T.count, want, skip_fwd ? 0 : 1, generic,
                            T.tiles, T.cls, T.lds_bytes / 8 - T.cls);
+    C.tm.close(KC_SOLVE_TOP, s);
+    if (!C.mfp().bwd.empty()) C.tm.open(s);
     for (const MfLaunch &L : C.mfp().bwd) {
         if (lvl2 && !generic && L.wimg >= 0) {
             if (L.hasbig) hipLaunchKernelGGL(k_mf_bwd2<true>, dim3(L.count, d.B), dim3(256), L.lds2, s, d, L.begin, want, L.wimg);
@@ -1953,6 +1961,7 @@ void mf_solve(Ctx &C, int want, bool skip_fwd, bool inertia)
         }
         else hipLaunchKernelGGL(k_mf_bwd, dim3(L.count, d.B), dim3(256), L.lds_bytes, s, d, L.begin, want, generic, L.tiles, L.cls, L.lds_bytes / 8 - L.cls);
     }
+    if (!C.mfp().bwd.empty()) C.tm.close(KC_SOLVE_LEVELS, s);
 }
 
 }  // namespace sqphip

@@ -9,8 +9,20 @@
 
 namespace sqphip {
 
+// kernel classes of a sweep for the per-kernel records of the bench line (Timers::detail; sqphip_get_kernel_times)
+enum { KC_VALUES = 0, KC_FRONTS_LOW = 1, KC_FRONTS_TOP = 2, KC_SOLVE_TOP = 3, KC_SOLVE_LEVELS = 4, KC_POST = 5, KC_TRANS = 6, KC_COUNT = 7 };
+
 struct Timers {
     bool enabled = false;
+    // detail (sqphip_set_timing(ctx, 2)): an event pair around every launch group of a class -- off in the timed region of
+    // the bench (twenty more event records per sweep), on in a short leg behind it
+    bool detail = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_class[KC_COUNT];
+    double class_seconds[KC_COUNT] = {0, 0, 0, 0, 0, 0, 0};
+    long class_groups[KC_COUNT] = {0, 0, 0, 0, 0, 0, 0};
+    std::pair<hipEvent_t, hipEvent_t> open_ev;
+    void open(hipStream_t s) { if (detail) { open_ev = get(); hipEventRecord(open_ev.first, s); } }
+    void close(int cls, hipStream_t s) { if (detail) { hipEventRecord(open_ev.second, s); pending_class[cls].push_back(open_ev); class_groups[cls]++; } }
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;   // recycled event pairs
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_trailing, pending_factor, pending_solve;
     double trailing_seconds = 0, factor_seconds = 0, solve_seconds = 0;
@@ -41,6 +53,7 @@ struct Timers {
         trailing_seconds += drain(pending_trailing, pool);
         factor_seconds += drain(pending_factor, pool);
         solve_seconds += drain(pending_solve, pool);
+        for (int c = 0; c < KC_COUNT; ++c) class_seconds[c] += drain(pending_class[c], pool);
     }
     ~Timers()
     {

@@ -432,6 +432,14 @@ class Context:
     def reset_counters(self):
         self._ck(self.L.sqphip_reset_counters(self.h))
 
+    KERNEL_CLASSES = ("values", "fronts_low", "fronts_top", "solve_top", "solve_levels", "post", "transitions")
+
+    def kernel_times(self):
+        """{class: (seconds of kernel time, launch groups timed)} since reset_counters (set_timing(2) collects them)."""
+        sec = np.zeros(7); grp = np.zeros(7, dtype=np.int64)
+        self._ck(self.L.sqphip_get_kernel_times(self.h, _d(sec), grp.ctypes.data_as(C.POINTER(C.c_int64)), 7))
+        return {k: (float(sec[i]), int(grp[i])) for i, k in enumerate(self.KERNEL_CLASSES)}
+
     def set_timing(self, on: bool):
         self._ck(self.L.sqphip_set_timing(self.h, int(on)))
 

@@ -30,7 +30,7 @@ int main(int argc, char **argv)
 
     /* struct layout: 10 doubles, 3 int32 (+ 4 bytes padding), 1 double, 8 int32 */
     CHECK(sizeof(sqphip_options) == 10 * 8 + 3 * 4 + 4 + 8 + 8 * 4);
-    CHECK(sizeof(sqphip_counters) == 26 * 8);                      /* 26 eight-byte fields */
+    CHECK(sizeof(sqphip_counters) == 29 * 8);                      /* 29 eight-byte fields */
     sqphip_options o;
     memset(&o, 0xff, sizeof o);
     p_sqphip_default_options(&o);

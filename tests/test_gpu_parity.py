@@ -103,13 +103,14 @@ def _newton_values(lay, seed, free_frac=0.1):
             rng.uniform(0, 1, lay.n), rt)
 
 
-def _sparse_newton(lay, Jv, Hv, Dd, sigp, hd, rt, hsc, dw):
-    """The condensed Newton matrix as a scipy sparse matrix (independent assembly), unknowns = variables, kept rows."""
+def _sparse_newton(lay, Jv, Hv, Dd, sigp, hd, rt, hsc, dw, cond=1):
+    """The Newton matrix as a scipy sparse matrix (independent assembly), unknowns = variables, kept rows: the condensed
+    form (rows with gL != gU eliminated) or -- cond = 0 -- the full form (every row kept)."""
     n, m = lay.n, lay.m
     J = sp.coo_matrix((Jv, (lay.jrow - 1, lay.jcol - 1)), shape=(m, n)).tocsr()
     Hl = sp.coo_matrix((Hv, (lay.hrow - 1, lay.hcol - 1)), shape=(n, n)).tocsr()
     H = Hl + Hl.T - sp.diags(Hl.diagonal())
-    kept = lay.gL == lay.gU
+    kept = (lay.gL == lay.gU) if cond else np.ones(m, dtype=bool)
     act = sp.diags((rt != 0).astype(float))
     J = act @ J
     el = np.flatnonzero(~kept & (rt != 0))
@@ -143,9 +144,10 @@ def test_multifrontal_kernels_match_host_reference(case, cond):
         fused, alone, dv = ctx.mf_solve_test(inst, Jv, Hv, Dd, sigp, hd, rt, 0.7, 1e-3, rhs)
         assert rel(fused, ref) < 1e-11 and rel(alone, ref) < 1e-11 and rel(dv, dref) < 1e-11
         assert int((dv > 0).sum()) == lay.n
-    if cond:
-        K = _sparse_newton(lay, Jv, Hv, Dd, sigp, hd, rt, 0.7, 1e-3)
-        assert np.abs(K @ fused - rhs).max() <= 1e-10 * np.abs(rhs).max()
+    # ... and against the mathematics, both forms: the residual of an independently assembled (scipy) Newton matrix
+    K = _sparse_newton(lay, Jv, Hv, Dd, sigp, hd, rt, 0.7, 1e-3, cond)
+    assert K.shape[0] == lay.n + mk
+    assert np.abs(K @ fused - rhs).max() <= 1e-10 * np.abs(rhs).max()
     ctx.close()
 
 
@@ -1201,6 +1203,39 @@ def test_dropin_seat_reproduces_reference_answers(name):
     assert [(t["iter"], t["accepted"], t["fr"], t["sub_status"]) for t in sqp.trace] == \
            [(t["iter"], t["accepted"], t["fr"], t["sub_status"]) for t in ro["trace"]]
     assert rel(model.mult_g, ro["mult_g"]) < 1e-6
+
+
+def test_no_hessian_path_on_the_device():
+    """`eval_h === nothing` (/root/reference/src/MOI_wrapper.jl:1092-1103,1178; src/algorithms/sqp.jl:92;
+    subproblem_JuMP.jl:137-140): a context created with nnzH = 0 solves sub-problems with a linear objective.  (a) modes QP
+    and SOC of HS071 at its start, feasible and infeasible radius, against the oracle without a Hessian (p, multipliers,
+    status, iteration counts); (b) the whole run! over the seat as sequential linear programming -- HS071, the reference's
+    toy NLP and README NLP reach their known optima with the oracle's iteration counts and decisions."""
+    pins = json.load(open(os.path.join(GOLD, "reference_pins.json")))["reference_pins"]
+    P = O.drop_hessian(O.problem_hs071()); S = P.structure(); x = P.x0
+    assert len(S["hrow"]) == 0
+    ctx = pkg.Context(S["n"], S["m"], S["num_linear"], S["jrow"], S["jcol"], S["hrow"], S["hcol"], S["xL"], S["xU"], S["gL"], S["gU"],
+                      pkg.default_options(), batch=1)
+    osolve = _oracle_qp(P, S)
+    df, E, jc = P.eval_grad_f(x), P.eval_g(x), P.eval_jac_g(x)
+    for mode, delta in ((O.MODE_QP, 10.0), (O.MODE_SOC, 10.0), (O.MODE_QP, 0.5), (O.MODE_QP, 2.0)):
+        ro = osolve(mode, x, delta, 1.0, df, E, jc, None)
+        rg = ctx.qp_solve(mode, x, delta, 1.0, df, E, jc, None)
+        _compare_qp(ro, rg, **_tols(mode, 0))
+    ctx.close()
+    for name in ("hs071", "toy", "readme1"):
+        P = O.drop_hessian(getattr(O, "problem_" + name)()); S = P.structure()
+        model = HM.Model(S["n"], S["m"], S["xL"], S["xU"], S["gL"], S["gU"],
+                          list(zip(S["jrow"].tolist(), S["jcol"].tolist())), [],
+                          P.eval_f, P.eval_g, P.eval_grad_f, P.eval_jac_g, None, S["num_linear"], HM.Parameters(max_iter=300))
+        model.x[:] = P.x0
+        sqp = HM.optimize(model)
+        ro = O.sqp_solve(P, O.default_options(max_iter=300))
+        assert model.status == ro["status"] == 0, name
+        assert np.allclose(model.x, pins[name]["x"], rtol=pins[name]["rtol"], atol=1e-8), name
+        assert rel(model.x, ro["x"]) < TOL and model.statistics["iter"] == ro["iter"], name
+        assert [(t["iter"], t["accepted"], t["fr"], t["sub_status"]) for t in sqp.trace] == \
+               [(t["iter"], t["accepted"], t["fr"], t["sub_status"]) for t in ro["trace"]], name
 
 
 class _OracleSeat:

@@ -20,7 +20,7 @@ import pytest
 import sqpsolver_jl_amd as pkg
 from sqpsolver_jl_amd.acopf_synth import acopf_synth, acopf_layout, acr_layout, contingency, synth_case, CASES
 from oracle import oracle as O
-from test_gpu_parity import _ipm_counts_close, _oracle_qp, _run_batch, _same_decisions, host_threads, rel, TOL
+from test_gpu_parity import _ipm_counts_close, _oracle_qp, _run_batch, _same_decisions, host_threads, rel, TOL, GOLD
 
 pytestmark = pytest.mark.gpu
 
@@ -58,6 +58,7 @@ def test_subproblems_of_the_bench_run_replay_through_both_seats():
     nlog = {b: 0 for b in ids}
     n_sub = n_equal_counts = 0
     worst_fr = 0.0
+    worst_mult = 0.0
     modes = set()
     for _ in range(iters):
         ctx.sqp_run(1)
@@ -94,12 +95,16 @@ def test_subproblems_of_the_bench_run_replay_through_both_seats():
                 # (a bound multiplier is mu / gap of the last iterate).  Data: two collections of 200 sub-problems along
                 # two different trajectories of this run (the rounding of the solve kernels changed between them): row
                 # multipliers at most 1.1e-8 and 9.0e-8, reduced costs at most 1.0e-8 and 2.1e-7 of the largest one
-                assert rel(rg["lam"], ro["lam"]) < 1e-6 and rel(rg["mult_x_L"] - rg["mult_x_U"], ro["mult_x_L"] - ro["mult_x_U"]) < 1e-6
+                # (round 4: the monotone barrier rule is the default -- it ends on well-centred iterates -- and the bound is the
+                #  5e-7 the verdict asked for; the worst case of this run is printed below)
+                e_lam, e_rc = rel(rg["lam"], ro["lam"]), rel(rg["mult_x_L"] - rg["mult_x_U"], ro["mult_x_L"] - ro["mult_x_U"])
+                worst_mult = max(worst_mult, e_lam, e_rc)
+                assert e_lam < 5e-7 and e_rc < 5e-7, (b, rq["mode"], e_lam, e_rc)
     assert n_sub >= 8 * iters - 8 and {O.MODE_QP, O.MODE_SOC, O.MODE_FR} <= modes
     # equal interior-point iteration AND factorisation counts on all but a few sub-problems (degenerate LPs, one
     # infeasible QP in the collection run): two implementations with different elimination orders
     assert n_equal_counts >= 0.95 * n_sub, (n_equal_counts, n_sub)
-    print(f"replay: {n_sub} sub-problems, {n_equal_counts} with equal counts, worst restoration-LP count gap {worst_fr:.2f}")
+    print(f"replay: {n_sub} sub-problems, {n_equal_counts} with equal counts, worst restoration-LP count gap {worst_fr:.2f}, worst multiplier error {worst_mult:.1e}")
     for c in seats.values():
         c.close()
     ctx.close()
@@ -270,3 +275,49 @@ def test_queue_shared_between_two_ranks_gives_the_single_rank_results(tmp_path):
     a, b = json.load(open(one)), json.load(open(two))
     assert a == b and all(i > 0 for i in a["iter"])
     assert json.loads(r1.stdout.decode().strip().splitlines()[-1])["converged"] >= 12
+
+
+def test_case9241_scenario_matches_the_oracle_fixture(capsys):
+    """BASELINE.json configs[4] as bench.py runs it -- the geographic 9241-bus network, line-outage scenario 1 -- against the
+    oracle's fixture tests/golden/geo9241_s1.npz (tests/golden/make_golden_9241.py; the oracle needs ~1.5 minutes per
+    sub-problem at this size, so its outputs are committed): (a) the bench's configuration, reference Hessian sign, the
+    first seven outer iterations: every decision of the trace and every sub-problem's status exact, radii at 1e-7,
+    interior-point counts within two (or 20 %), the point at the tolerance of a truncated trajectory; (b) the textbook sign
+    to convergence: status, outer iterations and decisions exact, objective and point at 1e-8.  The sub-problems this shape
+    ends by the third acceptable-termination rule (25 iterates within 1e4 x ipm_tol) are reported with the scaled error
+    they were accepted at -- on both sides."""
+    path = os.path.join(GOLD, "geo9241_s1.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/geo9241_s1.npz has not been generated (tests/golden/make_golden_9241.py)")
+    G = np.load(path)
+    base = synth_case("case9241")
+    seed = CASES["case9241"][3]
+    net = contingency(base, 1, seed); lay = acopf_layout(net)
+    report = []
+    for tag, kw in (("quirks1_7it", dict(literal_quirks=1, max_iter=7)), ("quirks0_conv", dict(literal_quirks=0, max_iter=60))):
+        ctx = _run_batch([net], [lay], dict(tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, **kw))
+        rg = ctx.sqp_get(0)
+        tr = ctx.sqp_trace(0)
+        log, term = ctx.sqp_qp_log(0), ctx.sqp_qp_log_term(0)
+        ctx.close()
+        gt, gq = G[f"{tag}_trace"], G[f"{tag}_qps"]
+        assert (rg["status"], rg["iter"]) == (int(G[f"{tag}_status"]), int(G[f"{tag}_iter"])), tag
+        assert [(t["iter"], t["accepted"], t["fr"], t["sub_status"]) for t in tr] == [tuple(int(v) for v in row[:4]) for row in gt], tag
+        assert np.allclose([t["delta"] for t in tr], gt[:, 4], rtol=1e-7), tag
+        # per sub-problem: mode and status exact, interior-point counts close, the termination rule and its error reported
+        assert len(log) == len(gq), (tag, len(log), len(gq))
+        for k, (row, (err, rule)) in enumerate(zip(log, term)):
+            mode, status, its, fac = row
+            assert (mode, status) == (int(gq[k, 0]), int(gq[k, 1])), (tag, k)
+            assert abs(its - gq[k, 2]) <= max(2, 0.2 * gq[k, 2]), (tag, k, its, gq[k, 2])
+            if rule == 3 or int(gq[k, 6]) == 3:
+                report.append(f"{tag} sub-problem {k} (mode {mode}): device rule {rule} at scaled error {err:.2e}, oracle rule {int(gq[k, 6])} at {gq[k, 7]:.2e}")
+        if tag == "quirks0_conv":
+            assert rg["status"] == 0
+            assert rel(rg["x"], G[f"{tag}_x"]) < TOL and abs(rg["obj_val"] - float(G[f"{tag}_obj_val"])) <= TOL * abs(float(G[f"{tag}_obj_val"])), tag
+        else:
+            assert rel(rg["x"], G[f"{tag}_x"]) < 1e-5, (tag, rel(rg["x"], G[f"{tag}_x"]))
+    with capsys.disabled():
+        print("\n[9241 fixture] sub-problems accepted by the third acceptable-termination rule (1e4 x ipm_tol = 1e-5):")
+        for ln in report or ["  none"]:
+            print("  " + ln)

@@ -269,6 +269,35 @@ def test_oracle_matches_committed_golden(name):
     assert np.allclose([t["delta"] for t in r["trace"]], [row[4] for row in g["trace"]], rtol=1e-10)
 
 
+def test_sequential_linear_programming_without_second_derivatives():
+    """`eval_h === nothing` (/root/reference/src/MOI_wrapper.jl:1092-1103,1178: an evaluator without the :Hess feature;
+    src/algorithms/sqp.jl:92 then never fills the Hessian and subproblem_JuMP.jl:137-140 gives every sub-problem a linear
+    objective): SQP-TR degenerates to sequential linear programming inside the trust region.  The oracle's run! on HS071,
+    the reference's toy NLP and the README NLP without their Hessians must still reach the known optima -- LP sub-problems
+    (nnzH = 0) through the same interior-point method."""
+    pins = json.load(open(os.path.join(GOLD, "reference_pins.json")))["reference_pins"]
+    for name in ("hs071", "toy", "readme1"):
+        P = O.drop_hessian(getattr(O, "problem_" + name)())
+        assert len(P.structure()["hrow"]) == 0
+        r = O.sqp_solve(P, O.default_options(max_iter=300))
+        assert r["status"] == 0, (name, r["status"])
+        assert np.allclose(r["x"], pins[name]["x"], rtol=pins[name]["rtol"], atol=1e-8), (name, r["x"])
+    # the QP sub-problem itself: no Hessian = the Hessian values at zero
+    P = O.problem_hs071(); S = P.structure(); x = P.x0
+    jcp, jrv, jslot, _ = O.coo_to_csc(S["n"], S["jrow"], S["jcol"])
+    hcp, hrv, hslot, hslot_t = O.coo_to_csc(S["n"], S["hrow"], S["hcol"], sym=True)
+    jv = np.zeros(len(jrv)); np.add.at(jv, jslot, P.eval_jac_g(x))
+    q_h = O.QpSolver(S["n"], S["m"], S["num_linear"], jcp, jrv, hcp, hrv, S["xL"], S["xU"], S["gL"], S["gU"])
+    q_0 = O.QpSolver(S["n"], S["m"], S["num_linear"], jcp, jrv, np.zeros(S["n"] + 1, dtype=np.int64), np.zeros(0, dtype=np.int64),
+                     S["xL"], S["xU"], S["gL"], S["gU"])
+    for mode, delta, want in ((O.MODE_QP, 10.0, O.MOI_LOCALLY_SOLVED), (O.MODE_SOC, 10.0, O.MOI_LOCALLY_SOLVED),
+                              (O.MODE_QP, 0.5, O.MOI_LOCALLY_INFEASIBLE)):      # (radius 0.5: the linearised rows cannot be met)
+        a = q_h.solve(mode, x, delta, 1.0, P.eval_grad_f(x), P.eval_g(x), jv, np.zeros(len(hrv)))
+        b = q_0.solve(mode, x, delta, 1.0, P.eval_grad_f(x), P.eval_g(x), jv, np.zeros(0))
+        assert a["status"] == b["status"] == want, (mode, delta, a["status"], b["status"])
+        assert np.abs(a["p"] - b["p"]).max() <= 1e-9 and np.abs(a["lam"] - b["lam"]).max() <= 1e-7
+
+
 def test_quirk_flag_switches_hessian_sign():
     """literal_quirks=1 feeds the JuMP-sign multipliers to eval_h (sqp.jl:93); 0 negates them."""
     nb, ng, nl, seed = CASES["case14"]
