@@ -272,6 +272,16 @@ int sqphip_acopf_set_instance(sqphip_ctx *ctx, int32_t inst, const double *ohm, 
 int sqphip_acopf_eval(sqphip_ctx *ctx, int32_t inst, const double *x, double sigma,
                       const double *lambda, double *f, double *grad, double *g, double *jval,
                       double *hval);
+/* A synthetic NLP with a DENSE Lagrangian Hessian for the batched run (bench.py --workload dense; no reference counterpart:
+ * the reference's examples are ACOPF models, whose Hessians are sparse):
+ *     min  1/2 x'Qx + c'x + kappa / 4 sum_i x_i^4    s.t.  A x = b,  xL <= x <= xU
+ * Q [n][n] symmetric and A [m][n] row-major are shared by the batch; an instance carries c [n], its start x0 and -- through
+ * sqphip_set_bounds -- xL, xU and gL = gU = b.  The context must have been created with the matching structure
+ * (sqpsolver.jl_amd/dense_synth.py): Jacobian COO = A row-major (m n entries), Hessian COO = lower triangle of Q
+ * column-major (n (n + 1) / 2 entries), num_linear = m.  With options.kkt_mode = 1 every sub-problem factorises a dense
+ * Newton matrix of order n + m on the MFMA path (ldlt.hip). */
+int sqphip_dense_attach(sqphip_ctx *ctx, const double *Q, const double *A, double kappa);
+int sqphip_dense_set_instance(sqphip_ctx *ctx, int32_t inst, const double *c, const double *x0);
 /* Run SQP-TR for every instance until each has terminated or done `max_outer` more outer
  * iterations (0 = no cap beyond options.max_iter).  Restartable: state stays on the device. */
 int sqphip_sqp_reset(sqphip_ctx *ctx);

@@ -109,6 +109,8 @@ def lib():
                              dp, dp, dp, dp, C.c_int, ip, dp, dp, C.c_int, dp]
         L.ora_problem_acopf_acwr.restype = C.c_void_p
         L.ora_problem_acopf_acwr.argtypes = L.ora_problem_acopf.argtypes + [C.c_int, ip, ip, ip, dp, dp, dp]
+        L.ora_problem_dense.restype = C.c_void_p
+        L.ora_problem_dense.argtypes = [C.c_int64, C.c_int64, dp, dp, dp, C.c_double, C.c_int64, lp, lp, C.c_int64, lp, lp, dp, dp, dp, dp, dp]
         L.ora_problem_nlp.restype = C.POINTER(Nlp)
         L.ora_problem_nlp.argtypes = [C.c_void_p]
         L.ora_problem_x0.restype = dp
@@ -271,6 +273,18 @@ def problem_acopf(net, lay):
                                          _d(f64(lay.bp_tmin)), _d(f64(lay.bp_tmax)))
     else:
         h = (lib().ora_problem_acopf_acr if form == "acr" else lib().ora_problem_acopf)(*common)
+    return Problem(h, x0=lay.x0)
+
+
+def problem_dense(nlp, lay):
+    """The synthetic dense-Hessian NLP of sqpsolver.jl_amd/dense_synth.py (CPU twin of the device evaluator dense_eval)."""
+    jr, jc, hr, hc = (np.ascontiguousarray(a, dtype=np.int64) for a in (lay.jrow, lay.jcol, lay.hrow, lay.hcol))
+    args = [f64(a) for a in (nlp.Q.ravel(), nlp.A.ravel(), nlp.c, lay.xL, lay.xU, lay.gL, lay.gU, lay.x0)]
+    Q, A, c, xL, xU, gL, gU, x0 = args
+    h = lib().ora_problem_dense(nlp.n, nlp.m, _d(Q), _d(A), _d(c), float(nlp.kappa), len(jr), _l(jr), _l(jc), len(hr), _l(hr), _l(hc),
+                                _d(xL), _d(xU), _d(gL), _d(gU), _d(x0))
+    if not h:
+        raise ValueError("ora_problem_dense: structure does not match the dense layout")
     return Problem(h, x0=lay.x0)
 
 

@@ -22,6 +22,8 @@ struct ora_problem {
     double *ohm, *c2, *c1, *bal_coef;      /* ohm[nl][12]: (A, Bc, Bs) of p_f, q_f, p_t, q_t per branch */
     /* W-space form (acwr): bus pairs i < j, pair and orientation of every branch, tan of the pairs' angle limits, shunts per bus */
     int nbp; int32_t *bp_i, *bp_j, *br_bp; double *br_sig, *bp_tmin, *bp_tmax, *gsb, *bsb;
+    /* synthetic dense-Hessian NLP (ora_problem_dense): Q [n][n] symmetric, A [m][n] row-major, linear cost, quartic weight */
+    double *dnQ, *dnA, *dnc, dn_kappa;
 };
 
 static int64_t *i64dup(const int64_t *s, int64_t k)
@@ -59,7 +61,7 @@ void ora_problem_destroy(ora_problem *P)
     void *ptrs[] = { P->x0, P->jrow, P->jcol, P->hrow, P->hcol, P->xL, P->xU, P->gL, P->gU,
         P->f_bus, P->t_bus, P->gen_bus, P->bal_ptr, P->bal_colP, P->bal_colQ, P->ohm,
         P->c2, P->c1, P->bal_coef, P->sh_bus, P->sh_gs, P->sh_bs, P->dc_loss1,
-        P->bp_i, P->bp_j, P->br_bp, P->br_sig, P->bp_tmin, P->bp_tmax, P->gsb, P->bsb };
+        P->bp_i, P->bp_j, P->br_bp, P->br_sig, P->bp_tmin, P->bp_tmax, P->gsb, P->bsb, P->dnQ, P->dnA, P->dnc };
     for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) free(ptrs[i]);
     free(P);
 }
@@ -589,5 +591,71 @@ ora_problem *ora_problem_acopf_acwr(int nb, int ng, int nl, const int32_t *f_bus
     P->c2 = ddup(c2, ng); P->c1 = ddup(c1, ng);
     P->nlp.eval_f = wr_f; P->nlp.eval_grad_f = wr_df; P->nlp.eval_g = wr_g;
     P->nlp.eval_jac_g = wr_jac; P->nlp.eval_h = wr_h;
+    return P;
+}
+
+
+/* ------------------------------------------------------------------ synthetic dense-Hessian NLP
+ * The CPU twin of dense_eval (sqpsolver.jl_amd/csrc/acopf_dev.hpp), bench.py --workload dense:
+ *     min 1/2 x'Qx + c'x + kappa/4 sum x_i^4   s.t.  A x = b,  xL <= x <= xU
+ * No reference counterpart (the reference's examples are ACOPF models); the callbacks have the shape of
+ * SqpSolver.Model (src/model.jl:3-35).  Jacobian COO = A row-major, Hessian COO = lower triangle of Q column-major. */
+static double dn_f(void *u, const double *x)
+{
+    const ora_problem *P = (const ora_problem *)u;
+    const int64_t n = P->nlp.n;
+    double f = 0.0;
+    for (int64_t j = 0; j < n; ++j) {
+        double acc = 0.0;
+        for (int64_t i = 0; i < n; ++i) acc += P->dnQ[i * n + j] * x[i];
+        const double x2 = x[j] * x[j];
+        f += 0.5 * x[j] * acc + P->dnc[j] * x[j] + 0.25 * P->dn_kappa * x2 * x2;
+    }
+    return f;
+}
+static void dn_df(void *u, const double *x, double *g)
+{
+    const ora_problem *P = (const ora_problem *)u;
+    const int64_t n = P->nlp.n;
+    for (int64_t j = 0; j < n; ++j) {
+        double acc = 0.0;
+        for (int64_t i = 0; i < n; ++i) acc += P->dnQ[i * n + j] * x[i];
+        g[j] = acc + P->dnc[j] + P->dn_kappa * (x[j] * x[j]) * x[j];
+    }
+}
+static void dn_g(void *u, const double *x, double *g)
+{
+    const ora_problem *P = (const ora_problem *)u;
+    const int64_t n = P->nlp.n, m = P->nlp.m;
+    for (int64_t i = 0; i < m; ++i) {
+        double acc = 0.0;
+        for (int64_t j = 0; j < n; ++j) acc += P->dnA[i * n + j] * x[j];
+        g[i] = acc;
+    }
+}
+static void dn_jac(void *u, const double *x, double *v)
+{
+    const ora_problem *P = (const ora_problem *)u; (void)x;
+    memcpy(v, P->dnA, sizeof(double) * (size_t)(P->nlp.n * P->nlp.m));
+}
+static void dn_h(void *u, const double *x, double s, const double *l, double *v)
+{
+    const ora_problem *P = (const ora_problem *)u; (void)l;
+    const int64_t n = P->nlp.n;
+    for (int64_t j = 0; j < n; ++j) {
+        const int64_t off = j * n - j * (j - 1) / 2;
+        for (int64_t i = j; i < n; ++i)
+            v[off + i - j] = s * (P->dnQ[j * n + i] + (i == j ? 3.0 * P->dn_kappa * x[j] * x[j] : 0.0));
+    }
+}
+ora_problem *ora_problem_dense(int64_t n, int64_t m, const double *Q, const double *A, const double *c, double kappa,
+                               int64_t nnzj, const int64_t *jrow, const int64_t *jcol, int64_t nnzh, const int64_t *hrow,
+                               const int64_t *hcol, const double *xL, const double *xU, const double *gL, const double *gU,
+                               const double *x0)
+{
+    if (nnzj != n * m || nnzh != n * (n + 1) / 2) return NULL;
+    ora_problem *P = mk(n, m, m, nnzj, jrow, jcol, nnzh, hrow, hcol, xL, xU, gL, gU, x0);
+    P->dnQ = ddup(Q, n * n); P->dnA = ddup(A, m * n); P->dnc = ddup(c, n); P->dn_kappa = kappa;
+    P->nlp.eval_f = dn_f; P->nlp.eval_grad_f = dn_df; P->nlp.eval_g = dn_g; P->nlp.eval_jac_g = dn_jac; P->nlp.eval_h = dn_h;
     return P;
 }

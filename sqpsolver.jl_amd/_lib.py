@@ -173,6 +173,8 @@ def lib():
             L.sqphip_acopf_attach_acwr.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, ip, ip, ip, ip, ip, ip, dp, C.c_int32,
                                                    C.c_int32, ip, ip, ip, dp, dp, dp]
             L.sqphip_acopf_set_instance.argtypes = [vp, C.c_int32, dp, dp, dp, dp]
+            L.sqphip_dense_attach.argtypes = [vp, dp, dp, C.c_double]
+            L.sqphip_dense_set_instance.argtypes = [vp, C.c_int32, dp, dp]
             L.sqphip_acopf_set_shunts.argtypes = [vp, C.c_int32, ip, dp, dp]
             L.sqphip_acopf_set_dclines.argtypes = [vp, C.c_int32, dp]
             L.sqphip_kkt_order.argtypes = [C.c_int64, C.c_int64, C.c_int64, lp, lp, C.c_int64, lp, lp, dp, dp, C.c_int32,
@@ -218,7 +220,7 @@ EXPORTS = [
     "sqphip_kt_residuals", "sqphip_norm_complementarity", "sqphip_compute_phi",
     "sqphip_compute_qmodel", "sqphip_compute_derivative", "sqphip_compute_derivative_full", "sqphip_compute_mu_rule_dev",
     "sqphip_acopf_armijo", "sqphip_tr_update",
-    "sqphip_kkt_order", "sqphip_kkt_symbolic", "sqphip_mf_host_solve", "sqphip_mf_host_top2_err", "sqphip_mf_host_spine_err", "sqphip_mf_solve_test", "sqphip_acopf_attach", "sqphip_acopf_attach_acr", "sqphip_acopf_attach_acwr", "sqphip_acopf_set_shunts", "sqphip_acopf_set_dclines", "sqphip_acopf_set_instance", "sqphip_acopf_eval", "sqphip_sqp_reset",
+    "sqphip_kkt_order", "sqphip_kkt_symbolic", "sqphip_mf_host_solve", "sqphip_mf_host_top2_err", "sqphip_mf_host_spine_err", "sqphip_mf_solve_test", "sqphip_acopf_attach", "sqphip_acopf_attach_acr", "sqphip_acopf_attach_acwr", "sqphip_acopf_set_shunts", "sqphip_acopf_set_dclines", "sqphip_acopf_set_instance", "sqphip_dense_attach", "sqphip_dense_set_instance", "sqphip_acopf_eval", "sqphip_sqp_reset",
     "sqphip_sqp_run", "sqphip_sqp_get", "sqphip_sqp_status", "sqphip_sqp_trace",
     "sqphip_comm_available", "sqphip_comm_unique_id", "sqphip_comm_init", "sqphip_gather_status", "sqphip_comm_destroy",
     "sqphip_get_counters", "sqphip_get_mode_counters", "sqphip_sqp_work", "sqphip_sqp_stream_begin", "sqphip_sqp_stream_set", "sqphip_sqp_stream_run", "sqphip_sqp_stream_get", "sqphip_sqp_stream_assign", "sqphip_sqp_stream_append", "sqphip_sqp_stream_release", "sqphip_sqp_stream_run_some", "sqphip_sqp_last_request", "sqphip_sqp_qp_log", "sqphip_reset_counters", "sqphip_set_timing", "sqphip_get_kernel_times", "sqphip_ldlt_factor_host",

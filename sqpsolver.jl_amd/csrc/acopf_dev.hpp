@@ -259,11 +259,59 @@ static __device__ __forceinline__ void acwr_eval(const DV &d, int inst, const do
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// A synthetic NLP with a DENSE Lagrangian Hessian (bench.py --workload dense; BASELINE.json north_star: "dense LDL^T tiled
+// on MFMA where the Hessian is dense").  No reference counterpart -- the reference's examples are all ACOPF -- but the
+// shape SqpSolver.Model describes (src/model.jl:3-35): callbacks f, grad f, g, Jacobian, Hessian of the Lagrangian.
+//     min  1/2 x'Qx + c'x + kappa/4 sum_i x_i^4     s.t.  A x = b (m linear rows),  xL <= x <= xU
+// Q (n x n, symmetric, dense; shared by the batch) and A (m x n, dense; shared) live in HBM once; an instance carries
+// c[n] and its bounds / right-hand sides.  Structure: Jacobian COO = A row-major, Hessian COO = lower triangle of Q
+// column-major (sqpsolver.jl_amd/dense_synth.py).  Hessian of the Lagrangian: sigma (Q + 3 kappa diag(x^2)) -- the rows
+// are linear.
+static __device__ __forceinline__ void dense_eval(const DV &d, int inst, const double *__restrict__ x, double sigma,
+                           const double *__restrict__ lam, double *f_out, double *grad, double *gv,
+                           double *jv, double *hv)
+{
+    (void)lam;
+    const int n = d.n, m = d.m;
+    const double *Q = d.dnQ, *A = d.dnA, *c = d.dnc + (long)inst * n;
+    const double kap = d.dn_kappa;
+    if (f_out || grad) {
+        // (Q x)_j: thread j walks column j of the symmetric Q (coalesced across the threads of a wave: consecutive j)
+        double f = 0.0;
+        for (int j = threadIdx.x; j < n; j += TPB) {
+            double acc = 0.0;
+            for (int i = 0; i < n; ++i) acc += Q[(long)i * n + j] * x[i];
+            const double xj = x[j], x2 = xj * xj;
+            if (grad) grad[j] = acc + c[j] + kap * x2 * xj;
+            f += 0.5 * xj * acc + c[j] * xj + 0.25 * kap * x2 * x2;
+        }
+        if (f_out) {
+            f = block_reduce<OpSum>(f);
+            if (threadIdx.x == 0) *f_out = f;
+        }
+    }
+    if (gv)
+        for (int i = threadIdx.x; i < m; i += TPB) {
+            double acc = 0.0;
+            for (int j = 0; j < n; ++j) acc += A[(long)i * n + j] * x[j];
+            gv[i] = acc;
+        }
+    if (jv) for (long k = threadIdx.x; k < (long)m * n; k += TPB) jv[k] = A[k];
+    if (hv)
+        for (int j = 0; j < n; ++j) {                       // column j of the lower triangle: entries i = j .. n - 1 at off(j) + i - j
+            const long off = (long)j * n - (long)j * (j - 1) / 2;
+            for (int i = j + threadIdx.x; i < n; i += TPB)
+                hv[off + i - j] = sigma * (Q[(long)j * n + i] + (i == j ? 3.0 * kap * x[j] * x[j] : 0.0));
+        }
+}
+
 // any of f_out, grad, gv, jv, hv may be null
 static __device__ __forceinline__ void acopf_eval(const DV &d, int inst, const double *__restrict__ x, double sigma,
                            const double *__restrict__ lam, double *f_out, double *grad, double *gv,
                            double *jv, double *hv)
 {
+    if (d.dense_nlp) { dense_eval(d, inst, x, sigma, lam, f_out, grad, gv, jv, hv); return; }   // uniform over the launch
     if (d.acr) { acr_eval(d, inst, x, sigma, lam, f_out, grad, gv, jv, hv); return; }   // uniform over the launch
     if (d.acwr) { acwr_eval(d, inst, x, sigma, lam, f_out, grad, gv, jv, hv); return; }
     const int nb = d.nb, ng = d.ng, nl = d.nl;

@@ -105,6 +105,7 @@ DV group_view(const DV &d, int i0, int Bg, int g)
     v.trace += o * SQPHIP_TRACE_CAP * SQPHIP_TRACE_COLS;
     v.counters = d.counters + 8 * (g + 1);
     if (v.br_ohm) { v.br_ohm += o * d.nl * 12; v.c2 += o * d.ng; v.c1 += o * d.ng; }
+    if (v.dnc) v.dnc += o * n;
     v.mf.fronts += o * d.mf.stride; v.mf.vals += o * (long)d.mf.nnzK;
     if (v.mf.fronts1) { v.mf.fronts1 += o * d.mf.stride; v.mf.vals1 += o * (long)d.mf.nnzK; v.dinv1 += o * d.Fpad; v.vv1 += o * d.Fpad; }
     return v;
@@ -209,6 +210,7 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
         Pattern PJ = build_pattern(n, nnzJ, jrow, jcol, false);
         Pattern PH = build_pattern(n, nnzH, hrow, hcol, true);
         d.nnzjc = (int)PJ.rowval.size(); d.nnzhc = (int)PH.rowval.size();
+        d.hfull = n > 1 && (long)d.nnzhc == (long)n * n;
         // CSR view of J
         std::vector<int> rptr(m + 1, 0), rcol(d.nnzjc), rslot(d.nnzjc);
         for (int s = 0; s < d.nnzjc; ++s) rptr[PJ.rowval[s] + 1]++;
@@ -904,6 +906,39 @@ extern "C" int sqphip_acopf_set_instance(sqphip_ctx *h, int32_t inst, const doub
         DV &d = C.d;
         h2d(C, d.br_ohm + (size_t)inst * d.nl * 12, ohm, (size_t)d.nl * 12);
         h2d(C, d.c2 + (size_t)inst * d.ng, c2, d.ng); h2d(C, d.c1 + (size_t)inst * d.ng, c1, d.ng);
+        h2d(C, d.x0 + (size_t)inst * d.n, x0, d.n);
+        SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        return SQPHIP_OK;
+    });
+}
+
+// ---- the synthetic dense-Hessian NLP (acopf_dev.hpp dense_eval): structure as sqpsolver.jl_amd/dense_synth.py lays it out
+extern "C" int sqphip_dense_attach(sqphip_ctx *h, const double *Q, const double *A, double kappa)
+{
+    if (!h || !Q || !A || !(kappa >= 0.0)) return SQPHIP_EINVAL;
+    Ctx &C0 = h->c;
+    const long n = C0.d.n, m = C0.d.m;
+    if (C0.d.nnzj_coo != m * n || C0.d.nnzh_coo != n * (n + 1) / 2 || C0.d.nlin != m) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) {
+        DV &d = C.d;
+        double *q = C.dalloc<double>((size_t)(n * n)), *a = C.dalloc<double>((size_t)(m * n));
+        h2d(C, q, Q, (size_t)(n * n)); h2d(C, a, A, (size_t)(m * n));
+        d.dnQ = q; d.dnA = a; d.dn_kappa = kappa;
+        d.dnc = C.dalloc<double>((size_t)d.B * n);
+        d.dense_nlp = 1;
+        SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
+        C.acopf_attached = true;           // (the batched run! has its device callbacks)
+        make_lanes(C);
+        return SQPHIP_OK;
+    });
+}
+
+extern "C" int sqphip_dense_set_instance(sqphip_ctx *h, int32_t inst, const double *c, const double *x0)
+{
+    if (!h || !h->c.d.dense_nlp || inst < 0 || inst >= h->c.d.B || !c || !x0) return SQPHIP_EINVAL;
+    return guarded(h, [&](Ctx &C) {
+        DV &d = C.d;
+        h2d(C, d.dnc + (size_t)inst * d.n, c, d.n);
         h2d(C, d.x0 + (size_t)inst * d.n, x0, d.n);
         SQPHIP_HIP_OK(hipStreamSynchronize(C.stream));
         return SQPHIP_OK;

@@ -146,6 +146,7 @@ struct DV {
     int ipm_max_iter, ipm_phase1, ipm_corrector, ipm_warm;
     double refine_tol;                    // refinement step when the relative residual is above this (condensed form)
     int vstage;                           // doubles of dynamic LDS of the vector stages (n + N; 0: the vectors do not fit, ipm.hip)
+    int hfull;                            // 1: the Hessian pattern is completely dense (n^2 entries of the full symmetric CSC): hess_row reads column k at row j (ipm.hip)
     int vals_inline;                      // 1: the stage kernel behind the Newton right-hand side assembles the matrix values too (mf_values_block)
     int flat;                             // 1: the sparse products of the vector stages by flat kernels over the batch (large instances, ipm.hip)
     double *fH, *fJt, *fJ, *fX;           // ... their results: H v and J' w [B][n], J v and J x of the eliminated rows [B][m]
@@ -157,6 +158,9 @@ struct DV {
     // ---- ACOPF evaluator data
     int nb, ng, nl, ref_bus;
     StreamDev stream;
+    int dense_nlp;                        // 1: the synthetic dense-Hessian NLP (acopf_dev.hpp dense_eval; sqphip_dense_attach)
+    const double *dnQ, *dnA;              // ... its shared Q [n][n] and A [m][n]
+    double *dnc; double dn_kappa;         // ... per-instance linear cost [B][n]; weight of the quartic term
     int acr;                              // 1: rectangular voltage coordinates (acopf_dev.hpp acr_eval), 0: polar
     int acwr, nbp;                        // 1: W-space form of examples/acopf/acwr.jl (acwr_eval); its bus pairs i < j
     const int *bp_i, *bp_j, *br_bp;       // pair -> buses; branch -> pair

@@ -55,8 +55,17 @@ extern "C" int sqphip_vec_trace_read(long long *out) { return (int)hipMemcpyFrom
 __device__ __forceinline__ double hess_row(const DV &d, const double *hv, const double *hd, double hsc, const double *v, int j)
 {
     double acc = 0.0;
-    const int k0 = d.hcolptr[j], k1 = d.hcolptr[j + 1];
     const double hdj = hd[j], vj = v[j];
+    if (d.hfull) {
+        // a completely dense Hessian (every column holds all n rows, ascending): H_jk is read out of COLUMN k at row j -- the
+        // mirror of H_kj, the same bits (both triangles come from one COO entry) -- so the threads j, j + 1, ... of a wave read
+        // consecutive addresses; same terms in the same order as the walk down column j
+        const double *hj = hv + j;
+#pragma unroll 8
+        for (int k = 0; k < d.n; ++k) acc += hj[(long)k * d.n] * v[k];
+        return hsc * acc + hdj * vj;
+    }
+    const int k0 = d.hcolptr[j], k1 = d.hcolptr[j + 1];
 #pragma unroll 4
     for (int k = k0; k < k1; ++k) acc += hv[k] * v[d.hrowval[k]];
     return hsc * acc + hdj * vj;
@@ -468,11 +477,53 @@ __global__ __launch_bounds__(128) void k_kkt_assemble(DV d)
         for (int i = p + threadIdx.x; i < d.Fpad; i += 128) col[i] = 0.0;
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    if (u < 0) { col[p] = 1.0; return; }
     const double *jv = d.jv + (long)inst * d.nnzjc;
     const int *rt = d.rtype + (long)inst * d.m;
     const double *Dd = d.Dd + (long)inst * d.m;
+    if (u >= 0 && u < d.n && d.hcolptr[u + 1] - d.hcolptr[u] > 256) {
+        // a long column (a dense Hessian: round 4): its Hessian entries and the entries of the rows that stay in the matrix
+        // go to distinct positions -- every thread of the workgroup scatters its share (one thread walking 1 920 entries per
+        // column was 37 % of the GPU time of the dense workload); the diagonal and the eliminated rows, whose contributions
+        // meet, stay with thread 0 in the order of the serial walk
+        const int j = u;
+        const double hsc = d.ist[inst].hsc;
+        const double *hv = d.hv + (long)inst * d.nnzhc;
+        __shared__ double hdiag;
+        if (threadIdx.x == 0) hdiag = 0.0;
+        __syncthreads();
+        for (int k = d.hcolptr[j] + threadIdx.x; k < d.hcolptr[j + 1]; k += 128) {
+            const int i = d.hrowval[k];
+            if (i == j) { hdiag = hsc * hv[k]; continue; }
+            const int q = d.upos[i];
+            if (q > p) col[q] += hsc * hv[k];
+        }
+        for (int k = d.jcolptr[j] + threadIdx.x; k < d.jcolptr[j + 1]; k += 128) {
+            const int i = d.jrowval[k];
+            if (rt[i] == ROW_FREE) continue;
+            if (!d.condense || d.kpos[i] >= 0) {
+                const int q = d.upos[d.n + (d.condense ? d.kpos[i] : i)];
+                if (q > p) col[q] += jv[k];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x != 0) return;
+        double diag = d.hd[(long)inst * d.n + j] + d.sigp[(long)inst * d.n + j] + d.ist[inst].dw + IPM_REG_P;
+        diag += hdiag;
+        col[p] = diag;
+        if (d.condense)
+            for (int k = d.jcolptr[j]; k < d.jcolptr[j + 1]; ++k) {
+                const int i = d.jrowval[k];
+                if (rt[i] == ROW_FREE || d.kpos[i] >= 0) continue;
+                const double f = jv[k] / (Dd[i] + IPM_REG_D);
+                for (int t = d.jrowptr[i]; t < d.jrowptr[i + 1]; ++t) {
+                    const int q = d.upos[d.jrcol[t]];
+                    if (q >= p) col[q] += f * jv[d.jrslot[t]];
+                }
+            }
+        return;
+    }
+    if (threadIdx.x != 0) return;
+    if (u < 0) { col[p] = 1.0; return; }
     if (u >= d.n) {
         // a row of the factorised matrix: diagonal, and its Jacobian entries towards variables placed after it
         const int i = d.condense ? d.krow[u - d.n] : u - d.n;

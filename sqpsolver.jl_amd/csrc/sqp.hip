@@ -278,7 +278,8 @@ static __device__ __forceinline__ double qmodel_step(const DV &d, int inst, cons
     double acc = 0.0;
     for (int j = threadIdx.x; j < d.n; j += TPB) {
         double hp = 0.0;
-        for (int k = d.hcolptr[j]; k < d.hcolptr[j + 1]; ++k) hp += hv[k] * p[d.hrowval[k]];
+        if (d.hfull) { const double *hj = hv + j; for (int k = 0; k < d.n; ++k) hp += hj[(long)k * d.n] * p[k]; }      // (dense Hessian: the mirrored entries, coalesced: ipm.hip hess_row)
+        else for (int k = d.hcolptr[j]; k < d.hcolptr[j + 1]; ++k) hp += hv[k] * p[d.hrowval[k]];
         acc += df[j] * p[j] + 0.5 * p[j] * hp;
         tmpx[j] = x[j] + p[j];
     }

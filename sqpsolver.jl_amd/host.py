@@ -279,6 +279,14 @@ class Context:
         self._ck(self.L.sqphip_acopf_set_instance(self.h, inst, _d(ohm), _d(_f(net.c2)),
                                                   _d(_f(net.c1)), _d(_f(lay.x0 if x0 is None else x0))))
 
+    # ---- the synthetic dense-Hessian NLP (dense_synth.py; csrc/acopf_dev.hpp dense_eval)
+    def dense_attach(self, nlp):
+        self._ck(self.L.sqphip_dense_attach(self.h, _d(_f(nlp.Q.ravel())), _d(_f(nlp.A.ravel())), float(nlp.kappa)))
+
+    def dense_set_instance(self, inst, nlp, lay, x0=None):
+        self._ck(self.L.sqphip_set_bounds(self.h, inst, _d(_f(lay.xL)), _d(_f(lay.xU)), _d(_f(lay.gL)), _d(_f(lay.gU))))
+        self._ck(self.L.sqphip_dense_set_instance(self.h, inst, _d(_f(nlp.c)), _d(_f(lay.x0 if x0 is None else x0))))
+
     def acopf_eval(self, inst, x, sigma=1.0, lam=None):
         f = C.c_double(); grad = np.zeros(self.n); g = np.zeros(self.m)
         jv = np.zeros(self.nnzj); hv = np.zeros(self.nnzh) if lam is not None else None

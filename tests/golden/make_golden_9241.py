@@ -3,7 +3,7 @@ through the CPU oracle -- (a) the reference's Hessian sign (literal_quirks = 1, 
 W + K = 7 outer iterations, (b) the textbook sign to convergence.  Per run: status, outer iterations, objective, the decision
 sequence and radii of the trace, the final point, and one row per sub-problem (mode, MOI status, interior-point iterations,
 factorisations, rule that ended it: 0 tolerance, 1 / 2 / 3 acceptable-termination rules, final scaled error).  Oracle outputs,
-NOT reference outputs (the reference cannot run here).  Takes ~20 minutes on 8 cores:  python tests/golden/make_golden_9241.py"""
+NOT reference outputs (the reference cannot run here).  Takes ~10 minutes (one core):  python tests/golden/make_golden_9241.py"""
 import os
 import sys
 import time

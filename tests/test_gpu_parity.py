@@ -1205,6 +1205,44 @@ def test_dropin_seat_reproduces_reference_answers(name):
     assert rel(model.mult_g, ro["mult_g"]) < 1e-6
 
 
+@pytest.mark.parametrize("kkt_mode", [1, 2])
+def test_dense_hessian_nlp_on_the_device(kkt_mode):
+    """The synthetic NLP with a dense Lagrangian Hessian (bench.py --workload dense; sqpsolver.jl_amd/dense_synth.py):
+    min 1/2 x'Qx + c'x + kappa/4 sum x^4 s.t. A x = b, |x| <= 1.  (a) the device callbacks (acopf_dev.hpp dense_eval)
+    against the oracle's twin at a random point: f, gradient, rows, Jacobian, Hessian of the Lagrangian at 1e-13; (b) three
+    scenarios through the batched run! with the dense MFMA LDL^T (kkt_mode 1: the Newton matrix of order n + m is
+    factorised densely, no tile sparsity to exploit) and with the multifrontal path (kkt_mode 2: one front) against the
+    oracle's dense path: status, outer iterations, decisions and interior-point counts exact, the optimum at 1e-8."""
+    from sqpsolver_jl_amd.dense_synth import dense_synth, dense_scenario, dense_layout
+    base = dense_synth(160, 16, 7)
+    probs = [dense_scenario(base, s) for s in range(3)]
+    lays = [dense_layout(p) for p in probs]
+    kw = dict(max_iter=40, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1)
+    ctx = pkg.Context(lays[0].n, lays[0].m, lays[0].num_linear, lays[0].jrow, lays[0].jcol, lays[0].hrow, lays[0].hcol,
+                      lays[0].xL, lays[0].xU, lays[0].gL, lays[0].gU, pkg.default_options(kkt_mode=kkt_mode, **kw), batch=3)
+    ctx.dense_attach(base)
+    for b in range(3):
+        ctx.dense_set_instance(b, probs[b], lays[b])
+    x = np.random.default_rng(1).uniform(-0.7, 0.7, base.n); lam = np.random.default_rng(2).normal(size=base.m)
+    for b in (0, 2):
+        Po = O.problem_dense(probs[b], lays[b])
+        ev = ctx.acopf_eval(b, x, 1.0, lam)
+        assert abs(ev["f"] - Po.eval_f(x)) <= 1e-12 * max(1.0, abs(Po.eval_f(x)))
+        assert rel(ev["grad"], Po.eval_grad_f(x)) < 1e-13 and rel(ev["g"], Po.eval_g(x)) < 1e-13
+        assert np.array_equal(ev["jval"], Po.eval_jac_g(x)) and rel(ev["hval"], Po.eval_h(x, 1.0, lam)) < 1e-14
+    ctx.sqp_reset(); ctx.sqp_run(0)
+    c = ctx.counters()
+    assert c["sparse"] == (0 if kkt_mode == 1 else 1) and c["kkt_order"] >= base.n + base.m      # (the dense tile order pads)
+    for b in range(3):
+        rg, tr = ctx.sqp_get(b), ctx.sqp_trace(b)
+        ro = O.sqp_solve(O.problem_dense(probs[b], lays[b]), O.default_options(kkt_mode=1, **kw))
+        assert rg["status"] == ro["status"] == 0 and rg["iter"] == ro["iter"], (b, rg["status"], ro["status"], rg["iter"], ro["iter"])
+        assert _same_decisions(ro, tr) and _ipm_counts_close(ro, tr), b
+        assert rel(rg["x"], ro["x"]) < TOL and abs(rg["obj_val"] - ro["obj_val"]) <= TOL * max(1.0, abs(ro["obj_val"])), b
+        assert np.abs(probs[b].A @ rg["x"] - probs[b].b).max() <= 1e-9
+    ctx.close()
+
+
 def test_no_hessian_path_on_the_device():
     """`eval_h === nothing` (/root/reference/src/MOI_wrapper.jl:1092-1103,1178; src/algorithms/sqp.jl:92;
     subproblem_JuMP.jl:137-140): a context created with nnzH = 0 solves sub-problems with a linear objective.  (a) modes QP
