@@ -209,11 +209,11 @@ def main():
                 scen[s_id] = (net, acopf_layout(net))
         return scen[s_id]
 
-    def make_ctx(literal_quirks, max_iter=3000, first=None):
+    def make_ctx(literal_quirks, max_iter=3000, first=None, corrector=None):
         """context over this rank's block of scenarios, or (first = k) over the scenarios 0..k-1"""
         ids = range(lo, hi) if first is None else range(first)
         opts = pkg.default_options(max_iter=max_iter, literal_quirks=literal_quirks, device=local_rank,
-                                   ipm_corrector=args.ipm_corrector, **lin_kw, **sqp_kw)
+                                   ipm_corrector=args.ipm_corrector if corrector is None else corrector, **lin_kw, **sqp_kw)
         ctx = pkg.Context(lay0.n, lay0.m, lay0.num_linear, lay0.jrow, lay0.jcol, lay0.hrow, lay0.hcol,
                           lay0.xL, lay0.xU, lay0.gL, lay0.gU, opts, batch=len(ids))
         if dense_wl:
@@ -525,8 +525,13 @@ def main():
     if rank == 0 and world == 1 and not args.no_termination and (small or topology == "geo"):
         try:
             termination = {}
-            for lq in ((1, 0) if small else (0,)):      # the large shapes: textbook sign only (they converge in ~15 iterations)
-                tctx, _ = make_ctx(lq, max_iter=60)
+            # (the large shapes: textbook sign only -- they converge in ~15 iterations.  Third leg of the small shapes: the textbook
+            #  sign with the OTHER barrier rule -- its sub-problems are convex, where Mehrotra's predictor-corrector halves the
+            #  factorisations per sub-problem and the monotone rule's cheaper sweeps do not; the options of the headline stay the
+            #  library defaults)
+            legs = [(1, args.ipm_corrector), (0, args.ipm_corrector), (0, 1 - args.ipm_corrector)] if small else [(0, args.ipm_corrector)]
+            for lq, corr in legs:
+                tctx, _ = make_ctx(lq, max_iter=60, corrector=corr)
                 torch.cuda.synchronize()
                 ta = time.perf_counter()
                 tctx.sqp_run(0)
@@ -535,12 +540,12 @@ def main():
                 tc = tctx.counters()
                 tm = tctx.mode_counters()
                 ret, it, done = tctx.sqp_status()
-                termination[f"literal_quirks_{lq}"] = {
-                    "seconds": tb - ta, "qp_solved": int(tc["n_qp"]), "qp_per_s": tc["n_qp"] / (tb - ta),
+                termination[f"literal_quirks_{lq}" + ("" if corr == args.ipm_corrector else f"_ipm_corrector_{corr}")] = {
+                    "ipm_corrector": corr, "seconds": tb - ta, "qp_solved": int(tc["n_qp"]), "qp_per_s": tc["n_qp"] / (tb - ta),
                     "instances_done": int(np.sum(done)), "converged_ret0": int(np.sum(ret == 0)),
                     "iteration_limit": int(np.sum(ret == -1)), "other": int(np.sum((ret != 0) & (ret != -1))),
                     "outer_iterations_median": float(np.median(it)), "ipm_iterations_per_qp": tc["n_ipm_iter"] / max(1, tc["n_qp"]),
-                    "factorisations_per_qp": tc["n_factor"] / max(1, tc["n_qp"]),
+                    "factorisations_per_qp": tc["n_factor"] / max(1, tc["n_qp"]), "sweeps": int(tc["n_sweeps"]),
                     "by_mode": {k: {"solved": int(v[0]), "ipm_iterations_per_solve": v[1] / v[0],
                                     "factorisations_per_solve": v[2] / v[0]} for k, v in tm.items() if v[0] > 0}}
                 tctx.close()

@@ -248,6 +248,7 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
                 if (const char *e = getenv("SQPHIP_MF_SMALL_FRONT")) so.small_front = atoi(e);
                 if (const char *e = getenv("SQPHIP_MF_ZERO_FRAC")) so.zero_frac = atof(e);
                 if (const char *e = getenv("SQPHIP_MF_ROWS_AFTER")) so.rows_after_vars = atoi(e);
+                so.merge_tiles = B <= 64 ? 4 : 0;        // (small batches: one launch per level of small fronts, mfplan.hip)
                 C.mfp_ = std::make_shared<MfPlan>(mf_build_plan(d.n, (int)m, kp, d.condense ? d.mk : (int)m, PH.colptr, PH.rowval, rptr, rcol, rslot, so));
                 const SparseSym &S = C.mfp().S;
                 // auto: the sparse factorisation when it does a quarter of the dense work or less and no front

@@ -190,7 +190,12 @@ MfPlan mf_build_plan(int n, int m, const std::vector<int> &kpos, int mk, const s
         // launch saved is a dependent kernel boundary less in a chain of ~45 per sweep
         int cnt = 0, tmax = 0;
         for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; ++q) { ++cnt; tmax = std::max(tmax, tiles(S.level_sn[q])); }
-        const bool merge = cnt <= 8 && tmax <= 8 && !getenv("SQPHIP_MF_NO_LEVEL_MERGE");
+        // (experiment, round 4: SQPHIP_MF_MERGE_T = t merges every level whose tallest front has at most t tiles, however many
+        //  fronts it holds -- the small fronts then run in the kernel of the tallest)
+        //  (measured, monotone sweep, QP/s without / with t = 4: 512 resident scenarios 8 995 / 8 517, 256: 6 570 / 6 285, 128: 4 309 / 4 321,
+        //  64: 2 549 / 2 611, 32: 1 373 / 1 427 -- the caller asks for it up to 64 instances, SymOptions::merge_tiles)
+        const int merge_t = getenv("SQPHIP_MF_MERGE_T") ? atoi(getenv("SQPHIP_MF_MERGE_T")) : opt.merge_tiles;
+        const bool merge = ((cnt <= 8 && tmax <= 8) || tmax <= merge_t) && !getenv("SQPHIP_MF_NO_LEVEL_MERGE");
         for (int c = 0; c < 10; ++c) {
             MfLaunch L{(int)P.sched.size(), 0, 0, 0, c, 0};
             L.level = l;

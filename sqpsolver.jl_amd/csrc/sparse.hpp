@@ -47,6 +47,8 @@ struct SymOptions {
     int small_front = 32;      // a child is always merged into its parent while the merged front stays within this
     double zero_frac = 0.25;   // ... or while the explicit zeros stay below this fraction of the merged supernode's L
     int order_method = 0;      // 0 approximate minimum degree (constrained), 1 natural order
+    int merge_tiles = 0;       // launch schedule: a level whose tallest front has at most this many 16-row tiles is ONE launch of that
+                               // front's kernel however many fronts it holds (small batches: a launch less per level beats the idle waves)
     int chain_front = 0;       // > 0: along the spine of the tree the deepest child is merged into its parent while the
                                // merged front stays within this many rows (symbolic.hip, second amalgamation pass)
 };
