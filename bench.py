@@ -441,6 +441,8 @@ def main():
             nK, nL, nKt, nLt, ct = (int(cc1[k]) for k in ("nnz_k", "nnz_l", "nnz_k_top", "nnz_l_top", "cols_top"))
             nj, nh = len(lay0.jrow), 2 * len(lay0.hrow)
             dres = max(0, dsol - dit)                      # refinement / corrector solves: forward + backward
+            no_top = nLt == 0 or kt1["solve_top"][1] == kt0["solve_top"][1]     # no streamed top in this plan: its fronts are level launches of the solves
+            sLt, sct = (0, 0) if no_top else (nLt, ct)
             per_unit = {
                 "values": ("k_mf_values", "instance-factorisation", dfac, 20.0 * nK, "12 B read (value + index) + 8 B written per structural entry"),
                 "fronts_low": ("k_mf_factor2<*> / k_mf_front<*> below the narrow top of the tree", "instance-factorisation", dfac,
@@ -451,13 +453,15 @@ def main():
                               (dit * (8.0 * nLt + 16.0 * ct) + dres * (16.0 * nLt + 16.0 * ct)) / max(1, dit + dres),
                               "backward pass: 8 B per entry of L of the top + 16 B per column; forward + backward: twice the L"),
                 "solve_levels": ("k_mf_fwd2 / k_mf_bwd2", "instance-solve", dit + dres,
-                                 (dit * (8.0 * (nL - nLt) + 16.0 * (N - ct)) + dres * (16.0 * (nL - nLt) + 16.0 * (N - ct))) / max(1, dit + dres),
+                                 (dit * (8.0 * (nL - sLt) + 16.0 * (N - sct)) + dres * (16.0 * (nL - sLt) + 16.0 * (N - sct))) / max(1, dit + dres),
                                  "as solve_top, the fronts below the top"),
                 "post": ("k_ipm_post (residual check, step, convergence test, next right-hand side)", "instance-iteration", dit,
                          8.0 * (36 * lay0.n + 52 * lay0.m) + 12.0 * (2 * nh + 6 * nj),
                          "36 vector passes over n + 52 over m (8 B each) + 2 Hessian and 6 Jacobian products (12 B per entry)"),
             }
             kernels = {}
+            if no_top:
+                per_unit.pop("solve_top", None)
             for cls, (name, unit, units, bpu, what) in per_unit.items():
                 sec, grp = kt1[cls][0] - kt0[cls][0], kt1[cls][1] - kt0[cls][1]
                 if sec <= 0 or grp <= 0:

@@ -1945,14 +1945,15 @@ void mf_solve(Ctx &C, int want, bool skip_fwd, bool inertia)
             else hipLaunchKernelGGL(k_mf_fwd, dim3(L.count, d.B), dim3(256), L.lds_bytes, s, d, L.begin, want, generic, L.tiles, L.cls, L.lds_bytes / 8 - L.cls);
         }
     if (!skip_fwd && !C.mfp().fwd.empty()) C.tm.close(KC_SOLVE_LEVELS, s);
-    C.tm.open(s);
+    const bool has_top = (d.mf.top_n > 0 && !generic) || C.mfp().top.count > 0;
+    if (has_top) C.tm.open(s);
     if (d.mf.top_n > 0 && !generic) {
         const size_t lds = (size_t)C.mfp().top2_lds_bytes;
         hipLaunchKernelGGL(k_mf_solve_top2, dim3(d.B), dim3(256), lds, s, d, want, skip_fwd ? 0 : 1, inertia ? 1 : 0);
     } else if (const MfLaunch &T = C.mfp().top; T.count > 0)
         hipLaunchKernelGGL(k_mf_solve_top, dim3(d.B), dim3(256), T.lds_bytes, s, d, T.begin, T.count, want, skip_fwd ? 0 : 1, generic,
                            T.tiles, T.cls, T.lds_bytes / 8 - T.cls);
-    C.tm.close(KC_SOLVE_TOP, s);
+    if (has_top) C.tm.close(KC_SOLVE_TOP, s);
     if (!C.mfp().bwd.empty()) C.tm.open(s);
     for (const MfLaunch &L : C.mfp().bwd) {
         if (lvl2 && !generic && L.wimg >= 0) {
