@@ -9,6 +9,8 @@ import sys
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 SO_PATH = os.path.join(_CSRC, "libsqphip.so")
+if os.environ.get("SQPHIP_SO"):        # experiment aid: another build of the library (A / B runs on one box); never set in normal use
+    SO_PATH = os.path.abspath(os.environ["SQPHIP_SO"])
 SOURCES = ["ldlt.hip", "kernel_api.hip", "ipm.hip", "acopf.hip", "sqp.hip", "api.hip", "order.hip", "symbolic.hip",
            "mfplan.hip", "mfront.hip", "comm.hip"]
 HEADERS = ["sqphip_internal.hpp", "ctx.hpp", "sparse.hpp", "dev_util.hpp", "mf_dev.hpp", "acopf_dev.hpp", os.path.join("..", "..", "include", "sqphip.h"),

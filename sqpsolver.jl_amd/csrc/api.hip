@@ -307,7 +307,9 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
                 // Large matrices (1354 / 9241 buses) rarely fail a shrink attempt and gain nothing (measured): the second
                 // arena is only spent where it is small (<= 1 GB).
                 const bool small_arena = (double)B * (double)P.stride * 8.0 <= 1e9;
-                d.spec_mode = getenv("SQPHIP_MF_SPEC") ? atoi(getenv("SQPHIP_MF_SPEC")) : (B <= 256 && small_arena ? 1 : 0);
+                // (round 4, monotone sweeps -- shorter, so a saved sweep is worth less against the doubled front work: 256
+                //  resident scenarios 6 541 QP/s with it, 6 627 without; 128: 4 307 / 4 110; on up to 192 instances)
+                d.spec_mode = getenv("SQPHIP_MF_SPEC") ? atoi(getenv("SQPHIP_MF_SPEC")) : (B <= (opt->ipm_corrector ? 256 : 192) && small_arena ? 1 : 0);
                 if (d.spec_mode != 0) {
                     M.vals1 = C.dalloc<double>((size_t)B * P.nnzK);
                     M.fronts1 = C.dalloc<double>((size_t)B * P.stride);
