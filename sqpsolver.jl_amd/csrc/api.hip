@@ -19,6 +19,7 @@ Ctx::~Ctx()
     plan.destroy_lookahead();
     for (void *p : allocs) hipFree(p);
     if (h_counters) hipHostFree(h_counters);
+    if (side) { hipStreamDestroy(side); for (auto &e : evS) if (e) hipEventDestroy(e); for (auto &e : evC) if (e) hipEventDestroy(e); }
     if (stream && owns_stream) hipStreamDestroy(stream);
 }
 
@@ -133,7 +134,7 @@ void make_lanes(Ctx &C)
         L->is_lane = true;
         L->opt = C.opt; L->n = C.n; L->m = C.m; L->acopf_attached = C.acopf_attached;
         L->mfp_ = C.mfp_;
-        L->trans_period = C.trans_period; L->mf_big_lds = C.mf_big_lds; L->post_split = C.post_split;
+        L->trans_period = C.trans_period; L->mf_big_lds = C.mf_big_lds; L->post_split = C.post_split; L->side_mode = C.side_mode;
         L->d = group_view(C.d, lo, hi - lo, g);
         // the first group runs on the owner's stream (idle during sqphip_sqp_run): HIP maps streams onto four hardware
         // queues by default, and a fifth stream would share one -- measured: 3131 QP/s with five streams against 5216
@@ -399,6 +400,7 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
         if (const char *e = getenv("SQPHIP_TRANS_PERIOD")) C.trans_period = atoi(e);      // experiment switch, read once per context
         if (d.sparse) mf_device_setup(C);
         C.post_split = getenv("SQPHIP_POST_SPLIT") && atoi(getenv("SQPHIP_POST_SPLIT")) == 1;
+        C.side_mode = getenv("SQPHIP_SIDE_TRANS") && atoi(getenv("SQPHIP_SIDE_TRANS")) == 1;      // transitions on a side stream (ctx.hpp)
         make_lanes(C);
         return SQPHIP_OK;
     });

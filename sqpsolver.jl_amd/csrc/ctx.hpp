@@ -14,7 +14,14 @@ namespace sqphip {
 // interior-point phases of one instance (kernels act only on instances in the phase they serve)
 // PH_SOLVE: first solve behind a factorisation (its forward half is fused into the factorisation); PH_RESOLVE: a
 // further right-hand side through the same factors -- the corrector of the predictor-corrector mode or a refinement step
-enum { PH_IDLE = 0, PH_PREP = 1, PH_FACTOR = 2, PH_SOLVE = 3, PH_STEP = 4, PH_MPC = 5, PH_RESOLVE = 6, PH_DONE = 9 };
+// Transitions on a side stream (Ctx::side_on, ipm_sweep): the kernels that end a sub-problem, run the stage of run! and start the
+// next sub-problem then work CONCURRENTLY with the factorisation / solve / post kernels of the same group, on instances the
+// main kernels do not touch.  The two sides hand instances over at the end of a sweep only (k_sqp_count, behind an event of
+// each stream): the main side files a finished interior-point run as PH_DONE2 (-> PH_DONE there), the side files a started
+// sub-problem with its first right-hand side as PH_PEND (-> PH_FACTOR there) and uses PH_PREP_S where the main side uses
+// PH_PREP, so that neither side ever sees a state of the other half-written.
+enum { PH_IDLE = 0, PH_PREP = 1, PH_FACTOR = 2, PH_SOLVE = 3, PH_STEP = 4, PH_MPC = 5, PH_RESOLVE = 6, PH_DONE = 9,
+       PH_PEND = 10, PH_DONE2 = 11, PH_PREP_S = 12 };
 enum { ROW_FREE = 0, ROW_EQ = 1, ROW_INEQ = 2 };
 
 struct IpmState {
@@ -144,6 +151,7 @@ struct DV {
     int *counters;      // [0] instances iterating, [1] start flags, [2] SQP not done, [3] start flags
     double ipm_tol;
     int ipm_max_iter, ipm_phase1, ipm_corrector, ipm_warm;
+    int side;                             // 0: transitions in line; 1: this launch is a transition kernel on the side stream; 2: a main kernel beside it
     double refine_tol;                    // refinement step when the relative residual is above this (condensed form)
     int vstage;                           // doubles of dynamic LDS of the vector stages (n + N; 0: the vectors do not fit, ipm.hip)
     int hfull;                            // 1: the Hessian pattern is completely dense (n^2 entries of the full symmetric CSC): hess_row reads column k at row j (ipm.hip)
@@ -175,6 +183,11 @@ struct DV {
     int max_iter, use_soc, literal_quirks;
 };
 
+// phase codes by the side a kernel runs on (see the enum)
+static __device__ __forceinline__ int ph_done(const DV &d) { return d.side == 2 ? PH_DONE2 : PH_DONE; }
+static __device__ __forceinline__ int ph_prep(const DV &d) { return d.side == 1 ? PH_PREP_S : PH_PREP; }
+static __device__ __forceinline__ int ph_fact(const DV &d) { return d.side == 1 ? PH_PEND : PH_FACTOR; }
+
 struct Ctx {
     sqphip_options opt;
     DV d;                       // device view (pointers into the arenas below)
@@ -195,6 +208,11 @@ struct Ctx {
     long run_sweep = 0;
     bool post_split = false;        // experiment (SQPHIP_POST_SPLIT): the right-hand side of the next iteration by its own launch behind k_ipm_post
     bool want_resolve = true;       // monotone rule: this sweep carries the second solve slot (an instance asked for a refinement solve)
+    // transitions on a side stream (see the PH_ enum): side_mode = allowed on this context (SQPHIP_SIDE_TRANS), side_on = in
+    // use by the current run; evS[k & 3]: side job of sweep k done, evC[k & 3]: hand-over kernel of sweep k done
+    bool side_mode = false, side_on = false;
+    hipStream_t side = nullptr;
+    hipEvent_t evS[4] = {}, evC[4] = {};
     int trans_period = 0;           // 0: by group size (3 from 64 instances, 2 from 32, else 1); SQPHIP_TRANS_PERIOD, read at creation
     Timers tm;
     std::vector<void *> allocs;
@@ -237,7 +255,7 @@ struct Ctx {
 // ipm.hip
 void ipm_run_all(Ctx &C);            // runs every instance whose IpmState.start is set, to completion
 void ipm_sweep(Ctx &C, bool sqp_level);
-void sqp_stage_kernels(Ctx &C);      // sqp.hip: SQP-level kernels of a sweep
+void sqp_stage_kernels(Ctx &C, hipStream_t s, const DV &d);      // sqp.hip: SQP-level kernels of a sweep (on the stream and with the device view given)
 void sqp_stream_arm(Ctx &C);          // scenario queue: every slot draws its first scenario in the first sweep
 void sqp_stream_rearm(Ctx &C);        // ... slots that found the queue empty look again (ids were appended)
 void launch_qp_gather(Ctx &C);       // COO -> CSC for instances with start set (stage 0)

@@ -293,7 +293,7 @@ static __device__ void b_ipm_start(const DV &d)
         st.cn = 0.0;
         st.mpc = d.ipm_corrector != 0; st.use_soc = 0; st.cavg = 0.0;
         st.start = 0;
-        d.phase[inst] = PH_PREP;
+        d.phase[inst] = ph_prep(d);
     }
 }
 
@@ -302,12 +302,12 @@ static __device__ void b_ipm_start(const DV &d)
 static __device__ void b_ipm_prepare(const DV &d)
 {
     const int inst = blockIdx.x;
-    if (d.phase[inst] != PH_PREP) return;
+    if (d.phase[inst] != ph_prep(d)) return;
     IpmState &st = d.ist[inst];
     INST_PTRS
     // iteration limit; half of it for a second-order correction (sqphip.h, options.ipm_max_iter)
     if (st.iter >= (st.mode == SQPHIP_MODE_SOC ? d.ipm_max_iter / 2 : d.ipm_max_iter)) {
-        if (threadIdx.x == 0) { st.rc = 1; d.phase[inst] = PH_DONE; }
+        if (threadIdx.x == 0) { st.rc = 1; d.phase[inst] = ph_done(d); }
         return;
     }
     const double hsc = st.hsc;
@@ -387,7 +387,7 @@ static __device__ void b_ipm_prepare(const DV &d)
     VTR(21)
     const double cavg = nc > 0 ? csum / nc : 0.0;
     if (!fin(rdn) || !fin(cavg) || !fin(rpn)) {
-        if (threadIdx.x == 0) { st.rc = 2; d.phase[inst] = PH_DONE; }
+        if (threadIdx.x == 0) { st.rc = 2; d.phase[inst] = ph_done(d); }
         return;
     }
     const double sd = fmax(100.0, dl1 / (double)(d.n + d.m)) / 100.0;
@@ -400,7 +400,7 @@ static __device__ void b_ipm_prepare(const DV &d)
     const int n_acc3 = e0 <= 1e4 * d.ipm_tol ? n_acc3_prev + 1 : 0;
     if (e0 <= d.ipm_tol || n_acc >= 8 || n_acc2 >= 15 || n_acc3 >= 25) {
         // (which rule ended the run and at what scaled error is reported: sqphip_qp_termination, sqphip_sqp_qp_log_term)
-        if (threadIdx.x == 0) { st.rc = 0; st.e0 = e0; st.acc_rule = e0 <= d.ipm_tol ? 0 : (n_acc >= 8 ? 1 : (n_acc2 >= 15 ? 2 : 3)); d.phase[inst] = PH_DONE; }
+        if (threadIdx.x == 0) { st.rc = 0; st.e0 = e0; st.acc_rule = e0 <= d.ipm_tol ? 0 : (n_acc >= 8 ? 1 : (n_acc2 >= 15 ? 2 : 3)); d.phase[inst] = ph_done(d); }
         return;
     }
     if (threadIdx.x == 0) { st.n_acc = n_acc; st.n_acc2 = n_acc2; st.n_acc3 = n_acc3; }
@@ -438,7 +438,7 @@ static __device__ void b_ipm_prepare(const DV &d)
         // skip the zero trial and start from a third of it
         const double keep = st.dw > 3e-10 ? fmax(1e-20, st.dw / 3.0) : 0.0;
         st.dw = keep; st.dw_floor = keep; st.fac_attempt = 0; st.dir_attempt = 0;
-        d.phase[inst] = PH_FACTOR;
+        d.phase[inst] = ph_fact(d);
     }
     VTR(22)
 }
@@ -648,7 +648,7 @@ __device__ double build_rhs(const DV &d, int inst, double tgt, bool soc)
 static __device__ void b_build_rhs(const DV &d)
 {
     const int inst = blockIdx.x;
-    if (d.phase[inst] != PH_FACTOR) return;
+    if (d.phase[inst] != ph_fact(d)) return;
     IpmState &st = d.ist[inst];
     const double rn = build_rhs(d, inst, st.mpc ? 0.0 : st.mu, false);
     if (threadIdx.x == 0) st.rn = fmax(1.0, rn);
@@ -921,7 +921,7 @@ static __device__ void b_ipm_step(const DV &d)
             st.dir_attempt++;
             const double fl = st.dw > 0.0 ? 8.0 * st.dw : (st.dw_last > 0.0 ? st.dw_last : 1e-4);
             st.dw_floor = fl; st.dw = fl; st.fac_attempt = 0;
-            if (st.dir_attempt >= 12 || fl > 1e20) { st.rc = 2; d.phase[inst] = PH_DONE; }
+            if (st.dir_attempt >= 12 || fl > 1e20) { st.rc = 2; d.phase[inst] = ph_done(d); }
             else d.phase[inst] = PH_FACTOR;
         }
         return;
@@ -945,7 +945,7 @@ static __device__ void b_ipm_step(const DV &d)
         zpv[i] = zpi - a_d * dyi; zmv[i] = zmi + a_d * dyi;
     }
     VTR(11)
-    if (threadIdx.x == 0) { st.iter++; d.phase[inst] = PH_PREP; }
+    if (threadIdx.x == 0) { st.iter++; d.phase[inst] = ph_prep(d); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1231,11 +1231,28 @@ void ipm_sweep(Ctx &C, bool sqp_level)
     // inertia trial as it was, so a sweep without transitions starts with the matrix values (the dense path consumes the
     // vector in place and keeps k_ipm_rhs)
     const bool mono = d.ipm_corrector == 0;
-    if (trans) {
+    // Transitions on a side stream (Ctx::side_on; ctx.hpp, the PH_ enum): from the second sweep of a run on, the three
+    // transition kernels of EVERY sweep run beside the factorisation / solve / post kernels of the same sweep, on the instances
+    // that had finished a sub-problem when the sweep before ended; what they start joins the next sweep.  The main chain loses
+    // the transition kernels (every fourth sweep ~330 us for the three or four instances of a group that needed them), an
+    // instance waits one sweep instead of 1.5 on average.
+    const bool side = sqp_level && C.side_on;
+    if (side && C.run_sweep > 1) {           // (run_sweep was incremented above: this is sweep run_sweep - 1 >= 1)
+        const long k = C.run_sweep - 1;
+        DV ds = d; ds.side = 1;
+        SQPHIP_HIP_OK(hipStreamWaitEvent(C.side, C.evC[(k - 1) & 3], 0));
+        C.tm.open(C.side);
+        hipLaunchKernelGGL(k_qp_finish, gB, bT, 0, C.side, ds);
+        sqp_stage_kernels(C, C.side, ds);
+        hipLaunchKernelGGL(k_ipm_head, gB, bT, vlds, C.side, ds);
+        C.tm.close(KC_TRANS, C.side);
+        SQPHIP_HIP_OK(hipEventRecord(C.evS[k & 3], C.side));
+    } else if (side || trans) {
+        DV d0 = d; d0.side = 0;              // (in line: the first sweep of a run with the side stream, every P-th without)
         C.tm.open(s);
-        hipLaunchKernelGGL(k_qp_finish, gB, bT, 0, s, d);
-        if (sqp_level) sqp_stage_kernels(C);
-        if (!d.flat) hipLaunchKernelGGL(k_ipm_head, gB, bT, vlds, s, d);
+        hipLaunchKernelGGL(k_qp_finish, gB, bT, 0, s, d0);
+        if (sqp_level) sqp_stage_kernels(C, s, d0);
+        if (!d.flat) hipLaunchKernelGGL(k_ipm_head, gB, bT, vlds, s, d0);
         else {
             hipLaunchKernelGGL(k_ipm_head_a, gB, bT, vlds, s, d);
             hipLaunchKernelGGL(k_sp_products, gP, b256, 0, s, d, (int)SP_PREP, (int)PH_PREP);

@@ -99,7 +99,7 @@ static __device__ __forceinline__ void inertia_decide(const DV &d, int inst, Ipm
         }
         st.fac_attempt++;
         st.dw = next_shift(st.dw, st.dw_last);   // (candidate 1 was factorised with exactly this shift)
-        if (st.dw > 1e40 || st.fac_attempt >= 60) { st.rc = 2; d.phase[inst] = PH_DONE; return; }
+        if (st.dw > 1e40 || st.fac_attempt >= 60) { st.rc = 2; d.phase[inst] = ph_done(d); return; }
     }
 }
 

@@ -479,6 +479,13 @@ __global__ void k_sqp_count(DV d, int *host_slot)
     // slot of a sweep is launched only when the host has seen one (ipm_sweep, Ctx::want_resolve)
     int nb = 0, ns = 0, nr = 0;
     for (int i = threadIdx.x; i < d.B; i += blockDim.x) {
+        // transitions on a side stream: the hand-over between the two sides (ctx.hpp, the PH_ enum); both streams are
+        // quiet here -- this launch is behind the event of the side job, the next side job is behind this launch's
+        if (d.side == 2) {
+            const int ph = d.phase[i];
+            if (ph == PH_DONE2) d.phase[i] = PH_DONE;
+            else if (ph == PH_PEND) d.phase[i] = PH_FACTOR;
+        }
         const SqpState &S = d.sst[i];
         if (!S.done && (S.budget > 0 || S.stage != ST_TOP)) ++nb;
         if (d.ist[i].start) ++ns;
@@ -570,6 +577,15 @@ static void sqp_run_lane(Ctx &C, int max_outer)
     const dim3 gB(d.B), bT(TPB);
     C.run_sweep = 0;                     // (the first sweep of a run always carries the transitions: ipm_sweep)
     C.want_resolve = true;               // (... and the refinement slot, until the first counter has come back)
+    // transitions on a side stream (ctx.hpp, the PH_ enum; ipm_sweep): monotone rule, sparse path, one-workgroup vector stages
+    C.side_on = C.side_mode && d.sparse && !d.flat && d.ipm_corrector == 0 && d.B >= 8;
+    if (C.side_on && !C.side) {
+        SQPHIP_HIP_OK(hipStreamCreateWithFlags(&C.side, hipStreamNonBlocking));
+        for (auto &e : C.evS) SQPHIP_HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &e : C.evC) SQPHIP_HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    d.side = C.side_on ? 2 : 0;
+    struct SideOff { Ctx &C; ~SideOff() { C.d.side = 0; C.side_on = false; } } side_off{C};     // (other entry points run in line)
     hipLaunchKernelGGL(k_sqp_budget, dim3(1), dim3(64), 0, s, d, max_outer > 0 ? max_outer : 0x3fffffff);
     hipLaunchKernelGGL(k_sqp_begin, gB, bT, 0, s, d);
     // The "anyone left?" counter of sweep k is read while sweep k + 1 is already queued: the stream never runs dry
@@ -578,8 +594,17 @@ static void sqp_run_lane(Ctx &C, int max_outer)
     static const bool lockstep = getenv("SQPHIP_SWEEP_LOCKSTEP") != nullptr; // experiment switch: read before queueing
     hipEvent_t ev[2];
     for (auto &e : ev) SQPHIP_HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    // experiment aid (SQPHIP_HOST_STATS): where the host thread of this group spends its time -- queueing a sweep, or waiting for
+    // the counter of the sweep before last; a wait that returns at once means the stream may have run dry behind the host
+    static const bool host_stats = getenv("SQPHIP_HOST_STATS") != nullptr;
+    double hs_queue = 0.0, hs_wait = 0.0; long hs_sweeps = 0, hs_nowait = 0;
     auto left_after = [&](long k) {          // instances with work left after sweep k
+        const auto w0 = std::chrono::steady_clock::now();
         SQPHIP_HIP_OK(hipEventSynchronize(ev[k & 1]));
+        if (host_stats) {
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
+            hs_wait += us; if (us < 5.0) ++hs_nowait;
+        }
         SQPHIP_HIP_OK(hipGetLastError());   // a failed launch anywhere in the sweep surfaces here
         const int left = C.h_counters[2 + 2 * (k & 1)];
         C.want_resolve = C.h_counters[3 + 2 * (k & 1)] > 0;      // (refinement solves pending after sweep k: the next sweep queued carries the slot)
@@ -588,16 +613,24 @@ static void sqp_run_lane(Ctx &C, int max_outer)
     };
     try {
         for (long sweep = 0; sweep < 100000000L; ++sweep) {
+            const auto q0 = std::chrono::steady_clock::now();
             ipm_sweep(C, /*sqp_level=*/true);
             int *slot = nullptr;                 // device view of the pinned words this sweep reports into
             SQPHIP_HIP_OK(hipHostGetDevicePointer((void **)&slot, C.h_counters + 2 + 2 * (sweep & 1), 0));
+            if (C.side_on && sweep > 0) SQPHIP_HIP_OK(hipStreamWaitEvent(s, C.evS[sweep & 3], 0));     // the side job of this sweep
             hipLaunchKernelGGL(k_sqp_count, dim3(1), dim3(64), 0, s, d, slot);
+            if (C.side_on) SQPHIP_HIP_OK(hipEventRecord(C.evC[sweep & 3], s));
             SQPHIP_HIP_OK(hipEventRecord(ev[sweep & 1], s));
+            if (host_stats) { hs_queue += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - q0).count(); ++hs_sweeps; }
             if (C.tm.pending_trailing.size() > 4096) C.tm.flush();
             if (lockstep) { if (left_after(sweep) == 0) break; continue; }
             if (sweep >= 1 && left_after(sweep - 1) == 0) break;
         }
         SQPHIP_HIP_OK(hipStreamSynchronize(s));
+        if (C.side_on) SQPHIP_HIP_OK(hipStreamSynchronize(C.side));
+        if (host_stats && hs_sweeps > 0)
+            fprintf(stderr, "sqphip: group of %d: %ld sweeps, host queues a sweep in %.1f us, waits %.1f us per sweep, %ld waits returned at once\n",
+                    d.B, hs_sweeps, hs_queue / hs_sweeps, hs_wait / hs_sweeps, hs_nowait);
     } catch (...) {
         for (auto &e : ev) hipEventDestroy(e);
         throw;
@@ -673,9 +706,9 @@ __global__ __launch_bounds__(TPB, SQPHIP_VEC_WAVES_PER_EU) void k_sqp_stage(DV d
     if (d.stream.M > 0) { __syncthreads(); b_sqp_stream(d); }
 }
 
-void sqp_stage_kernels(Ctx &C)          // called from ipm_sweep
+void sqp_stage_kernels(Ctx &C, hipStream_t s, const DV &d)          // called from ipm_sweep
 {
-    hipLaunchKernelGGL(k_sqp_stage, dim3(C.d.B), dim3(TPB), 0, C.stream, C.d);
+    hipLaunchKernelGGL(k_sqp_stage, dim3(d.B), dim3(TPB), 0, s, d);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1483,6 +1483,38 @@ def test_transition_period_changes_nothing_but_the_schedule(monkeypatch):
     assert got["1"][4] <= got["2"][4] <= got["3"][4]
 
 
+def test_side_stream_transitions_change_nothing_but_the_schedule(monkeypatch):
+    """SQPHIP_SIDE_TRANS=1: from the second sweep of a run on, the transition kernels (k_qp_finish, the stage kernel of run!,
+    k_ipm_head) of every sweep run on a side stream BESIDE the factorisation / solve / post kernels of the same group, on the
+    instances that had finished a sub-problem when the sweep before ended; the two sides hand instances over in k_sqp_count
+    only (ctx.hpp, the PH_ enum).  Which sweep an instance moves on in changes nothing it computes: sixteen scenarios in two
+    groups of eight, with the queue of a second run on the same context -- the same iterates bit for bit, the same
+    per-sub-problem logs and work counters as with the transitions in line."""
+    nb, ng, nl, seed = CASES["case14"]
+    base = acopf_synth(nb, ng, nl, seed)
+    nets = [base] + [contingency(base, s, seed) for s in range(1, 16)]
+    lays = [acopf_layout(nt) for nt in nets]
+    kw = dict(max_iter=10, tol_infeas=1e-6, tol_residual=1e-4, use_soc=1, literal_quirks=1)
+    got = {}
+    for side in ("0", "1"):
+        monkeypatch.setenv("SQPHIP_SIDE_TRANS", side)
+        ctx = pkg.Context(lays[0].n, lays[0].m, lays[0].num_linear, lays[0].jrow, lays[0].jcol, lays[0].hrow, lays[0].hcol,
+                          lays[0].xL, lays[0].xU, lays[0].gL, lays[0].gU, pkg.default_options(kkt_mode=2, **kw), batch=16)
+        ctx.acopf_attach(nets[0], lays[0])
+        for b in range(16):
+            ctx.acopf_set_instance(b, nets[b], lays[b])
+        ctx.sqp_reset(); ctx.sqp_run(3)
+        ctx.sqp_run(0)                      # (a second run on the context: its first sweep carries the transitions in line)
+        c = ctx.counters()
+        got[side] = ([ctx.sqp_get(b)["x"] for b in range(16)], [ctx.sqp_qp_log(b) for b in range(16)],
+                     [(ctx.sqp_get(b)["status"], ctx.sqp_get(b)["iter"]) for b in range(16)],
+                     (c["n_qp"], c["n_ipm_iter"], c["n_factor"]), c["n_sweeps"], c["n_groups"])
+        ctx.close()
+    assert got["0"][5] == got["1"][5] == 2
+    assert all(np.array_equal(a, b) for a, b in zip(got["1"][0], got["0"][0]))
+    assert got["1"][1] == got["0"][1] and got["1"][2] == got["0"][2] and got["1"][3] == got["0"][3]
+
+
 def test_speculative_second_shift_changes_nothing_but_the_schedule(monkeypatch):
     """Below ~256 resident instances a sweep factorises the shift delta_w AND the next shift of the inertia-correction
     schedule for every instance whose first shift is a shrink attempt or a retry; k_inertia then books the work exactly
