@@ -134,7 +134,7 @@ void make_lanes(Ctx &C)
         L->is_lane = true;
         L->opt = C.opt; L->n = C.n; L->m = C.m; L->acopf_attached = C.acopf_attached;
         L->mfp_ = C.mfp_;
-        L->trans_period = C.trans_period; L->mf_big_lds = C.mf_big_lds; L->post_split = C.post_split; L->side_mode = C.side_mode;
+        L->trans_period = C.trans_period; L->mf_big_lds = C.mf_big_lds; L->post_split = C.post_split; L->side_mode = C.side_mode; L->spec_tail = C.spec_tail; L->spec_mode0 = C.spec_mode0;
         L->d = group_view(C.d, lo, hi - lo, g);
         // the first group runs on the owner's stream (idle during sqphip_sqp_run): HIP maps streams onto four hardware
         // queues by default, and a fifth stream would share one -- measured: 3131 QP/s with five streams against 5216
@@ -311,7 +311,14 @@ extern "C" int sqphip_create(sqphip_ctx **out, int64_t n, int64_t m, int64_t num
                 // (round 4, monotone sweeps -- shorter, so a saved sweep is worth less against the doubled front work: 256
                 //  resident scenarios 6 541 QP/s with it, 6 627 without; 128: 4 307 / 4 110; on up to 192 instances)
                 d.spec_mode = getenv("SQPHIP_MF_SPEC") ? atoi(getenv("SQPHIP_MF_SPEC")) : (B <= (opt->ipm_corrector ? 256 : 192) && small_arena ? 1 : 0);
-                if (d.spec_mode != 0) {
+                // ... and for larger batches in the TAIL of a run: once most instances of a group have used up their outer iterations
+                // the sweeps are latency-bound again and the stragglers' failed shifts are the critical path (sqp_run_lane switches
+                // it on while at most spec_tail instances of the group have work left; SQPHIP_MF_SPEC_TAIL, 0 = never).  Measured,
+                // driver's command: threshold 0 / 16 / 32 / 48 / 64 / 96 -> 8 992 / 9 036 / 9 052 / 9 031 / 9 049 / 9 016 QP/s at 512 resident
+                // scenarios (1.4 % fewer sweeps, identical work counters), 6 614 / 6 682 / 6 708 / 6 692 / 6 552 / 6 561 at 256
+                C.spec_tail = d.spec_mode == 0 && small_arena ? (getenv("SQPHIP_MF_SPEC_TAIL") ? atoi(getenv("SQPHIP_MF_SPEC_TAIL")) : (getenv("SQPHIP_MF_SPEC") ? 0 : 32)) : 0;
+                C.spec_mode0 = d.spec_mode;
+                if (d.spec_mode != 0 || C.spec_tail > 0) {
                     M.vals1 = C.dalloc<double>((size_t)B * P.nnzK);
                     M.fronts1 = C.dalloc<double>((size_t)B * P.stride);
                 }

@@ -213,6 +213,9 @@ struct Ctx {
     bool side_mode = false, side_on = false;
     hipStream_t side = nullptr;
     hipEvent_t evS[4] = {}, evC[4] = {};
+    // second shift per sweep in the TAIL of a run only (large batches, where it costs throughput while every instance is busy):
+    // on while at most spec_tail instances of the group have work left (sqp_run_lane); 0: off.  spec_mode0: the mode at creation
+    int spec_tail = 0, spec_mode0 = 0;
     int trans_period = 0;           // 0: by group size (3 from 64 instances, 2 from 32, else 1); SQPHIP_TRANS_PERIOD, read at creation
     Timers tm;
     std::vector<void *> allocs;

@@ -113,7 +113,7 @@ static __device__ __forceinline__ double next_shift(double dw, double dw_last)
 // in three); the plain delta_w = 0 of a solve that never needed a correction is not speculated on
 static __device__ __forceinline__ bool mf_speculates(const DV &d, const IpmState &st)
 {
-    return d.sparse && d.mf.fronts1 != nullptr && (st.fac_attempt > 0 || (d.spec_mode == 1 && st.dw > 0.0));
+    return d.sparse && d.mf.fronts1 != nullptr && d.spec_mode != 0 && (st.fac_attempt > 0 || (d.spec_mode == 1 && st.dw > 0.0));
 }
 
 }  // namespace sqphip

@@ -1850,7 +1850,7 @@ void mf_factor(Ctx &C, int want, bool with_rhs, bool values_done)
     hipStream_t s = C.stream;
     static const bool v1 = getenv("SQPHIP_MF_V1") != nullptr;      // cross-check: the plain rank-1 kernel for every front
     const int wr = (int)with_rhs;
-    const int nb = d.mf.fronts1 ? 2 * d.B : d.B;         // with the second candidate the factor side runs over 2 B "instances"
+    const int nb = d.mf.fronts1 && d.spec_mode != 0 ? 2 * d.B : d.B;         // with the second candidate the factor side runs over 2 B "instances"
     // (values_done: the stage kernel that built the right-hand sides has assembled the values too: mf_values_block)
     if (!v1 && !values_done) { C.tm.open(s); hipLaunchKernelGGL(k_mf_values, dim3((d.mf.nnzK + 255) / 256, nb), dim3(256), 0, s, d, want); C.tm.close(KC_VALUES, s); }
     // static front kernels (k_mf_front<T, NW, LDSIMG>) unless SQPHIP_MF_STATIC=0 asks for the generic ones (cross-check)

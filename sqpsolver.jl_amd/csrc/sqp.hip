@@ -585,7 +585,7 @@ static void sqp_run_lane(Ctx &C, int max_outer)
         for (auto &e : C.evC) SQPHIP_HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     d.side = C.side_on ? 2 : 0;
-    struct SideOff { Ctx &C; ~SideOff() { C.d.side = 0; C.side_on = false; } } side_off{C};     // (other entry points run in line)
+    struct SideOff { Ctx &C; ~SideOff() { C.d.side = 0; C.side_on = false; C.d.spec_mode = C.spec_mode0; } } side_off{C};     // (other entry points run in line)
     hipLaunchKernelGGL(k_sqp_budget, dim3(1), dim3(64), 0, s, d, max_outer > 0 ? max_outer : 0x3fffffff);
     hipLaunchKernelGGL(k_sqp_begin, gB, bT, 0, s, d);
     // The "anyone left?" counter of sweep k is read while sweep k + 1 is already queued: the stream never runs dry
@@ -608,6 +608,7 @@ static void sqp_run_lane(Ctx &C, int max_outer)
         SQPHIP_HIP_OK(hipGetLastError());   // a failed launch anywhere in the sweep surfaces here
         const int left = C.h_counters[2 + 2 * (k & 1)];
         C.want_resolve = C.h_counters[3 + 2 * (k & 1)] > 0;      // (refinement solves pending after sweep k: the next sweep queued carries the slot)
+        if (C.spec_tail > 0) d.spec_mode = left <= C.spec_tail ? 1 : 0;     // second shift per sweep in the tail of the run (api.hip)
         if (sweep_log) fprintf(stderr, "%d%c", left, (k % 32) == 31 ? '\n' : ' ');
         return left;
     };

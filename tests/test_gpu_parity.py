@@ -1533,10 +1533,19 @@ def test_speculative_second_shift_changes_nothing_but_the_schedule(monkeypatch):
         got[mode] = ([ctx.sqp_get(b)["x"] for b in range(3)], [ctx.sqp_qp_log(b) for b in range(3)],
                      (c["n_qp"], c["n_ipm_iter"], c["n_factor"]), c["n_sweeps"])
         ctx.close()
-    for mode in ("1", "2"):
+    # ... and switched on in the tail of a run only (large batches: sqp_run_lane, Ctx::spec_tail): off while more than two of
+    # the three instances have work left, on from then on -- the toggle between sweeps changes nothing either
+    monkeypatch.setenv("SQPHIP_MF_SPEC", "0"); monkeypatch.setenv("SQPHIP_MF_SPEC_TAIL", "2")
+    ctx = _run_batch(nets, lays, dict(kw, max_iter=6))
+    c = ctx.counters()
+    got["tail"] = ([ctx.sqp_get(b)["x"] for b in range(3)], [ctx.sqp_qp_log(b) for b in range(3)],
+                   (c["n_qp"], c["n_ipm_iter"], c["n_factor"]), c["n_sweeps"])
+    ctx.close()
+    for mode in ("1", "2", "tail"):
         assert all(np.array_equal(a, b) for a, b in zip(got[mode][0], got["0"][0]))
         assert got[mode][1] == got["0"][1] and got[mode][2] == got["0"][2]
     assert got["1"][3] <= got["2"][3] < got["0"][3]
+    assert got["tail"][3] <= got["0"][3]
 
 
 def test_flat_sparse_products_give_the_fused_stage_bits(monkeypatch):
