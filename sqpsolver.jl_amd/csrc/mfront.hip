@@ -192,11 +192,20 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 // 1 / x by v_rcp_f64 and two Newton steps: a quarter of the dependent instructions of an IEEE division, within one ulp
 // (four of these sit on the critical path of every four-column block).  0 gives inf -> NaN, which k_inertia reports.
+#ifndef SQPHIP_MF_RCP_NR
+#define SQPHIP_MF_RCP_NR 2
+#endif
+#ifndef SQPHIP_MF_LDL4_FAST
+#define SQPHIP_MF_LDL4_FAST 0
+#endif
 __device__ __forceinline__ double mf_rcp(double x)
 {
     double r = __builtin_amdgcn_rcp(x);
     r = fma(fma(-x, r, 1.0), r, r);
-    return fma(fma(-x, r, 1.0), r, r);
+#if SQPHIP_MF_RCP_NR >= 2
+    r = fma(fma(-x, r, 1.0), r, r);
+#endif
+    return r;
 }
 
 __device__ __forceinline__ double mf_readlane(double x, int lane)
@@ -397,9 +406,24 @@ __device__ __forceinline__ MfBlk4 mf_ldl4(double a00, double a10, double a11, do
     double i1 = 0.0, i2 = 0.0, i3 = 0.0, l21 = 0.0, l31 = 0.0, l32 = 0.0;
     const double i0 = mf_rcp(a00);
     const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
+#if SQPHIP_MF_LDL4_FAST
+    // (experiment: the products of a column's entries are formed beside the reciprocal, so that one fma -- not a product and an
+    //  fma -- separates a pivot's reciprocal from the next pivot)
+    {
+        const double p11 = a10 * a10, p21 = a10 * a20, p22 = a20 * a20, p31 = a10 * a30, p32 = a20 * a30, p33 = a30 * a30;
+        a11 = fma(-p11, i0, a11); a21 = fma(-p21, i0, a21); a22 = fma(-p22, i0, a22); a31 = fma(-p31, i0, a31); a32 = fma(-p32, i0, a32); a33 = fma(-p33, i0, a33);
+    }
+    if (bw > 1) {
+        i1 = mf_rcp(a11); l21 = a21 * i1; l31 = a31 * i1;
+        const double q22 = a21 * a21, q32 = a21 * a31, q33 = a31 * a31;
+        a22 = fma(-q22, i1, a22); a32 = fma(-q32, i1, a32); a33 = fma(-q33, i1, a33);
+    }
+    if (bw > 2) { i2 = mf_rcp(a22); l32 = a32 * i2; a33 = fma(-(a32 * a32), i2, a33); }
+#else
     a11 -= l10 * a10; a21 -= l10 * a20; a22 -= l20 * a20; a31 -= l10 * a30; a32 -= l20 * a30; a33 -= l30 * a30;
     if (bw > 1) { i1 = mf_rcp(a11); l21 = a21 * i1; l31 = a31 * i1; a22 -= l21 * a21; a32 -= l21 * a31; a33 -= l31 * a31; }
     if (bw > 2) { i2 = mf_rcp(a22); l32 = a32 * i2; a33 -= l32 * a32; }
+#endif
     if (bw > 3) i3 = mf_rcp(a33);
     MfBlk4 B;
     B.i0 = i0; B.i1 = i1; B.i2 = i2; B.i3 = i3;
