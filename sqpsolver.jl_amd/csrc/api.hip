@@ -139,6 +139,20 @@ void make_lanes(Ctx &C)
         // the first group runs on the owner's stream (idle during sqphip_sqp_run): HIP maps streams onto four hardware
         // queues by default, and a fifth stream would share one -- measured: 3131 QP/s with five streams against 5216
         // with four (or with GPU_MAX_HW_QUEUES=8)
+        // (experiment, SQPHIP_CU_PARTITION = 1 | 2: every group on a stream restricted to a quarter of the CUs -- 1: a contiguous
+        //  quarter of the mask bits, 2: every G-th bit -- so that one group's throughput-bound launches cannot slow another group's
+        //  latency-bound ones; measured: profiles/r04_ab_experiments.txt)
+        static const int cu_part = getenv("SQPHIP_CU_PARTITION") ? atoi(getenv("SQPHIP_CU_PARTITION")) : 0;
+        if (cu_part != 0) {
+            hipDeviceProp_t prop; SQPHIP_HIP_OK(hipGetDeviceProperties(&prop, C.opt.device));
+            const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+            std::vector<uint32_t> mask(words, 0u);
+            for (int c = 0; c < ncu; ++c) {
+                const bool mine = cu_part == 1 ? (c * G / ncu == g) : (c % G == g);
+                if (mine) mask[c / 32] |= 1u << (c % 32);
+            }
+            SQPHIP_HIP_OK(hipExtStreamCreateWithCUMask(&L->stream, (uint32_t)words, mask.data()));
+        } else
         if (g == 0) { L->stream = C.stream; L->owns_stream = false; }
         else SQPHIP_HIP_OK(hipStreamCreateWithFlags(&L->stream, getenv("SQPHIP_STREAM_BLOCKING") ? hipStreamDefault : hipStreamNonBlocking));
         SQPHIP_HIP_OK(hipHostMalloc((void **)&L->h_counters, 8 * sizeof(int)));
