@@ -374,8 +374,10 @@ class QpSolver:
         it, nf = C.c_int(), C.c_int()
         el = C.c_double()
         lib().ora_qp_stats(self.h, C.byref(it), C.byref(nf), C.byref(el))
+        rule, err = C.c_int(), C.c_double()
+        lib().ora_qp_termination(C.c_void_p(self.h), C.byref(rule), C.byref(err))     # how the interior-point run ended (qp_ipm.c)
         out = dict(status=st, p=p, lam=lam, mult_x_U=mu_u, mult_x_L=mu_l,
-                   ipm_iters=it.value, n_factor=nf.value, elastic=el.value)
+                   ipm_iters=it.value, n_factor=nf.value, elastic=el.value, term_rule=rule.value, scaled_error=err.value)
         if want_slack:
             out["slack"] = slack
         return out

@@ -437,6 +437,12 @@ def _compare_qp(ro, rg, mult_tol=TOL, p_tol=TOL):
     if p_tol > TOL and ro["status"] == O.MOI_LOCALLY_SOLVED:  # p compared loosely: the optimal value must still agree
         vo, vg = float(np.sum(ro["slack"])), float(np.sum(rg["slack"]))
         assert abs(vg - vo) <= TOL * max(1.0, abs(vo))
+    if ro["status"] == O.MOI_LOCALLY_SOLVED and "term_rule" in rg and "term_rule" in ro and p_tol <= TOL:
+        # how the interior-point run ended (sqphip_qp_termination / ora_qp_termination): the same rule on both sides -- 0 = the
+        # scaled error reached ipm_tol, 1 .. 3 = an acceptable-termination counter -- and, by that rule, an error below its level
+        assert rg["term_rule"] == ro["term_rule"], (rg["term_rule"], ro["term_rule"], rg["scaled_error"], ro["scaled_error"])
+        level = (1e-9, 1e-7, 1e-6, 1e-5)[rg["term_rule"]]
+        assert rg["scaled_error"] <= level * 1.0000001 and ro["scaled_error"] <= level * 1.0000001
     if ro["status"] == O.MOI_LOCALLY_SOLVED:
         if p_tol > TOL:      # optimal face + jammed ratio tests: see the note above _tols (hs071 FR: 18 vs 13 iterations)
             assert abs(rg["ipm_iters"] - ro["ipm_iters"]) <= max(2, ro["ipm_iters"] // 2)
