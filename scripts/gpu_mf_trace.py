@@ -64,6 +64,10 @@ if L.sqphip_mf_trace2_read(buf2.ctypes.data_as(C.POINTER(C.c_longlong)), ns) == 
         if t[0] == 0: continue
         seg = [t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5], (t[9] - t[6]) if t[9] > 0 else -1, t[7] - t[2], t[8] - t[7], t[10] - t[8]]
         print(f"  front {srow:4d}: " + " ".join(f"{int(v):7d}" for v in seg))
+        if t[11] > 0 and t[15] > 0:      # first 4 x 4 block of the diagonal tile: block in LDS -> read | LDL^T | rows x inverse | (issue) | update
+            print("              first 4 x 4 block: start -> LDS written+sync " + str(int(t[11] - t[2])) + " | ten reads " + str(int(t[12] - t[11]))
+                  + " | mf_ldl4 " + str(int(t[13] - t[12])) + " | apply4 + ic + product " + str(int(t[14] - t[13])) + " | mfma " + str(int(t[15] - t[14]))
+                  + " | rest of the tile (three more blocks, records, tile out) " + str(int(t[3] - t[15])))
 
 # the four-wave solve routines (thread 0): forward: loads issued | barrier | gather | 16-column blocks | rows below ; backward likewise
 buf3 = np.zeros((ns, 16), dtype=np.int64)

@@ -1,0 +1,21 @@
+#!/bin/bash
+# lane swaps + readlane in the static front kernels (default build) against the shuffle / LDS paths (probe build), with the
+# static kernels from four tile rows on (round-3 rule) and from one / two
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+run() { # args... -- env...
+  A=$1; shift
+  out=$(env "$@" timeout -k 10 400 python bench.py --quick $A 2>/dev/null | tail -1)
+  python3 - "$A" "$*" "$out" <<'PY'
+import json,sys
+d=json.loads(sys.argv[3]); c=d["config"]
+print(f"{sys.argv[1]} {sys.argv[2]}: {d['value']:.1f} sweeps {c['sweeps']} fac/qp {c['factorisations_per_qp']:.2f} qp {c['qp_solved']} fac {c['kkt_factorisations']}", flush=True)
+PY
+}
+P=SQPHIP_SO=scripts/probes/libsqphip_shfl.so
+for A in "--steps 20 --warmup 5 --batch 512" "--steps 20 --warmup 5 --batch 64" "--workload case14" "--workload case1354" "--workload case9241"; do
+  run "$A" X=0
+  run "$A" $P
+  run "$A" SQPHIP_MF_STATIC_MIN=2
+  run "$A" $P SQPHIP_MF_STATIC_MIN=2
+  run "$A" SQPHIP_MF_STATIC_MIN=1
+done

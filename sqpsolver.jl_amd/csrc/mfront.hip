@@ -214,6 +214,31 @@ __device__ __forceinline__ double mf_readlane(double x, int lane)
     return __hiloint2double(hi, lo);
 }
 
+// Row broadcasts of a wave seen as four rows of sixteen lanes (lane = l15 + 16 l4): r_k[lane] = x[l15 + 16 k].  gfx950 has two
+// VALU lane swaps for this -- v_permlane16_swap (odd rows of one operand against the even rows of the other) and
+// v_permlane32_swap (upper half against lower half) --: (x, x) -> (r0 r0 r2 r2), (r1 r1 r3 r3) -> (r0 r0 r0 r0), (r2 ..), (r1 ..):
+// six VALU instructions for the three rows of a double where __shfl costs three ds_bpermute round trips through the LDS
+// pipe (~120 cycles each; round 4, cycle stamps of the first 4 x 4 block of a diagonal tile: rows x inverse 364 -> see
+// profiles/r04_front_diag_stamps.txt).  Same values, so the same bits.  SQPHIP_MF_SHFL=1 (build) keeps the shuffles.
+#ifndef SQPHIP_MF_SHFL
+#define SQPHIP_MF_SHFL 0
+#endif
+struct MfRows { double r0, r1, r2; };
+__device__ __forceinline__ double mf_hilo(unsigned hi, unsigned lo) { return __hiloint2double((int)hi, (int)lo); }
+__device__ __forceinline__ MfRows mf_rows3(double x, int l15)
+{
+#if SQPHIP_MF_SHFL
+    return {__shfl(x, l15), __shfl(x, l15 + 16), __shfl(x, l15 + 32)};
+#else
+    (void)l15;
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto pl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), ph = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const auto al = __builtin_amdgcn_permlane32_swap(pl[0], pl[0], false, false), ah = __builtin_amdgcn_permlane32_swap(ph[0], ph[0], false, false);
+    const auto bl = __builtin_amdgcn_permlane32_swap(pl[1], pl[1], false, false), bh = __builtin_amdgcn_permlane32_swap(ph[1], ph[1], false, false);
+    return {mf_hilo(ah[0], al[0]), mf_hilo(bh[0], bl[0]), mf_hilo(ah[1], al[1])};
+#endif
+}
+
 template <int NW, int MAXT, bool LDSIMG>
 __global__ __launch_bounds__(64 * NW) void k_mf_factor2(DV d, int sbegin, int want, int with_rhs, int Tl)
 {
@@ -330,8 +355,8 @@ __global__ __launch_bounds__(64 * NW) void k_mf_factor2(DV d, int sbegin, int wa
             for (int q = 0; q < MAXT; ++q)
                 if (tj_[q] == tk && ti_[q] >= 0) {
                     double x = acc[q][rr0];
-                    x -= __shfl(x, l15) * lc0;
-                    x -= __shfl(x, l15 + 16) * lc1;
+                    x -= __shfl(x, l15) * lc0;       // (the lane swaps of mf_rows3 were measured here too: row by row, each broadcast
+                    x -= __shfl(x, l15 + 16) * lc1;  //  behind the update before it, they cost this kernel a quarter of its speed)
                     x -= __shfl(x, l15 + 32) * lc2;
                     acc[q][rr0] = x;
                     const int row = 16 * ti_[q] + l15;
@@ -448,7 +473,8 @@ __device__ __forceinline__ double mf_sel_ic(const MfLaneSel &S, const MfBlk4 &B)
 }
 __device__ __forceinline__ double mf_apply4(double x, int l15, const MfLaneSel &S, const MfBlk4 &B)
 {
-    const double v0 = __shfl(x, l15), v1 = __shfl(x, l15 + 16), v2 = __shfl(x, l15 + 32);
+    const MfRows V = mf_rows3(x, l15);
+    const double v0 = V.r0, v1 = V.r1, v2 = V.r2;
     const double c0 = fma(S.s3, B.m30, fma(S.s2, B.m20, S.s1 * B.m10));
     const double c1 = fma(S.s3, B.m31, S.s2 * B.m21);
     const double c2 = S.s3 * B.m32;
@@ -538,17 +564,41 @@ __device__ __forceinline__ void mf_front_elim(MfAcc<T, NW, W> &A, int nc, double
                 if (4 * sub >= live) break;
                 const int bw = live - 4 * sub < 4 ? live - 4 * sub : 4, b0 = 4 * sub;
                 const double dv = dt[sub];
+                // the 4 x 4 block to every lane: element (b0 + r, b0 + c) sits in lane (b0 + r) + 16 c of dv -- ten v_readlane pairs at
+                // constant lanes (round 4; through the wave's LDS scratch before: write, wave barrier, ten reads, wave barrier =
+                // 408 of the ~1 330 cycles of a block; SQPHIP_MF_SHFL=1 keeps that path)
+#if SQPHIP_MF_SHFL
                 dsc[lane] = dv;
                 wave_sync_lds();
+                if (tk == 0 && sub == 0) { MF_TRW(11) }
                 const double a00 = dsc[b0], a10 = dsc[b0 + 1], a11 = dsc[b0 + 17], a20 = dsc[b0 + 2], a21 = dsc[b0 + 18],
                              a22 = dsc[b0 + 34], a30 = dsc[b0 + 3], a31 = dsc[b0 + 19], a32 = dsc[b0 + 35], a33 = dsc[b0 + 51];
                 wave_sync_lds();
+#else
+                if (tk == 0 && sub == 0) { MF_TRW(11) }
+                const double a00 = mf_readlane(dv, b0), a10 = mf_readlane(dv, b0 + 1), a11 = mf_readlane(dv, b0 + 17),
+                             a20 = mf_readlane(dv, b0 + 2), a21 = mf_readlane(dv, b0 + 18), a22 = mf_readlane(dv, b0 + 34),
+                             a30 = mf_readlane(dv, b0 + 3), a31 = mf_readlane(dv, b0 + 19), a32 = mf_readlane(dv, b0 + 35),
+                             a33 = mf_readlane(dv, b0 + 51);
+#endif
+#ifdef SQPHIP_MF_TRACE
+                if (tk == 0 && sub == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); MF_TRW(12) }
+#endif
                 const MfBlk4 B = mf_ldl4(a00, a10, a11, a20, a21, a22, a30, a31, a32, a33, bw);
+#ifdef SQPHIP_MF_TRACE
+                if (tk == 0 && sub == 0) { double tdep = B.m30; asm volatile("v_mov_b64 %0, %0" : "+v"(tdep)); MF_TRW(13) }
+#endif
                 const double x = mf_apply4(dv, l15, LS, B);
                 const double ic = mf_sel_ic(LS, B);
                 dt[sub] = x;
                 ls[sub] = x * ic;
+#ifdef SQPHIP_MF_TRACE
+                if (tk == 0 && sub == 0) { double tdep = ls[sub]; asm volatile("v_mov_b64 %0, %0" : "+v"(tdep)); MF_TRW(14) }
+#endif
                 dt = __builtin_amdgcn_mfma_f64_16x16x4f64(l15 >= b0 + 4 ? -ls[sub] : 0.0, x, dt, 0, 0, 0);
+#ifdef SQPHIP_MF_TRACE
+                if (tk == 0 && sub == 0) { double tdep = dt[1]; asm volatile("v_mov_b64 %0, %0" : "+v"(tdep)); MF_TRW(15) }
+#endif
                 if (lane == 0) {
                     double *o = rec + 10 * sub;
                     o[0] = B.i0; o[1] = B.i1; o[2] = B.i2; o[3] = B.i3; o[4] = B.m10; o[5] = B.m20; o[6] = B.m21; o[7] = B.m30;
