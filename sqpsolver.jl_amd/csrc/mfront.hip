@@ -223,6 +223,9 @@ __device__ __forceinline__ double mf_readlane(double x, int lane)
 #ifndef SQPHIP_MF_SHFL
 #define SQPHIP_MF_SHFL 0
 #endif
+#ifndef SQPHIP_MF_EARLY_STORE
+#define SQPHIP_MF_EARLY_STORE 1      // the level launches of the static front kernels store L step by step (mf_front_elim, EARLY), from five tile rows on
+#endif
 struct MfRows { double r0, r1, r2; };
 __device__ __forceinline__ double mf_hilo(unsigned hi, unsigned lo) { return __hiloint2double((int)hi, (int)lo); }
 __device__ __forceinline__ MfRows mf_rows3(double x, int l15)
@@ -537,8 +540,53 @@ __device__ __forceinline__ void lds_barrier()
 }
 template <bool LDSBAR> __device__ __forceinline__ void mf_elim_barrier() { if constexpr (LDSBAR) lds_barrier(); else __syncthreads(); }
 
-template <int T, int NW, int W, bool LDSIMG, bool LDSBAR = false>
-__device__ __forceinline__ void mf_front_elim(MfAcc<T, NW, W> &A, int nc, double *lds, int lane, int trs)
+// L part (columns below nc) of tile column tk of this wave's tiles, out of the registers: final once step tk of the elimination
+// has solved the tiles below the diagonal tile (EARLY, below).  The expressions are those of mf_front_store.
+template <int T, int NW, int W, bool LDSIMG>
+__device__ __forceinline__ void mf_front_store_col(const MfAcc<T, NW, W> &A, int tk, double *G, int ld, int fs, int nc, int with_rhs,
+                                                   const double *lds, double *vv, int lane)
+{
+    const auto &acc = A.v;
+    constexpr int R = 16 * T;
+    constexpr int U = (LDSIMG ? R * R : 0) > 16 * R ? R * R : 16 * R;
+    constexpr int NROWS = MfTileSet<T, NW, W>::NROWS;
+    const double *dl = lds + U + 256 + 40;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    int o = 0;
+#pragma unroll
+    for (int s = 0; s < NROWS; ++s) {
+        const int ti = W + s * NW;
+        if (ti >= tk) {
+            const bool inside = ti > tk && 16 * ti + 15 < fs;
+            if (inside && 16 * tk + 15 < nc) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int col = 16 * tk + l4 + 4 * rr;
+                    G[(long)col * ld + 16 * ti + l15] = acc[o + tk][rr] * dl[col];
+                }
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int col = 16 * tk + l4 + 4 * rr, row = 16 * ti + l15;
+                    const double v = acc[o + tk][rr];
+                    if (col < nc) {
+                        if (row > col && row < fs) G[(long)col * ld + row] = v * dl[col];
+                        else if (row == fs && with_rhs) vv[col] = v * dl[col];
+                    }
+                }
+            }
+        }
+        o += ti + 1;
+    }
+}
+
+// EARLY (round 4): the L part of a tile column goes to the arena as soon as its step of the elimination is through, instead of
+// in one burst behind the last step -- the stores (5 000 - 7 000 cycles of issue per 80-column front: cycle stamps) then overlap
+// with the remaining steps.  The barriers of the loop must then wait for LDS traffic only (a __syncthreads() waits for the
+// stores in flight too).  Same values to the same places.
+template <int T, int NW, int W, bool LDSIMG, bool LDSBAR = false, bool EARLY = false>
+__device__ __forceinline__ void mf_front_elim(MfAcc<T, NW, W> &A, int nc, double *lds, int lane, int trs, double *G = nullptr, int ld = 0,
+                                              int fs = 0, int with_rhs = 0, double *vv = nullptr)
 {
     auto &acc = A.v;
     constexpr int R = 16 * T;
@@ -611,7 +659,7 @@ __device__ __forceinline__ void mf_front_elim(MfAcc<T, NW, W> &A, int nc, double
             acc[od] = dt;
         }
         if (tk == 0) { MF_TRW(3) }
-        mf_elim_barrier<LDSBAR>();
+        mf_elim_barrier<LDSBAR || EARLY>();
         if (tk == 0) { MF_TRW(4) }
         // B. my tiles below the diagonal tile: sixteen columns of every row; the rows of L go to LDS, X = L D stays here
         {
@@ -640,7 +688,7 @@ __device__ __forceinline__ void mf_front_elim(MfAcc<T, NW, W> &A, int nc, double
             }
         }
         if (tk == 0) { MF_TRW(5) }
-        mf_elim_barrier<LDSBAR>();
+        mf_elim_barrier<LDSBAR || EARLY>();
         if (tk == 0) { MF_TRW(6) }
         // C. rank-16 update of my tiles to the right
         {
@@ -661,6 +709,7 @@ __device__ __forceinline__ void mf_front_elim(MfAcc<T, NW, W> &A, int nc, double
                 o += ti + 1;
             }
         }
+        if constexpr (EARLY) mf_front_store_col<T, NW, W, LDSIMG>(A, tk, G, ld, fs, nc, with_rhs, lds, vv, lane);
     }
 }
 
@@ -668,7 +717,7 @@ __device__ __forceinline__ void mf_front_elim(MfAcc<T, NW, W> &A, int nc, double
 // hands the block to the parent front in registers instead: mf_front_scatter)
 // CB / ldcb: where the contribution block goes -- entry (row, col) of the front to CB[col * ldcb + row]: the front's own
 // storage in the arena (CB = G, ldcb = ld), or the spine kernel's LDS staging area in block coordinates
-template <int T, int NW, int W, bool LDSIMG>
+template <int T, int NW, int W, bool LDSIMG, bool EARLY = false>
 __device__ __forceinline__ void mf_front_store(const MfAcc<T, NW, W> &A, double *G, int ld, int fs, int nc,
                                                int with_rhs, double *CB, int ldcb, const double *lds, double *dinv, double *vv, int lane)
 {
@@ -688,10 +737,12 @@ __device__ __forceinline__ void mf_front_store(const MfAcc<T, NW, W> &A, double 
             // eliminated (L) or all kept (contribution block) need no test per lane: most tiles of a large front
             const bool inside = ti > tj && 16 * ti + 15 < fs;
             if (inside && 16 * tj + 15 < nc) {
+                if constexpr (!EARLY) {          // (EARLY: mf_front_store_col has written the L part step by step)
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int col = 16 * tj + l4 + 4 * rr;
-                    G[(long)col * ld + 16 * ti + l15] = acc[o + tj][rr] * dl[col];
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int col = 16 * tj + l4 + 4 * rr;
+                        G[(long)col * ld + 16 * ti + l15] = acc[o + tj][rr] * dl[col];
+                    }
                 }
             } else if (inside && 16 * tj >= nc) {
 #pragma unroll
@@ -702,8 +753,10 @@ __device__ __forceinline__ void mf_front_store(const MfAcc<T, NW, W> &A, double 
                     const int col = 16 * tj + l4 + 4 * rr, row = 16 * ti + l15;
                     const double v = acc[o + tj][rr];
                     if (col < nc) {
-                        if (row > col && row < fs) G[(long)col * ld + row] = v * dl[col];
-                        else if (row == fs && with_rhs) vv[col] = v * dl[col];
+                        if constexpr (!EARLY) {
+                            if (row > col && row < fs) G[(long)col * ld + row] = v * dl[col];
+                            else if (row == fs && with_rhs) vv[col] = v * dl[col];
+                        }
                     } else if (col < fs && row >= col && row <= fs) CB[(long)col * ldcb + row] = v;
                 }
             }
@@ -713,7 +766,7 @@ __device__ __forceinline__ void mf_front_store(const MfAcc<T, NW, W> &A, double 
     if (W == 0) for (int k = lane; k < nc; k += 64) dinv[k] = dl[k];
 }
 
-template <int T, int NW, int W, bool LDSIMG, bool LDSBAR = false>
+template <int T, int NW, int W, bool LDSIMG, bool LDSBAR = false, bool EARLY = false>
 __device__ __forceinline__ void mf_front_wave(const double *F, int LD, double *G, int ld, int fs, int nc, int with_rhs,
                                               double *lds, double *dinv, double *vv, int lane, int trs, double *CB, int ldcb)
 {
@@ -721,13 +774,15 @@ __device__ __forceinline__ void mf_front_wave(const double *F, int LD, double *G
     MfAcc<T, NW, W> acc;
     mf_front_load<T, NW, W, LDSIMG>(acc, F, LD, fs, lane);
     MF_TRW(1)
-    mf_elim_barrier<LDSBAR>();            // the image is dead from here on: its LDS carries the rows of L
-    MF_TRW(2)
-    mf_front_elim<T, NW, W, LDSIMG, LDSBAR>(acc, nc, lds, lane, trs);
-    MF_TRW(7)
+    // the image is dead from here on: its LDS carries the rows of L -- and, EARLY with the image in the arena, its storage the
+    // columns of L: this barrier waits for the loads of the image too (the level kernels' __syncthreads())
     mf_elim_barrier<LDSBAR>();
+    MF_TRW(2)
+    mf_front_elim<T, NW, W, LDSIMG, LDSBAR, EARLY>(acc, nc, lds, lane, trs, G, ld, fs, with_rhs, vv);
+    MF_TRW(7)
+    mf_elim_barrier<LDSBAR || EARLY>();
     MF_TRW(8)
-    mf_front_store<T, NW, W, LDSIMG>(acc, G, ld, fs, nc, with_rhs, CB, ldcb, lds, dinv, vv, lane);
+    mf_front_store<T, NW, W, LDSIMG, EARLY>(acc, G, ld, fs, nc, with_rhs, CB, ldcb, lds, dinv, vv, lane);
     MF_TRW(10)
 }
 
@@ -735,7 +790,7 @@ template <int T, int NW, int W, bool LDSIMG>
 __device__ __forceinline__ void mf_front_dispatch(int wave, const double *F, int LD, double *G, int ld, int fs, int nc,
                                                   int with_rhs, double *lds, double *dinv, double *vv, int lane, int trs)
 {
-    if (wave == W) mf_front_wave<T, NW, W, LDSIMG>(F, LD, G, ld, fs, nc, with_rhs, lds, dinv, vv, lane, trs, G, ld);
+    if (wave == W) mf_front_wave<T, NW, W, LDSIMG, false, (SQPHIP_MF_EARLY_STORE != 0 && T >= 5)>(F, LD, G, ld, fs, nc, with_rhs, lds, dinv, vv, lane, trs, G, ld);
     else if constexpr (W + 1 < NW) mf_front_dispatch<T, NW, W + 1, LDSIMG>(wave, F, LD, G, ld, fs, nc, with_rhs, lds, dinv, vv, lane, trs);
 }
 
