@@ -639,6 +639,7 @@ static void sqp_run_lane(Ctx &C, int max_outer)
     for (auto &e : ev) hipEventDestroy(e);
     if (const char *e = getenv("SQPHIP_EMPTY_SWEEPS")) {      // experiment: wall time of a sweep with every kernel gated off
         const int n = atoi(e);
+        C.side_on = false; d.side = 0;       // (the experiment's sweeps run in line)
         const auto t0 = std::chrono::steady_clock::now();
         for (int k = 0; k < n; ++k) ipm_sweep(C, true);
         SQPHIP_HIP_OK(hipStreamSynchronize(s));
