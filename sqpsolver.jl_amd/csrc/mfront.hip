@@ -2011,7 +2011,11 @@ void mf_factor(Ctx &C, int want, bool with_rhs, bool values_done)
         const bool nw8 = !(getenv("SQPHIP_MF_NW8") && atoi(getenv("SQPHIP_MF_NW8")) == 0);
         const int nw4 = L.count <= 8 ? (getenv("SQPHIP_MF_NW4") ? atoi(getenv("SQPHIP_MF_NW4")) : 3) : 0;
         const bool big_img = C.mf_big_lds && !(getenv("SQPHIP_MF_BIG_LDSIMG") && atoi(getenv("SQPHIP_MF_BIG_LDSIMG")) == 0);     // (read per call: tests flip it)
-        if (!stat || T > 8 || T < stat_min) {
+        // (round 4: nine to twelve tile rows too -- the fronts of 129 .. 192 rows of the 1354- and 9241-bus shapes --, eight waves,
+        //  image in the arena: 1354 buses 549 -> 557 QP/s, 9241 buses 28.5 -> 29.2; SQPHIP_MF_STATIC_MAX = 8 gives them back to the
+        //  generic kernel)
+        static const int stat_max = getenv("SQPHIP_MF_STATIC_MAX") ? atoi(getenv("SQPHIP_MF_STATIC_MAX")) : 12;
+        if (!stat || T > stat_max || T > 12 || T < stat_min) {
             if (T <= 2) MF_GENERIC(1, 3, true);
             else if (T <= 4) MF_GENERIC(2, 5, true);
             else if (T <= 5) MF_GENERIC(4, 4, true);
@@ -2030,7 +2034,11 @@ void mf_factor(Ctx &C, int want, bool with_rhs, bool values_done)
         //  one workgroup per CU is all there is anyway: +0.3 % on 512 x IEEE-118; SQPHIP_MF_BIG_LDSIMG=0: image in the arena)
         case 6: if (big_img && L.count <= 8) { if (nw8) MF_STATIC(6, 8, true); else MF_STATIC(6, 4, true); } else MF_STATIC(6, 4, false); break;
         case 7: if (big_img && L.count <= 8) { if (nw8) MF_STATIC(7, 8, true); else MF_STATIC(7, 4, true); } else MF_STATIC(7, 4, false); break;
-        default: if (big_img && L.count <= 8) { if (nw8) MF_STATIC(8, 8, true); else MF_STATIC(8, 4, true); } else MF_STATIC(8, 4, false); break;
+        case 8: if (big_img && L.count <= 8) { if (nw8) MF_STATIC(8, 8, true); else MF_STATIC(8, 4, true); } else MF_STATIC(8, 4, false); break;
+        case 9: MF_STATIC(9, 8, false); break;
+        case 10: MF_STATIC(10, 8, false); break;
+        case 11: MF_STATIC(11, 8, false); break;
+        default: MF_STATIC(12, 8, false); break;
         }
 #undef MF_GENERIC
 #undef MF_STATIC

@@ -157,7 +157,7 @@ def test_multifrontal_kernels_match_host_reference(case, cond):
 def test_every_front_kernel_variant_matches_the_host_reference(env, monkeypatch):
     """The kernels the default dispatch does not pick: the static front kernels k_mf_front<T, ...> for fronts of one to
     three tile rows (default: from four on), the generic k_mf_factor2 kernels for every height (default: up to three,
-    and from nine on), and round 2's solve kernels -- the top of the assembly tree by k_mf_solve_top where the streamed
+    and from thirteen on; round 4: the static kernels run nine to twelve tile rows too), and round 2's solve kernels -- the top of the assembly tree by k_mf_solve_top where the streamed
     k_mf_solve_top2 is the default (IEEE-14 / IEEE-118: every top front within 128 rows and 84 columns; the 1354 shape runs
     k_mf_solve_top either way), the level launches by k_mf_fwd / k_mf_bwd instead of the LDS-staged k_mf_fwd2 / k_mf_bwd2;
     the static kernels of the narrow levels on two / four waves instead of four / eight -- same comparison as above on the
