@@ -22,7 +22,9 @@ _lib = None
 # per-file extra flags.  mfront.hip: keep the MFMA accumulators of the front kernels in VGPRs -- the elimination works on
 # the accumulator tiles with ordinary vector instructions between the MFMAs, and with the accumulators homed in AGPRs
 # the compiler copied all of them (72 v_accvgpr_read per four-column step) in and out at every step
-EXTRA_FLAGS = {"mfront.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+# mfront.hip: MFMA accumulators in VGPRs; and a pragma-unroll budget that covers the static front kernels of nine to twelve tile
+# rows (at the default budget some of their tile loops stay rolled and the tiles they index move to scratch: 416 - 544 B per lane)
+EXTRA_FLAGS = {"mfront.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-mllvm", "-pragma-unroll-threshold=131072"]}
 _OBJ = os.path.join(_CSRC, "build")
 
 
